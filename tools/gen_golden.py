@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by EXECUTING THE REFERENCE'S OWN CODE (this container only).
+
+The reference (read-only at /root/reference) cannot be imported as shipped: gpytorch,
+gym and imageio are absent and cannot be installed.  They contain no
+arithmetic used on the hot path except gpytorch's kernel evaluation
+(models/gp_model.py:425), so this tool registers inert, name-only placeholder modules
+for them and then runs, verbatim:
+
+  * calculate_factorizations            (gp_model.py:400-431)  fed a closed-form K
+  * predict_next_state_change           (gp_model.py:112-180)
+  * predict_trajectory                  (gp_model.py:60-110)
+  * SetpointStateRewardMapper           (setpoint_distance_reward_mapper.py)
+  * Normalization/DerivativeActionMapper
+  * GpMpcController.compute_mean_lcb_trajectory / _get_optimal_actions (gp_mpc_controller.py)
+
+Only data (inputs + expected outputs) is written to tests/golden/.  Nothing from the
+reference is copied.  Re-run:  python tools/gen_golden.py
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+
+
+def _install_placeholders():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Inert:                                   # no arithmetic anywhere in here
+        def __init__(self, *a, **k):
+            pass
+
+    gp = mod("gpytorch")
+    gp.models = mod("gpytorch.models", ExactGP=_Inert)
+    gp.likelihoods = mod("gpytorch.likelihoods", GaussianLikelihood=_Inert)
+    gp.kernels = mod("gpytorch.kernels", ScaleKernel=_Inert, RBFKernel=_Inert)
+    gp.means = mod("gpytorch.means", ZeroMean=_Inert)
+    gp.constraints = mod("gpytorch.constraints", Interval=_Inert)
+    gp.mlls = mod("gpytorch.mlls", ExactMarginalLogLikelihood=_Inert)
+    gp.distributions = mod("gpytorch.distributions", MultivariateNormal=_Inert)
+    gym = mod("gym")
+    gym.core = mod("gym.core", Env=_Inert)
+    gym.spaces = mod("gym.spaces", Box=_Inert)
+    gym.utils = mod("gym.utils", seeding=types.SimpleNamespace())
+    gym.wrappers = mod("gym.wrappers")
+    gym.wrappers.monitoring = mod("gym.wrappers.monitoring")
+    gym.wrappers.monitoring.video_recorder = mod("gym.wrappers.monitoring.video_recorder", VideoRecorder=_Inert)
+    mod("imageio")
+
+
+_install_placeholders()
+sys.path.insert(0, REF)
+import torch  # noqa: E402
+
+import rl_gp_mpc  # noqa: E402,F401  (sets torch default dtype to float64: total_config.py:11)
+from rl_gp_mpc.control_objects.models import gp_model as ref_gp  # noqa: E402
+from rl_gp_mpc.control_objects.controllers.gp_mpc_controller import GpMpcController as RefCtrl  # noqa: E402
+from rl_gp_mpc.control_objects.states_reward_mappers.setpoint_distance_reward_mapper import SetpointStateRewardMapper  # noqa: E402
+from rl_gp_mpc.control_objects.actions_mappers.normalization_action_mapper import NormalizationActionMapper  # noqa: E402
+from rl_gp_mpc.control_objects.actions_mappers.derivative_action_mapper import DerivativeActionMapper  # noqa: E402
+from rl_gp_mpc.control_objects.utils.pytorch_utils import Clamp  # noqa: E402
+from rl_gp_mpc.config_classes.reward_config import RewardConfig  # noqa: E402
+from rl_gp_mpc.config_classes.actions_config import ActionsConfig  # noqa: E402
+
+from oracle import synth  # noqa: E402
+from oracle.gpmpc_oracle import rbf_ard_gram  # noqa: E402
+
+
+class _DuckKernel:
+    def __init__(self, K):
+        self._K = K
+
+    def __call__(self, x):
+        return self
+
+    def evaluate(self):
+        return self._K
+
+
+class _DuckModel:
+    """Stands in for ExactGPModelMonoTask: supplies K (closed form) and the three
+    hyper-parameter reads the hot path makes (gp_model.py:189-190,427)."""
+
+    def __init__(self, K, ls, outputscale, noise):
+        self.covar_module = _DuckKernel(torch.tensor(K))
+        self.covar_module.base_kernel = types.SimpleNamespace(lengthscale=torch.tensor(ls)[None, :])
+        self.covar_module.outputscale = torch.tensor(outputscale)
+        self.likelihood = types.SimpleNamespace(noise=torch.tensor([noise]))
+
+
+def ref_model(w):
+    """A reference GpStateTransitionModel with its cached attributes produced by the
+    reference's own prepare_inference (gp_model.py:182-191)."""
+    N, D, A, E, H, B = w.dims
+    K = rbf_ard_gram(w.X, w.lengthscales, w.outputscales)
+    m = object.__new__(ref_gp.GpStateTransitionModel)
+    m.dim_state, m.dim_action, m.dim_input = D, A, E
+    m.config = types.SimpleNamespace(include_time_model=w.include_time)
+    m.models = [_DuckModel(K[a], w.lengthscales[a], w.outputscales[a], w.noises[a]) for a in range(D)]
+    m.prepare_inference(torch.tensor(w.X), torch.tensor(w.Y))
+    return m
+
+
+def ref_reward_mapper(w, clip=False, use_constraints=False, state_min=None, state_max=None):
+    D = w.Y.shape[1]
+    cfg = RewardConfig(
+        target_state_norm=list(w.target[:D]), weight_state=list(np.diag(w.W)[:D]),
+        weight_state_terminal=list(np.diag(w.W_T)), target_action_norm=list(w.target[D:]),
+        weight_action=list(np.diag(w.W)[D:]), exploration_factor=w.kappa,
+        use_constraints=use_constraints,
+        state_min=list(state_min) if state_min is not None else [0.0] * D,
+        state_max=list(state_max) if state_max is not None else [1.0] * D,
+        clip_lower_bound_cost_to_0=clip)
+    return SetpointStateRewardMapper(cfg), cfg
+
+
+def inputs_dict(w):
+    return dict(X=w.X, Y=w.Y, lengthscales=w.lengthscales, outputscales=w.outputscales, noises=w.noises,
+                actions=w.actions, mu0=w.mu0, S0=w.S0, include_time=np.array(w.include_time),
+                time0=np.array(w.time0), target=w.target, W=w.W, W_T=w.W_T, kappa=np.array(w.kappa))
+
+
+def traj_case(name, w, with_iK=False, clip=False, use_constraints=False, state_min=None, state_max=None):
+    m = ref_model(w)
+    N, D, A, E, H, B = w.dims
+    rm, rcfg = ref_reward_mapper(w, clip, use_constraints, state_min, state_max)
+    mus, Sigs, rews, rvars, Js = [], [], [], [], []
+    for b in range(B):
+        act = torch.tensor(w.actions[b])
+        mu, Sig = m.predict_trajectory(act, torch.tensor(w.mu0), torch.tensor(w.S0), H, int(w.time0))
+        r, rv = rm.get_rewards_trajectory(mu, Sig, act)
+        ucb = r + rcfg.exploration_factor * torch.sqrt(rv)
+        if clip:
+            ucb = Clamp.apply(ucb, float('-inf'), 0)
+        mus.append(mu.numpy()); Sigs.append(Sig.numpy()); rews.append(r.numpy()); rvars.append(rv.numpy())
+        Js.append(float(-ucb.mean()))
+    d = inputs_dict(w)
+    d.update(beta=m.beta.numpy(), mu=np.stack(mus), Sig=np.stack(Sigs), rewards=np.stack(rews),
+             reward_vars=np.stack(rvars), J=np.array(Js), clip=np.array(clip),
+             use_constraints=np.array(use_constraints))
+    if use_constraints:
+        d.update(state_min=np.asarray(state_min, float), state_max=np.asarray(state_max, float))
+    if with_iK:
+        d.update(iK=m.iK.numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(f"{name}: N={N} D={D} A={A} E={E} H={H} B={B}  J[0]={Js[0]:.12g}")
+
+
+def step_case(name, w, dense):
+    """Single predict_next_state_change call: Sigma = 0 known-answer case or dense Sigma."""
+    m = ref_model(w)
+    N, D, A, E, H, B = w.dims
+    rng = np.random.default_rng(7)
+    mean = np.concatenate([w.mu0, w.actions[0, 0]])
+    if w.include_time:
+        mean = np.concatenate([mean, [w.time0]])
+    s = np.zeros((E, E))
+    if dense:
+        G = rng.standard_normal((D, D)) * 0.05
+        s[:D, :D] = G @ G.T + 1e-4 * np.eye(D)
+    Mt, S, Vt = m.predict_next_state_change(torch.tensor(mean), torch.tensor(s))
+    d = inputs_dict(w)
+    d.update(beta=m.beta.numpy(), iK=m.iK.numpy(), in_mean=mean, in_var=s,
+             M=Mt.numpy(), S=S.numpy(), V=Vt.numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(f"{name}: M={Mt.numpy().ravel()[:3]}")
+
+
+def make_ref_controller(w, limit_action_change, optimize, restarts, clip=False):
+    """Reference GpMpcController with its gpytorch-dependent constructor bypassed; every
+    attribute compute_mean_lcb_trajectory/_get_optimal_actions read is set by hand."""
+    N, D, A, E, H, B = w.dims
+    c = object.__new__(RefCtrl)
+    rm, rcfg = ref_reward_mapper(w, clip)
+    acfg = ActionsConfig(limit_action_change=limit_action_change, max_change_action_norm=[0.3] * A)
+    Mapper = DerivativeActionMapper if limit_action_change else NormalizationActionMapper
+    c.actions_mapper = Mapper(config=acfg, action_low=np.zeros(A), action_high=np.ones(A), len_horizon=H)
+    if limit_action_change:
+        c.actions_mapper.action_model_previous_iter = torch.full((A,), 0.4)
+    c.transition_model = ref_model(w)
+    c.state_reward_mapper = rm
+    c.clamp_lcb_class = Clamp()
+    c.iter_ctrl = int(w.time0)
+    c.actions_mpc_previous_iter = None
+    c.config = types.SimpleNamespace(
+        reward=rcfg,
+        controller=types.SimpleNamespace(len_horizon=H, restarts_optim=restarts, optimize=optimize,
+                                         init_from_previous_actions=True,
+                                         actions_optimizer_params={"disp": None, "maxcor": 4, "ftol": 1e-15, "gtol": 1e-15,
+                                                                   "eps": 1e-2, "maxfun": 4, "maxiter": 4, "iprint": -1,
+                                                                   "maxls": 4, "finite_diff_rel_step": None}))
+    c.memory = types.SimpleNamespace(get=lambda: (torch.tensor(w.X), torch.tensor(w.Y)))
+    return c
+
+
+def lcb_grad_case(name, w, limit_action_change, clip=False):
+    """compute_mean_lcb_trajectory value + autograd gradient (gp_mpc_controller.py:229-285)."""
+    N, D, A, E, H, B = w.dims
+    c = make_ref_controller(w, limit_action_change, optimize=False, restarts=1, clip=clip)
+    Js, grads, acts_model = [], [], []
+    for b in range(B):
+        J, g = c.compute_mean_lcb_trajectory(w.actions[b].reshape(-1), torch.tensor(w.mu0), torch.tensor(w.S0))
+        Js.append(J); grads.append(g)
+        acts_model.append(c.actions_mapper.transform_action_mpc_to_action_model(torch.tensor(w.actions[b].reshape(-1))).numpy())
+    d = inputs_dict(w)
+    d.update(J=np.array(Js), grad=np.stack(grads), actions_model=np.stack(acts_model),
+             limit_action_change=np.array(limit_action_change), clip=np.array(clip),
+             max_change=np.full(A, 0.3), action_prev=np.full(A, 0.4),
+             mu_last=c.states_mu_pred.numpy(), Sig_last=c.states_var_pred.numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(f"{name}: J={Js}")
+
+
+def argmin_trace_case(name, w, restarts, np_seed):
+    """`optimize=False, restarts_optim=B` candidate loop + argmin (gp_mpc_controller.py:125-148)."""
+    N, D, A, E, H, B = w.dims
+    c = make_ref_controller(w, False, optimize=False, restarts=restarts)
+    seen = []
+    orig = c.compute_mean_lcb_trajectory
+
+    def spy(actions_mpc, mu, var):
+        J, g = orig(actions_mpc, mu, var)
+        seen.append((np.array(actions_mpc, dtype=np.float64).copy(), J))
+        return J, g
+    c.compute_mean_lcb_trajectory = spy
+    np.random.seed(np_seed)
+    best_model = c._get_optimal_actions(torch.tensor(w.mu0), torch.tensor(w.S0))
+    d = inputs_dict(w)
+    d.update(np_seed=np.array(np_seed), restarts=np.array(restarts),
+             cand_actions=np.stack([s[0] for s in seen]).reshape(len(seen), H, A),
+             cand_J=np.array([s[1] for s in seen]), best_actions=best_model.numpy(),
+             best_flat=c.actions_mpc_previous_iter)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(f"{name}: evaluated {len(seen)} candidates, best J={min(s[1] for s in seen):.12g}")
+
+
+def factor_case(name, w):
+    m = ref_model(w)
+    d = inputs_dict(w)
+    d.update(iK=m.iK.numpy(), beta=m.beta.numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(f"{name}: |beta|max={np.abs(m.beta.numpy()).max():.4g}")
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    mk = synth.make_workload
+    # (i) factorisation
+    factor_case("factor_n50", mk(50, 3, 1, 2, 1, seed=10))
+    factor_case("factor_n96_d2", mk(96, 2, 1, 2, 1, seed=11))
+    # (ii) single step
+    step_case("step_zero_var", mk(50, 3, 1, 2, 1, seed=12), dense=False)
+    step_case("step_dense_var", mk(50, 3, 1, 2, 1, seed=13), dense=True)
+    step_case("step_dense_var_time", mk(40, 2, 2, 2, 1, include_time=True, seed=14, time0=40.0), dense=True)
+    # (iii) trajectories
+    traj_case("traj_c1", mk(50, 3, 1, 15, 8, seed=20), with_iK=True)
+    traj_case("traj_c2", mk(200, 3, 1, 25, 8, seed=21))
+    traj_case("traj_c3", mk(500, 2, 1, 40, 2, seed=22))
+    traj_case("traj_c4", mk(600, 4, 2, 30, 2, seed=23))
+    traj_case("traj_c4_time", mk(300, 4, 2, 30, 2, include_time=True, seed=24, time0=300.0))
+    traj_case("traj_c5class", mk(128, 16, 4, 5, 2, seed=25))
+    traj_case("traj_n1_dummy", _dummy_memory_workload())
+    traj_case("traj_clip", mk(50, 3, 1, 10, 4, seed=26), clip=True)
+    traj_case("traj_constraints", mk(50, 3, 1, 10, 4, seed=27), use_constraints=True,
+              state_min=[0.05, 0.05, 0.05], state_max=[0.95, 0.95, 0.925])
+    traj_case("traj_bigvar", mk(80, 3, 1, 12, 4, seed=28, s0=2e-2, noise_var=1e-4))
+    # (iv) objective + autograd gradient
+    lcb_grad_case("lcb_grad_norm", mk(50, 3, 1, 15, 3, seed=30), limit_action_change=False)
+    lcb_grad_case("lcb_grad_deriv", mk(50, 3, 2, 8, 3, seed=31), limit_action_change=True)
+    # (v) argmin trace
+    argmin_trace_case("argmin_trace", mk(50, 3, 1, 15, 1, seed=40), restarts=12, np_seed=123)
+
+
+def _dummy_memory_workload():
+    """Empty memory => Memory.get() hands out one all-zero point (memories/gp_memory.py:109-111)."""
+    w = synth.make_workload(1, 3, 1, 6, 3, seed=50)
+    w.X[:] = 0.0
+    w.Y[:] = 0.0
+    return w
+
+
+if __name__ == "__main__":
+    main()
