@@ -1,0 +1,221 @@
+// abi.hip -- extern "C" entry points of libgpmpc_hip.so (declared in include/gpmpc.h).
+#include <cstring>
+#include <new>
+
+#include "gpmpc_internal.h"
+
+using namespace gpmpc_hip;
+
+struct gpmpc {
+    Handle h;
+};
+
+#define H_(x) (&(x)->h)
+
+static int bad(gpmpc_t* g, const char* msg) {
+    if (g) g->h.err = msg;
+    return GPMPC_ERR_ARG;
+}
+
+static void free_buf(Buf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+extern "C" {
+
+int gpmpc_abi_version(void) { return 1; }
+
+int gpmpc_create(gpmpc_t** out, int device_id) {
+    if (!out) return GPMPC_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device_id < 0 || device_id >= ndev) return GPMPC_ERR_HIP;
+    if (hipSetDevice(device_id) != hipSuccess) return GPMPC_ERR_HIP;
+    gpmpc_t* g = new (std::nothrow) gpmpc();
+    if (!g) return GPMPC_ERR_HIP;
+    g->h.device = device_id;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        g->h.num_cu = prop.multiProcessorCount;
+        if (prop.maxSharedMemoryPerMultiProcessor >= 64 * 1024)
+            g->h.lds_limit = (int)prop.maxSharedMemoryPerMultiProcessor;
+        if (g->h.lds_limit > 160 * 1024) g->h.lds_limit = 160 * 1024;
+    }
+    *out = g;
+    return GPMPC_OK;
+}
+
+int gpmpc_destroy(gpmpc_t* g) {
+    if (!g) return GPMPC_ERR_ARG;
+    Handle* h = H_(g);
+    (void)hipSetDevice(h->device);
+    Buf* all[] = {&h->Xt, &h->beta, &h->iK, &h->Tm, &h->ils2, &h->var, &h->logvar, &h->gram,
+                  &h->linv, &h->zvec, &h->cost, &h->scratch, &h->best};
+    for (Buf* b : all) free_buf(*b);
+    if (h->info) (void)hipFree(h->info);
+    delete g;
+    return GPMPC_OK;
+}
+
+const char* gpmpc_last_error(const gpmpc_t* g) { return g ? g->h.err.c_str() : "null handle"; }
+
+int gpmpc_set_option(gpmpc_t* g, const char* name, long long value) {
+    if (!g || !name) return GPMPC_ERR_ARG;
+    Handle* h = H_(g);
+    if (!strcmp(name, "keep_gram")) h->opt_keep_gram = (int)value;
+    else if (!strcmp(name, "threads")) h->opt_threads = (int)value;
+    else if (!strcmp(name, "force_global_scratch")) h->opt_force_global = (int)value;
+    else if (!strcmp(name, "rows_per_chunk")) h->opt_rows_per_chunk = (int)value;
+    else return bad(g, "unknown option");
+    return GPMPC_OK;
+}
+
+static int check_dims(gpmpc_t* g, int N, int D, int E) {
+    if (N < 1 || D < 1 || E < D) return bad(g, "need N >= 1, D >= 1, E >= D");
+    if (D > kMaxD || E > kMaxE) { g->h.err = "shape outside compiled limits (D <= 16, E <= 24)"; return GPMPC_ERR_LIMIT; }
+    return GPMPC_OK;
+}
+
+int gpmpc_prepare(gpmpc_t* g, const double* X, const double* Y, const double* ls, const double* os,
+                  const double* noise, int N, int D, int E, void* stream) {
+    if (!g || !X || !Y || !ls || !os || !noise) return bad(g, "null argument");
+    int rc = check_dims(g, N, D, E);
+    if (rc) return rc;
+    GPMPC_HIP_CHECK(H_(g), hipSetDevice(g->h.device));
+    return run_prepare(H_(g), X, Y, ls, os, noise, N, D, E, (hipStream_t)stream);
+}
+
+int gpmpc_set_factors(gpmpc_t* g, const double* X, const double* iK, const double* beta, const double* ls,
+                      const double* os, int N, int D, int E, void* stream) {
+    if (!g || !X || !iK || !beta || !ls || !os) return bad(g, "null argument");
+    int rc = check_dims(g, N, D, E);
+    if (rc) return rc;
+    GPMPC_HIP_CHECK(H_(g), hipSetDevice(g->h.device));
+    return run_set_factors(H_(g), X, iK, beta, ls, os, N, D, E, (hipStream_t)stream);
+}
+
+int gpmpc_get_factors(gpmpc_t* g, const double** iK, const double** beta) {
+    if (!g || !g->h.ready) return bad(g, "no factors cached: call gpmpc_prepare first");
+    if (iK) *iK = g->h.iK.p;
+    if (beta) *beta = g->h.beta.p;
+    return GPMPC_OK;
+}
+
+int gpmpc_read_factors(gpmpc_t* g, double* iK_dst, double* beta_dst, void* stream) {
+    if (!g || !g->h.ready) return bad(g, "no factors cached: call gpmpc_prepare first");
+    Handle* h = H_(g);
+    GPMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const size_t DN = (size_t)h->D * h->N;
+    if (iK_dst) GPMPC_HIP_CHECK(h, hipMemcpyAsync(iK_dst, h->iK.p, DN * h->N * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    if (beta_dst) GPMPC_HIP_CHECK(h, hipMemcpyAsync(beta_dst, h->beta.p, DN * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return GPMPC_OK;
+}
+
+int gpmpc_get_gram(gpmpc_t* g, const double** K) {
+    if (!g || !K) return GPMPC_ERR_ARG;
+    if (!g->h.opt_keep_gram || !g->h.gram.p) return bad(g, "gram not kept: set option keep_gram before prepare");
+    *K = g->h.gram.p;
+    return GPMPC_OK;
+}
+
+int gpmpc_set_cost(gpmpc_t* g, const double* target, const double* W, const double* W_T, double kappa,
+                   int clip, const double* smin, const double* smax, int D, int A) {
+    if (!g || !target || !W || !W_T) return bad(g, "null argument");
+    if (D < 1 || A < 0 || D > kMaxD || D + A > kMaxE) return bad(g, "bad D / A");
+    if ((smin == nullptr) != (smax == nullptr)) return bad(g, "state_min and state_max must both be given or both be NULL");
+    Handle* h = H_(g);
+    GPMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const int DA = D + A;
+    const size_t n = (size_t)DA + (size_t)DA * DA + (size_t)D * D + 2 * (size_t)D;
+    int rc = grow(h, h->cost, n);
+    if (rc) return rc;
+    double host[kMaxE + kMaxE * kMaxE + kMaxD * kMaxD + 2 * kMaxD];
+    double* q = host;
+    memcpy(q, target, DA * sizeof(double)); q += DA;
+    memcpy(q, W, (size_t)DA * DA * sizeof(double)); q += DA * DA;
+    memcpy(q, W_T, (size_t)D * D * sizeof(double)); q += D * D;
+    for (int d = 0; d < D; ++d) q[d] = smin ? smin[d] : 0.0;
+    q += D;
+    for (int d = 0; d < D; ++d) q[d] = smax ? smax[d] : 0.0;
+    GPMPC_HIP_CHECK(h, hipMemcpy(h->cost.p, host, n * sizeof(double), hipMemcpyHostToDevice));
+    h->cost_D = D; h->cost_A = A; h->kappa = kappa; h->clip = clip; h->use_constraints = smin ? 1 : 0;
+    return GPMPC_OK;
+}
+
+static int fill_args(gpmpc_t* g, RolloutArgs& a, const double* actions, const double* mu0, const double* S0,
+                     int B, int H, int A, int include_time, double time0) {
+    Handle* h = H_(g);
+    if (!h->ready) return bad(g, "rollout before prepare / set_factors");
+    if (!actions || !mu0 || !S0) return bad(g, "null argument");
+    if (B < 1 || H < 1 || A < 0) return bad(g, "need B >= 1, H >= 1");
+    if (h->D + A + (include_time ? 1 : 0) != h->E) return bad(g, "D + A (+1 with time) must equal the model's input dim E");
+    if (h->cost_D != h->D || h->cost_A != A) return bad(g, "gpmpc_set_cost not called for this (D, A)");
+    memset(&a, 0, sizeof a);
+    a.Xt = h->Xt.p; a.beta = h->beta.p; a.Tm = h->Tm.p; a.ils2 = h->ils2.p; a.var = h->var.p; a.logvar = h->logvar.p;
+    a.cost = h->cost.p; a.kappa = h->kappa; a.clip = h->clip; a.use_constraints = h->use_constraints;
+    a.actions = actions;
+    a.N = h->N; a.D = h->D; a.A = A; a.E = h->E; a.H = H; a.B = B;
+    a.include_time = include_time; a.time0 = time0;
+    memcpy(a.mu0, mu0, h->D * sizeof(double));
+    memcpy(a.S0, S0, (size_t)h->D * h->D * sizeof(double));
+    return GPMPC_OK;
+}
+
+int gpmpc_rollout(gpmpc_t* g, const double* actions, const double* mu0, const double* S0, int B, int H, int A,
+                  int include_time, double time0, double* mu_out, double* Sig_out, double* cm_out, double* cv_out,
+                  double* J_out, void* stream) {
+    if (!g) return GPMPC_ERR_ARG;
+    RolloutArgs a;
+    int rc = fill_args(g, a, actions, mu0, S0, B, H, A, include_time, time0);
+    if (rc) return rc;
+    GPMPC_HIP_CHECK(H_(g), hipSetDevice(g->h.device));
+    a.mu_out = mu_out; a.Sig_out = Sig_out; a.cm_out = cm_out; a.cv_out = cv_out; a.J_out = J_out;
+    return launch_rollout(H_(g), a, (hipStream_t)stream);
+}
+
+int gpmpc_rollout_timed(gpmpc_t* g, const double* actions, const double* mu0, const double* S0, int B, int H, int A,
+                        int include_time, double time0, double* J_out, int reps, float* ms, void* stream) {
+    if (!g || !ms || reps < 1) return GPMPC_ERR_ARG;
+    Handle* h = H_(g);
+    RolloutArgs a;
+    int rc = fill_args(g, a, actions, mu0, S0, B, H, A, include_time, time0);
+    if (rc) return rc;
+    GPMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    a.J_out = J_out;
+    hipStream_t s = (hipStream_t)stream;
+    hipEvent_t e0, e1;
+    GPMPC_HIP_CHECK(h, hipEventCreate(&e0));
+    GPMPC_HIP_CHECK(h, hipEventCreate(&e1));
+    GPMPC_HIP_CHECK(h, hipEventRecord(e0, s));
+    for (int r = 0; r < reps; ++r) {
+        rc = launch_rollout(h, a, s);
+        if (rc) break;
+    }
+    GPMPC_HIP_CHECK(h, hipEventRecord(e1, s));
+    GPMPC_HIP_CHECK(h, hipEventSynchronize(e1));
+    float t = 0.f;
+    GPMPC_HIP_CHECK(h, hipEventElapsedTime(&t, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms = t / (float)reps;
+    return rc;
+}
+
+int gpmpc_argmin(gpmpc_t* g, const double* J, int B, double* best_J, long long* best_idx, void* stream) {
+    if (!g || !J || B < 1) return bad(g, "bad argument");
+    Handle* h = H_(g);
+    GPMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    hipStream_t s = (hipStream_t)stream;
+    int rc = launch_argmin(h, J, B, s);
+    if (rc) return rc;
+    double out[2];
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(out, h->best.p, sizeof out, hipMemcpyDeviceToHost, s));
+    GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
+    if (best_J) *best_J = out[0];
+    if (best_idx) memcpy(best_idx, &out[1], sizeof(long long));
+    return GPMPC_OK;
+}
+
+}  // extern "C"

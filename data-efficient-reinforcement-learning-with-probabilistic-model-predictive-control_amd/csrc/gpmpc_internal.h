@@ -1,0 +1,115 @@
+// Internal declarations shared by the HIP translation units of libgpmpc_hip.so.
+// gfx950 (MI355X / CDNA4) only: 64-lane wavefronts, 160 KiB LDS per CU, 256 CUs.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdio>
+#include <string>
+
+#include "../../include/gpmpc.h"
+
+namespace gpmpc_hip {
+
+constexpr int kMaxD = GPMPC_MAX_D;
+constexpr int kMaxE = GPMPC_MAX_E;
+constexpr int kWave = 64;
+
+// ---------------------------------------------------------------------------------------
+// Kernel argument block of the rollout kernel (passed by value, < 4 KiB).
+struct RolloutArgs {
+    // cached model (device)
+    const double* Xt;      // (E, N)  inputs, structure-of-arrays
+    const double* beta;    // (D, N)
+    const double* Tm;      // (D, N, N)  beta beta^T - iK with the diagonal halved
+    const double* ils2;    // (D, E)  1 / lengthscale^2
+    const double* var;     // (D)     outputscale
+    const double* logvar;  // (D)
+    // cost block (device): target (D+A) | W (D+A)^2 | W_T D^2 | smin D | smax D
+    const double* cost;
+    double kappa;
+    int clip;
+    int use_constraints;
+    // problem
+    const double* actions;  // (B, H, A)
+    int N, D, A, E, H, B;
+    int include_time;
+    double time0;
+    // outputs (nullable)
+    double* mu_out;
+    double* Sig_out;
+    double* cm_out;
+    double* cv_out;
+    double* J_out;
+    // tiling
+    int G;        // output pairs per group
+    int CH;       // rows per chunk
+    int RC;       // row chunks per column
+    double* scratch;         // per-candidate global scratch (large-N variant)
+    size_t scratch_stride;   // doubles per candidate
+    // initial state distribution
+    double mu0[kMaxD];
+    double S0[kMaxD * kMaxD];
+};
+
+// A device buffer that only ever grows.
+struct Buf {
+    double* p = nullptr;
+    size_t cap = 0;      // doubles
+};
+
+struct Handle {
+    int device = 0;
+    std::string err;
+    // shapes of the cached model
+    int N = 0, D = 0, E = 0;
+    bool ready = false;
+    // device buffers owned by the handle
+    Buf Xt;       // (E, N)
+    Buf beta;     // (D, N)
+    Buf iK;       // (D, N, N)
+    Buf Tm;       // (D, N, N)
+    Buf ils2;     // (D, E)
+    Buf var;      // (D)
+    Buf logvar;   // (D)
+    Buf gram;     // (D, N, N)  K + noise I, then L in its lower triangle (prepare workspace)
+    Buf linv;     // (D, N, N)  L^-1 (prepare workspace)
+    Buf zvec;     // (D, N)     temp for beta
+    Buf cost;     // target | W | W_T | smin | smax
+    Buf scratch;  // per-candidate rollout scratch (large-N variant)
+    Buf best;     // argmin result: [best_J, best_idx bits]
+    int* info = nullptr;        // (kMaxD) first non-positive pivot + 1, or 0
+    // cost settings
+    int cost_D = -1, cost_A = -1;
+    double kappa = 1.0;
+    int clip = 0;
+    int use_constraints = 0;
+    // options
+    int opt_keep_gram = 0;
+    int opt_threads = 0;
+    int opt_force_global = 0;
+    int opt_rows_per_chunk = 0;
+    int lds_limit = 160 * 1024;
+    int num_cu = 256;
+};
+
+#define GPMPC_HIP_CHECK(h, expr)                                                         \
+    do {                                                                                 \
+        hipError_t e_ = (expr);                                                          \
+        if (e_ != hipSuccess) {                                                          \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                \
+            return GPMPC_ERR_HIP;                                                        \
+        }                                                                                \
+    } while (0)
+
+// rollout.hip
+int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s);
+int launch_argmin(Handle* h, const double* J, int B, hipStream_t s);
+// prepare.hip
+int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, const double* os,
+                const double* noise, int N, int D, int E, hipStream_t s);
+int run_set_factors(Handle* h, const double* X, const double* iK, const double* beta,
+                    const double* ls, const double* os, int N, int D, int E, hipStream_t s);
+int ensure_model_buffers(Handle* h, int N, int D, int E, bool need_factor_ws);
+int grow(Handle* h, Buf& b, size_t need);
+
+}  // namespace gpmpc_hip

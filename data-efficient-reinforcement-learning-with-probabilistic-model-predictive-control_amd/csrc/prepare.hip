@@ -1,0 +1,362 @@
+// prepare.hip -- once-per-control-step factorisation for gfx950 (MI355X, CDNA4).
+//
+// Replaces calculate_factorizations + prepare_inference of the reference
+// (rl_gp_mpc/control_objects/models/gp_model.py:400-431, 182-191):
+//   K_a   = outputscale_a * exp(-1/2 sum_e ((x_ie - x_je)/l_ae)^2) + noise_a I     (:425,427)
+//   L_a   = chol(K_a)                       blocked right-looking, fp64 MFMA trailing update (:427)
+//   Y_a   = L_a^-1                          blocked forward substitution, fp64 MFMA
+//   beta  = Y^T (Y y)                       (= cholesky_solve(y, L), :429-430)
+//   iK_a  = Y_a^T Y_a                       fp64 MFMA (= cholesky_solve(I, L), :428)
+//   T_a   = beta_a beta_a^T - iK_a, diagonal halved   (table streamed by the rollout kernel)
+// The Gram build is HBM-write-bound (one coalesced 8-byte store per element); the three
+// N^3 contractions are the only dense contractions of the hot path and run on the matrix
+// cores with v_mfma_f64_16x16x4_f64 (wave64: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15],
+// D[row=(l>>4)+4r][col=l&15]).
+#include "gpmpc_internal.h"
+
+namespace gpmpc_hip {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+constexpr int NB = 32;   // panel width
+
+// ------------------------------------------------------------------------------------------
+__global__ void pack_inputs_kernel(const double* __restrict__ X, const double* __restrict__ ls,
+                                   const double* __restrict__ os, int N, int D, int E,
+                                   double* __restrict__ Xt, double* __restrict__ ils2,
+                                   double* __restrict__ var, double* __restrict__ logvar) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx < N * E) {
+        const int e = idx / N, pt = idx - e * N;
+        Xt[idx] = X[(size_t)pt * E + e];
+    }
+    if (idx < D * E) { const double l = ls[idx]; ils2[idx] = 1.0 / (l * l); }
+    if (idx < D) { var[idx] = os[idx]; logvar[idx] = log(os[idx]); }
+}
+
+// K[a][i][j], lanes along j (coalesced stores); x_i broadcast through the scalar path.
+__global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xt, const double* __restrict__ ils2,
+                                                   const double* __restrict__ var, const double* __restrict__ noise,
+                                                   int N, int E, double* __restrict__ K) {
+    const int a = blockIdx.z;
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= N || j >= N) return;
+    double s = 0.0;
+    for (int e = 0; e < E; ++e) {
+        const double d = Xt[(size_t)e * N + i] - Xt[(size_t)e * N + j];
+        s = fma(d * d, ils2[a * E + e], s);
+    }
+    double v = var[a] * exp(-0.5 * s);
+    if (i == j) v += noise[a];
+    K[((size_t)a * N + i) * N + j] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// Unblocked Cholesky of the nb x nb diagonal block at (k0, k0) and its inverse (for the
+// triangular-inverse recursion).  One workgroup of NB*NB threads per GP.
+__global__ __launch_bounds__(NB * NB) void potrf_diag_kernel(double* __restrict__ Kall, double* __restrict__ Yall,
+                                                            int N, int k0, int nb, int* __restrict__ info) {
+    __shared__ double s[NB][NB + 1];
+    __shared__ double y[NB][NB + 1];
+    const int a = blockIdx.x;
+    double* K = Kall + (size_t)a * N * N;
+    double* Y = Yall + (size_t)a * N * N;
+    const int r = threadIdx.x / NB, c = threadIdx.x % NB;
+    const bool in = (r < nb && c < nb);
+    s[r][c] = (in && c <= r) ? K[(size_t)(k0 + r) * N + (k0 + c)] : 0.0;
+    __syncthreads();
+    for (int k = 0; k < nb; ++k) {
+        if (r == k && c == k) {
+            const double d = s[k][k];
+            if (!(d > 0.0) && info[a] == 0) info[a] = k0 + k + 1;
+            s[k][k] = sqrt(d);
+        }
+        __syncthreads();
+        if (c == k && r > k && r < nb) s[r][k] /= s[k][k];
+        __syncthreads();
+        if (in && c > k && c <= r) s[r][c] -= s[r][k] * s[c][k];
+        __syncthreads();
+    }
+    if (in && c <= r) K[(size_t)(k0 + r) * N + (k0 + c)] = s[r][c];
+    // inverse of the lower-triangular block: thread column c solves L y = e_c
+    if (r == 0 && c < nb) {
+        for (int i = 0; i < nb; ++i) {
+            double v = (i == c) ? 1.0 : 0.0;
+            for (int m = c; m < i; ++m) v -= s[i][m] * y[m][c];
+            y[i][c] = (i < c) ? 0.0 : v / s[i][i];
+        }
+    }
+    __syncthreads();
+    if (in) Y[(size_t)(k0 + r) * N + (k0 + c)] = (c <= r) ? y[r][c] : 0.0;
+}
+
+// Panel solve: rows below the diagonal block, A21 <- A21 L11^-T  (one thread per row).
+__global__ __launch_bounds__(256) void trsm_panel_kernel(double* __restrict__ Kall, int N, int k0, int nb) {
+    __shared__ double l11[NB][NB + 1];
+    const int a = blockIdx.y;
+    double* K = Kall + (size_t)a * N * N;
+    for (int idx = threadIdx.x; idx < NB * NB; idx += blockDim.x) {
+        const int r = idx / NB, c = idx % NB;
+        l11[r][c] = (r < nb && c <= r) ? K[(size_t)(k0 + r) * N + (k0 + c)] : 0.0;
+    }
+    __syncthreads();
+    const int row = k0 + nb + blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= N) return;
+    double x[NB];
+    double* rp = K + (size_t)row * N + k0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) x[c] = (c < nb) ? rp[c] : 0.0;
+#pragma unroll
+    for (int c = 0; c < NB; ++c) {
+        if (c < nb) {
+            double v = x[c];
+#pragma unroll
+            for (int m = 0; m < NB; ++m)
+                if (m < c) v = fma(-x[m], l11[c][m], v);
+            x[c] = v / l11[c][c];
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+        if (c < nb) rp[c] = x[c];
+}
+
+// Trailing update A22 -= L21 L21^T on the lower triangle; 32x32 block per workgroup, one
+// 16x16 fp64 MFMA tile per wave.
+__global__ __launch_bounds__(256) void syrk_trailing_kernel(double* __restrict__ Kall, int N, int k0, int nb) {
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    const int a = blockIdx.z;
+    double* K = Kall + (size_t)a * N * N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = k0 + nb;
+    const int i0 = r0 + ti * 32 + (wave >> 1) * 16;
+    const int j0 = r0 + tj * 32 + (wave & 1) * 16;
+    if (j0 > i0 + 15) return;
+    const int li = lane & 15, lk = lane >> 4;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int ri = i0 + li, rj = j0 + li;
+    for (int kk = 0; kk < nb; kk += 4) {
+        const int k = kk + lk;
+        const double av = (ri < N && k < nb) ? K[(size_t)ri * N + k0 + k] : 0.0;
+        const double bv = (rj < N && k < nb) ? K[(size_t)rj * N + k0 + k] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = i0 + lk + 4 * r, col = j0 + li;
+        if (row < N && col <= row) K[(size_t)row * N + col] -= acc[r];
+    }
+}
+
+// Row block k of Y = L^-1:  Y[k, c] = -Ykk * (sum_p L[k, p] Y[p, c]) for column tiles c < k0.
+__global__ __launch_bounds__(256) void trinv_row_kernel(const double* __restrict__ Kall, double* __restrict__ Yall,
+                                                        int N, int k0, int nb) {
+    __shared__ double w[32][33];
+    __shared__ double ykk[NB][NB + 1];
+    const int a = blockIdx.y;
+    const double* L = Kall + (size_t)a * N * N;
+    double* Y = Yall + (size_t)a * N * N;
+    const int c0 = blockIdx.x * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
+    const int li = lane & 15, lk = lane >> 4;
+    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+        const int r = idx / NB, c = idx % NB;
+        ykk[r][c] = (r < nb && c <= r) ? Y[(size_t)(k0 + r) * N + (k0 + c)] : 0.0;
+    }
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int rowA = k0 + wi + li;              // row of L in block k
+    const int colB = c0 + wj + li;              // column of Y
+    for (int p = c0; p < k0; p += 4) {
+        const int pk = p + lk;
+        const double av = (wi + li < nb && pk < k0) ? L[(size_t)rowA * N + pk] : 0.0;
+        const double bv = (pk < k0 && colB < k0) ? Y[(size_t)pk * N + colB] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w[wi + lk + 4 * r][wj + li] = acc[r];
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+        const int r = idx / 32, c = idx % 32;
+        if (r < nb && c0 + c < k0) {
+            double s = 0.0;
+            for (int m = 0; m <= r; ++m) s = fma(ykk[r][m], w[m][c], s);
+            Y[(size_t)(k0 + r) * N + c0 + c] = -s;
+        }
+    }
+}
+
+// z = Y y  (wave per row), beta = Y^T z  (thread per column)
+__global__ __launch_bounds__(256) void zvec_kernel(const double* __restrict__ Yall, const double* __restrict__ Ymem,
+                                                   int N, int D, double* __restrict__ z) {
+    const int a = blockIdx.y;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= N) return;
+    const double* Y = Yall + (size_t)a * N * N + (size_t)row * N;
+    double s = 0.0;
+    for (int p = lane; p <= row; p += 64) s = fma(Y[p], Ymem[(size_t)p * D + a], s);
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) z[(size_t)a * N + row] = s;
+}
+
+__global__ __launch_bounds__(256) void beta_kernel(const double* __restrict__ Yall, const double* __restrict__ z,
+                                                   int N, double* __restrict__ beta) {
+    const int a = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    const double* Y = Yall + (size_t)a * N * N;
+    double s = 0.0;
+    for (int p = i; p < N; ++p) s = fma(Y[(size_t)p * N + i], z[(size_t)a * N + p], s);
+    beta[(size_t)a * N + i] = s;
+}
+
+// iK = Y^T Y on lower-triangular 32x32 blocks (mirrored on store), plus T = beta beta^T - iK
+// with the diagonal halved.
+__global__ __launch_bounds__(256) void syrk_inverse_kernel(const double* __restrict__ Yall, const double* __restrict__ beta,
+                                                           int N, double* __restrict__ iKall, double* __restrict__ Tall) {
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    const int a = blockIdx.z;
+    const double* Y = Yall + (size_t)a * N * N;
+    double* iK = iKall + (size_t)a * N * N;
+    double* T = Tall + (size_t)a * N * N;
+    const double* be = beta + (size_t)a * N;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = ti * 32 + (wave >> 1) * 16;
+    const int j0 = tj * 32 + (wave & 1) * 16;
+    const int li = lane & 15, lk = lane >> 4;
+    d4 acc = {0.0, 0.0, 0.0, 0.0};
+    const int ci = i0 + li, cj = j0 + li;
+    const int pstart = (i0 > j0 ? i0 : j0) & ~3;
+    for (int p = pstart; p < N; p += 4) {
+        const int pk = p + lk;
+        const double av = (pk < N && ci < N) ? Y[(size_t)pk * N + ci] : 0.0;
+        const double bv = (pk < N && cj < N) ? Y[(size_t)pk * N + cj] : 0.0;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = i0 + lk + 4 * r, col = j0 + li;
+        if (row < N && col < N && col <= row) {
+            const double v = acc[r];
+            double t = be[row] * be[col] - v;
+            if (row == col) t *= 0.5;
+            iK[(size_t)row * N + col] = v;
+            T[(size_t)row * N + col] = t;
+            if (row != col) { iK[(size_t)col * N + row] = v; T[(size_t)col * N + row] = t; }
+        }
+    }
+}
+
+// T from externally supplied iK / beta (gpmpc_set_factors)
+__global__ __launch_bounds__(256) void tm_kernel(const double* __restrict__ iK, const double* __restrict__ beta, int N,
+                                                 double* __restrict__ T) {
+    const int a = blockIdx.z;
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= N || j >= N) return;
+    const size_t o = ((size_t)a * N + i) * N + j;
+    double t = beta[(size_t)a * N + i] * beta[(size_t)a * N + j] - iK[o];
+    if (i == j) t *= 0.5;
+    T[o] = t;
+}
+
+// ------------------------------------------------------------------------------------------
+int grow(Handle* h, Buf& b, size_t need) {
+    if (b.p && need <= b.cap) return GPMPC_OK;
+    if (b.p) GPMPC_HIP_CHECK(h, hipFree(b.p));
+    b.p = nullptr; b.cap = 0;
+    GPMPC_HIP_CHECK(h, hipMalloc(&b.p, (need ? need : 1) * sizeof(double)));
+    b.cap = need ? need : 1;
+    return GPMPC_OK;
+}
+
+int ensure_model_buffers(Handle* h, int N, int D, int E, bool need_factor_ws) {
+    const size_t NN = (size_t)D * N * N, DN = (size_t)D * N, DE = (size_t)D * E, EN = (size_t)E * N;
+    int rc;
+    if ((rc = grow(h, h->Xt, EN))) return rc;
+    if ((rc = grow(h, h->ils2, DE))) return rc;
+    if ((rc = grow(h, h->var, kMaxD))) return rc;
+    if ((rc = grow(h, h->logvar, kMaxD))) return rc;
+    if ((rc = grow(h, h->beta, DN))) return rc;
+    if ((rc = grow(h, h->zvec, DN))) return rc;
+    if ((rc = grow(h, h->iK, NN))) return rc;
+    if ((rc = grow(h, h->Tm, NN))) return rc;
+    if (need_factor_ws) {
+        if ((rc = grow(h, h->gram, NN))) return rc;
+        if ((rc = grow(h, h->linv, NN))) return rc;
+    }
+    if (!h->info) GPMPC_HIP_CHECK(h, hipMalloc(&h->info, kMaxD * sizeof(int)));
+    return GPMPC_OK;
+}
+
+static int pack(Handle* h, const double* X, const double* ls, const double* os, int N, int D, int E, hipStream_t s) {
+    int n = N * E; if (D * E > n) n = D * E; if (D > n) n = D;
+    hipLaunchKernelGGL(pack_inputs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, X, ls, os, N, D, E,
+                       h->Xt.p, h->ils2.p, h->var.p, h->logvar.p);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    return GPMPC_OK;
+}
+
+int run_set_factors(Handle* h, const double* X, const double* iK, const double* beta, const double* ls,
+                    const double* os, int N, int D, int E, hipStream_t s) {
+    int rc = ensure_model_buffers(h, N, D, E, false);
+    if (rc) return rc;
+    if ((rc = pack(h, X, ls, os, N, D, E, s))) return rc;
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->iK.p, iK, (size_t)D * N * N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->beta.p, beta, (size_t)D * N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    hipLaunchKernelGGL(tm_kernel, dim3((N + 63) / 64, (N + 3) / 4, D), dim3(256), 0, s, h->iK.p, h->beta.p, N, h->Tm.p);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    h->N = N; h->D = D; h->E = E; h->ready = true;
+    return GPMPC_OK;
+}
+
+int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, const double* os,
+                const double* noise, int N, int D, int E, hipStream_t s) {
+    int rc = ensure_model_buffers(h, N, D, E, true);
+    if (rc) return rc;
+    h->ready = false;
+    if ((rc = pack(h, X, ls, os, N, D, E, s))) return rc;
+    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->info, 0, kMaxD * sizeof(int), s));
+    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->linv.p, 0, (size_t)D * N * N * sizeof(double), s));
+    hipLaunchKernelGGL(gram_kernel, dim3((N + 63) / 64, (N + 3) / 4, D), dim3(256), 0, s,
+                       h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    for (int k0 = 0; k0 < N; k0 += NB) {
+        const int nb = (N - k0 < NB) ? (N - k0) : NB;
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
+        const int M = N - k0 - nb;
+        if (M > 0) {
+            hipLaunchKernelGGL(trsm_panel_kernel, dim3((M + 255) / 256, D), dim3(256), 0, s, h->gram.p, N, k0, nb);
+            const int nt = (M + 31) / 32;
+            hipLaunchKernelGGL(syrk_trailing_kernel, dim3(nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb);
+        }
+        if (k0 > 0) {
+            hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb);
+        }
+    }
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    hipLaunchKernelGGL(zvec_kernel, dim3((N + 3) / 4, D), dim3(256), 0, s, h->linv.p, Y, N, D, h->zvec.p);
+    hipLaunchKernelGGL(beta_kernel, dim3((N + 255) / 256, D), dim3(256), 0, s, h->linv.p, h->zvec.p, N, h->beta.p);
+    const int nt = (N + 31) / 32;
+    hipLaunchKernelGGL(syrk_inverse_kernel, dim3(nt, nt, D), dim3(256), 0, s, h->linv.p, h->beta.p, N, h->iK.p, h->Tm.p);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    int info[kMaxD];
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(info, h->info, kMaxD * sizeof(int), hipMemcpyDeviceToHost, s));
+    GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
+    for (int a = 0; a < D; ++a) {
+        if (info[a] != 0) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "cholesky: GP %d: leading minor of order %d of K + noise*I is not positive-definite",
+                     a, info[a]);
+            h->err = buf;
+            return GPMPC_ERR_NOT_PD;
+        }
+    }
+    h->N = N; h->D = D; h->E = E; h->ready = true;
+    return GPMPC_OK;
+}
+
+}  // namespace gpmpc_hip

@@ -1,0 +1,42 @@
+// rollout_dp.hip -- one translation unit per padded state dimension (compiled with
+// -DGPMPC_DP=<n>) so that the template instantiations build in parallel.
+#include "rollout_kernel.h"
+
+#ifndef GPMPC_DP
+#error "compile with -DGPMPC_DP=<padded state dimension>"
+#endif
+
+namespace gpmpc_hip {
+
+// ------------------------------------------------------------------------------------------
+template <int DP, int NT>
+static int launch_variant(Handle* h, RolloutArgs& a, bool global_scratch, size_t lds_bytes, hipStream_t s) {
+    auto kern = global_scratch ? rollout_kernel<DP, NT, true> : rollout_kernel<DP, NT, false>;
+    static thread_local const void* configured[2] = {nullptr, nullptr};
+    const void* kp = reinterpret_cast<const void*>(kern);
+    if (configured[global_scratch] != kp) {
+        GPMPC_HIP_CHECK(h, hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit));
+        configured[global_scratch] = kp;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(NT), lds_bytes, s, a);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    return GPMPC_OK;
+}
+
+template <int DP>
+static int launch_dp(Handle* h, RolloutArgs& a, int nt, bool gs, size_t lds, hipStream_t s) {
+    switch (nt) {
+        case 256: return launch_variant<DP, 256>(h, a, gs, lds, s);
+        case 512: return launch_variant<DP, 512>(h, a, gs, lds, s);
+        default:  return launch_variant<DP, 1024>(h, a, gs, lds, s);
+    }
+}
+
+
+#define GPMPC_CAT_(a, b) a##b
+#define GPMPC_CAT(a, b) GPMPC_CAT_(a, b)
+int GPMPC_CAT(launch_rollout_dp, GPMPC_DP)(Handle* h, RolloutArgs& a, int nt, bool gs, size_t lds, hipStream_t s) {
+    return launch_dp<GPMPC_DP>(h, a, nt, gs, lds, s);
+}
+
+}  // namespace gpmpc_hip

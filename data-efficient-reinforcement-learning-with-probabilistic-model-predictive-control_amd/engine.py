@@ -1,0 +1,164 @@
+"""Thin object wrapper over the C ABI: device memory and streams come from PyTorch-ROCm,
+all arithmetic happens in libgpmpc_hip.so."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _host(a, shape=None):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if shape is not None and a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def _hp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class HipEngine:
+    """One handle per GPU (gpmpc_create).  All tensors are fp64 on ``device``."""
+
+    def __init__(self, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipEngine needs a ROCm GPU: the GP-MPC hot path has no CPU fallback")
+        self.lib = L.lib()
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        h = C.c_void_p()
+        rc = self.lib.gpmpc_create(C.byref(h), self.device.index)
+        if rc != L.GPMPC_OK:
+            raise L.GpmpcError(rc, "gpmpc_create failed")
+        self._h = h
+        self.N = self.D = self.E = 0
+        self._cost = None
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.gpmpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ---------------------------------------------------------------------
+    def _check(self, rc):
+        if rc == L.GPMPC_OK:
+            return
+        msg = self.lib.gpmpc_last_error(self._h).decode()
+        if rc == L.GPMPC_ERR_NOT_PD:
+            raise L.NotPositiveDefiniteError(rc, msg)
+        raise L.GpmpcError(rc, msg)
+
+    def _dev(self, t, shape=None):
+        t = torch.as_tensor(t, dtype=torch.float64).to(self.device).contiguous()
+        if shape is not None and tuple(t.shape) != tuple(shape):
+            raise ValueError(f"expected shape {tuple(shape)}, got {tuple(t.shape)}")
+        return t
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def set_option(self, name, value):
+        self._check(self.lib.gpmpc_set_option(self._h, name.encode(), int(value)))
+
+    # -- a1/a2 -------------------------------------------------------------------------
+    def prepare(self, X, Y, lengthscales, outputscales, noises):
+        X = self._dev(X)
+        N, E = X.shape
+        Y = self._dev(Y)
+        D = Y.shape[1]
+        ls = self._dev(lengthscales, (D, E))
+        osc = self._dev(outputscales).reshape(D)
+        nz = self._dev(noises).reshape(D)
+        self._keep = (X, Y, ls, osc, nz)
+        self._check(self.lib.gpmpc_prepare(self._h, X.data_ptr(), Y.data_ptr(), ls.data_ptr(), osc.data_ptr(),
+                                           nz.data_ptr(), N, D, E, self._stream()))
+        self.N, self.D, self.E = N, D, E
+
+    def set_factors(self, X, iK, beta, lengthscales, outputscales):
+        X = self._dev(X)
+        N, E = X.shape
+        beta = self._dev(beta)
+        D = beta.shape[0]
+        iK = self._dev(iK, (D, N, N))
+        ls = self._dev(lengthscales, (D, E))
+        osc = self._dev(outputscales).reshape(D)
+        self._check(self.lib.gpmpc_set_factors(self._h, X.data_ptr(), iK.data_ptr(), beta.data_ptr(), ls.data_ptr(),
+                                               osc.data_ptr(), N, D, E, self._stream()))
+        torch.cuda.current_stream(self.device).synchronize()
+        self.N, self.D, self.E = N, D, E
+
+    def factors(self):
+        iK = torch.empty((self.D, self.N, self.N), dtype=torch.float64, device=self.device)
+        beta = torch.empty((self.D, self.N), dtype=torch.float64, device=self.device)
+        self._check(self.lib.gpmpc_read_factors(self._h, iK.data_ptr(), beta.data_ptr(), self._stream()))
+        return iK, beta
+
+    def gram(self):
+        p = C.c_void_p()
+        self._check(self.lib.gpmpc_get_gram(self._h, C.byref(p)))
+        return p.value
+
+    # -- a6 ----------------------------------------------------------------------------
+    def set_cost(self, target, W, W_T, kappa, clip_to_zero=False, state_min=None, state_max=None):
+        W_T = _host(W_T)
+        D = W_T.shape[0]
+        W = _host(W)
+        A = W.shape[0] - D
+        target = _host(target, (D + A,))
+        smin = _host(state_min, (D,)) if state_min is not None else None
+        smax = _host(state_max, (D,)) if state_max is not None else None
+        self._check(self.lib.gpmpc_set_cost(self._h, _hp(target), _hp(W), _hp(W_T), float(kappa), int(bool(clip_to_zero)),
+                                            _hp(smin) if smin is not None else None,
+                                            _hp(smax) if smax is not None else None, D, A))
+        self._cost = (D, A)
+
+    # -- a3-a5 -------------------------------------------------------------------------
+    def rollout(self, actions, mu0, S0, include_time=False, time0=0.0, trajectories=True, stage_costs=True):
+        """actions (B,H,A) -> dict(J (B,), [mu (B,H+1,D), Sig (B,H+1,D,D)], [cost_mu, cost_var (B,H+1)])."""
+        actions = self._dev(actions)
+        B, H, A = actions.shape
+        D = self.D
+        mu0 = _host(mu0, (D,))
+        S0 = _host(S0, (D, D))
+        out = {"J": torch.empty(B, dtype=torch.float64, device=self.device)}
+        if trajectories:
+            out["mu"] = torch.empty((B, H + 1, D), dtype=torch.float64, device=self.device)
+            out["Sig"] = torch.empty((B, H + 1, D, D), dtype=torch.float64, device=self.device)
+        if stage_costs:
+            out["cost_mu"] = torch.empty((B, H + 1), dtype=torch.float64, device=self.device)
+            out["cost_var"] = torch.empty((B, H + 1), dtype=torch.float64, device=self.device)
+
+        def ptr(k):
+            return out[k].data_ptr() if k in out else None
+        self._check(self.lib.gpmpc_rollout(self._h, actions.data_ptr(), _hp(mu0), _hp(S0), B, H, A, int(bool(include_time)),
+                                           float(time0), ptr("mu"), ptr("Sig"), ptr("cost_mu"), ptr("cost_var"),
+                                           out["J"].data_ptr(), self._stream()))
+        return out
+
+    def rollout_timed(self, actions, mu0, S0, reps, include_time=False, time0=0.0):
+        """Average kernel milliseconds per launch, measured with HIP events on the launch stream."""
+        actions = self._dev(actions)
+        B, H, A = actions.shape
+        mu0 = _host(mu0, (self.D,))
+        S0 = _host(S0, (self.D, self.D))
+        J = torch.empty(B, dtype=torch.float64, device=self.device)
+        ms = C.c_float(0.0)
+        self._check(self.lib.gpmpc_rollout_timed(self._h, actions.data_ptr(), _hp(mu0), _hp(S0), B, H, A,
+                                                 int(bool(include_time)), float(time0), J.data_ptr(), int(reps),
+                                                 C.byref(ms), self._stream()))
+        return float(ms.value), J
+
+    # -- a8 ----------------------------------------------------------------------------
+    def argmin(self, J):
+        J = self._dev(J)
+        bj = C.c_double()
+        bi = C.c_longlong()
+        self._check(self.lib.gpmpc_argmin(self._h, J.data_ptr(), J.numel(), C.byref(bj), C.byref(bi), self._stream()))
+        return float(bj.value), int(bi.value)

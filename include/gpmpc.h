@@ -1,0 +1,142 @@
+/*
+ * gpmpc.h -- C ABI of the MI355X-native GP-MPC hot path (libgpmpc_hip.so).
+ *
+ * The reference (SimonRennotte/Data-Efficient-RL-with-Probabilistic-MPC) has no FFI:
+ * its boundary is the duck-typed Python interface AbstractStateTransitionModel
+ * (rl_gp_mpc/control_objects/models/abstract_model.py:5-28) plus the candidate loop
+ * of GpMpcController._get_optimal_actions (controllers/gp_mpc_controller.py:114-153).
+ * Each entry point below names the reference code it replaces.  The Python mirror
+ * of those classes (package `..._amd/control_objects/`) calls ONLY these functions
+ * for arithmetic; INTEGRATION.md shows the ctypes stub a reference maintainer adds.
+ *
+ * Conventions
+ *   - every array is fp64 (the reference forces fp64: config_classes/total_config.py:11),
+ *     row-major, contiguous;
+ *   - `*_dev` pointers are DEVICE pointers on the handle's GPU (e.g. tensor.data_ptr()),
+ *     `*_host` pointers are HOST pointers read before the call returns;
+ *   - `stream` is a hipStream_t (NULL = default stream).  Calls are asynchronous on that
+ *     stream unless stated otherwise; the caller owns all in/out buffers, the handle owns
+ *     its workspace (factor matrices, per-candidate scratch);
+ *   - return value: GPMPC_OK or a negative error; gpmpc_last_error() gives the text;
+ *   - one handle per device; a handle is not thread-safe; handles are independent.
+ */
+#ifndef GPMPC_H
+#define GPMPC_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct gpmpc gpmpc_t;
+
+enum {
+    GPMPC_OK = 0,
+    GPMPC_ERR_ARG = -1,    /* bad argument / shape / state                                   */
+    GPMPC_ERR_NOT_PD = -2, /* Cholesky hit a non-positive pivot (reference: uncaught          */
+                           /* torch.linalg.cholesky error, models/gp_model.py:427)            */
+    GPMPC_ERR_HIP = -3,    /* HIP runtime error                                               */
+    GPMPC_ERR_LIMIT = -4   /* shape outside compiled limits (D <= 16, D+A+time <= 24)          */
+};
+
+#define GPMPC_MAX_D 16
+#define GPMPC_MAX_E 24
+
+/* Library ABI version (bumped on any signature change). */
+int gpmpc_abi_version(void);
+
+/* Create / destroy a handle bound to HIP device `device_id`. */
+int gpmpc_create(gpmpc_t** out, int device_id);
+int gpmpc_destroy(gpmpc_t* h);
+const char* gpmpc_last_error(const gpmpc_t* h);
+
+/*
+ * gpmpc_prepare  <->  GpStateTransitionModel.prepare_inference + calculate_factorizations
+ *                     (models/gp_model.py:182-191, 400-431).
+ * Builds, per output dimension a: K_a = outputscale_a * exp(-1/2 sum_e ((x_e-x'_e)/l_ae)^2)
+ * (gpytorch ScaleKernel(RBFKernel(ard)), gp_model.py:391,425), L_a = chol(K_a + noise_a I)
+ * (:427), iK_a = (L_a L_a^T)^-1 (:428), beta_a = iK_a y_a (:429-430), and the derived
+ * tables the rollout kernel streams.  Synchronises `stream` before returning so that a
+ * failed factorisation is reported here (GPMPC_ERR_NOT_PD; failing GP via
+ * gpmpc_last_error()).
+ *   X_dev (N,E)  Y_dev (N,D)  lengthscales_dev (D,E)  outputscales_dev (D)  noises_dev (D)
+ */
+int gpmpc_prepare(gpmpc_t* h, const double* X_dev, const double* Y_dev,
+                  const double* lengthscales_dev, const double* outputscales_dev,
+                  const double* noises_dev, int N, int D, int E, void* stream);
+
+/*
+ * Same cached state as gpmpc_prepare but with iK (D,N,N) and beta (D,N) supplied by the
+ * caller (test hook: lets the rollout kernel be checked in isolation from the
+ * factorisation; also the entry for callers that keep their own factorisation).
+ */
+int gpmpc_set_factors(gpmpc_t* h, const double* X_dev, const double* iK_dev, const double* beta_dev,
+                      const double* lengthscales_dev, const double* outputscales_dev,
+                      int N, int D, int E, void* stream);
+
+/* Borrowed device pointers to iK (D,N,N) and beta (D,N); valid until the next
+ * prepare/set_factors/destroy.  <-> attributes self.iK, self.beta (gp_model.py:187). */
+int gpmpc_get_factors(gpmpc_t* h, const double** iK_dev, const double** beta_dev);
+
+/* Copies of the cached factors into caller-owned device buffers (either may be NULL):
+ * iK_dst_dev (D,N,N), beta_dst_dev (D,N).  Asynchronous on `stream`. */
+int gpmpc_read_factors(gpmpc_t* h, double* iK_dst_dev, double* beta_dst_dev, void* stream);
+
+/* Borrowed device pointer to the (D,N,N) Gram matrices K + noise*I of the last prepare
+ * (diagnostics / tests).  Only valid when the handle was created with keep_gram, see
+ * gpmpc_set_option. */
+int gpmpc_get_gram(gpmpc_t* h, const double** K_dev);
+
+/* Options: "keep_gram" (0/1, default 0), "threads" (rollout workgroup size: 0 = auto,
+ * 256/512/1024), "force_global_scratch" (0/1, testing the large-N path at small N). */
+int gpmpc_set_option(gpmpc_t* h, const char* name, long long value);
+
+/*
+ * Quadratic cost of SetpointStateRewardMapper
+ * (states_reward_mappers/setpoint_distance_reward_mapper.py:12-68,124-142) and the LCB
+ * objective settings of compute_mean_lcb_trajectory (gp_mpc_controller.py:270-276).
+ *   target_host (D+A)   W_host (D+A,D+A)   W_T_host (D,D)   kappa = exploration_factor
+ *   clip_to_zero  = reward.clip_lower_bound_cost_to_0
+ *   state_min_host/state_max_host (D) or NULL = reward.use_constraints False
+ */
+int gpmpc_set_cost(gpmpc_t* h, const double* target_host, const double* W_host,
+                   const double* W_T_host, double kappa, int clip_to_zero,
+                   const double* state_min_host, const double* state_max_host, int D, int A);
+
+/*
+ * gpmpc_rollout  <->  B x [ predict_trajectory (gp_model.py:60-110, H calls of
+ * predict_next_state_change :112-180) + get_rewards_trajectory
+ * (setpoint_distance_reward_mapper.py:144-149) + forward value of
+ * compute_mean_lcb_trajectory (gp_mpc_controller.py:267-276) ], one candidate action
+ * sequence per workgroup, all H steps inside one launch.
+ *   actions_dev (B,H,A) model-space actions in [0,1]
+ *   mu0_host (D), S0_host (D,D): initial state distribution (same for all candidates)
+ *   include_time / time0: ModelConfig.include_time_model, current_time_idx (gp_model.py:101-102)
+ * Outputs (each may be NULL to skip the store):
+ *   mu_out_dev (B,H+1,D)  Sig_out_dev (B,H+1,D,D)   index 0 = input state (gp_model.py:91-92)
+ *   cost_mu_out_dev (B,H+1) = -rewards   cost_var_out_dev (B,H+1)
+ *   J_out_dev (B) = mean-LCB objective the optimiser / argmin sees
+ */
+int gpmpc_rollout(gpmpc_t* h, const double* actions_dev, const double* mu0_host,
+                  const double* S0_host, int B, int H, int A, int include_time, double time0,
+                  double* mu_out_dev, double* Sig_out_dev, double* cost_mu_out_dev,
+                  double* cost_var_out_dev, double* J_out_dev, void* stream);
+
+/*
+ * gpmpc_argmin  <->  the keep-the-best rule of gp_mpc_controller.py:146-148 applied to a
+ * vector of objective values: first strict minimum wins; a NaN in slot 0 is adopted and
+ * never displaced.  Synchronises `stream`; results are written to HOST memory.
+ */
+int gpmpc_argmin(gpmpc_t* h, const double* J_dev, int B, double* best_J_host,
+                 long long* best_idx_host, void* stream);
+
+/* Kernel-only timing helper for bench.py: runs `reps` rollouts back to back on `stream`
+ * bracketed by HIP events recorded on THAT stream and returns the average milliseconds
+ * per launch in *ms_host (outputs as gpmpc_rollout; synchronises). */
+int gpmpc_rollout_timed(gpmpc_t* h, const double* actions_dev, const double* mu0_host,
+                        const double* S0_host, int B, int H, int A, int include_time, double time0,
+                        double* J_out_dev, int reps, float* ms_host, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPMPC_H */
