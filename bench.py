@@ -1,0 +1,201 @@
+#!/usr/bin/env python3
+"""bench.py -- MPC trajectory rollouts/sec of the MI355X-native GP-MPC hot path.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one batch of candidate action sequences: one
+gpmpc_rollout launch (H-step moment-matched propagation + stage/terminal costs + LCB objective
+for every candidate, trajectories written to HBM) + the argmin (and, for N > 1, the 16-byte
+RCCL gather and the winner broadcast).  Workload = BASELINE.json configs[1] (Pendulum scale:
+N=200 memory points, D=3, A=1, H=25, B=256 candidates, fp64) per GPU; candidates shard across
+ranks with no data-path collective, so scaling is weak (B = 256 per GPU).  Inputs are resident
+in HBM before the timed region.  `prepare` (K build + Cholesky + inverse, once per control step)
+is timed separately and reported beside the metric.
+
+One JSON line on stdout (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F64_VECTOR_TFLOPS = 78.6     # MI355X fp64 vector peak (AMD spec; = 1/2 of the 157.3 TF fp32 vector peak)
+
+
+def algorithmic_flops_per_rollout(N, D, A, E, H):
+    """F_step = P N^2 (2E+7) + 2 D N^2 + P N (4E^2+4E) + D N (2E^2+7E+4), exp = 1 flop."""
+    P = D * (D + 1) // 2
+    f_step = P * N * N * (2 * E + 7) + 2 * D * N * N + P * N * (4 * E * E + 4 * E) + D * N * (2 * E * E + 7 * E + 4)
+    return H * f_step
+
+
+def algorithmic_bytes_per_rollout(N, D, E, H):
+    """Q_step = 8 (D N^2 + N E + 2 D N) compulsory bytes, no cross-candidate reuse."""
+    return H * 8 * (D * N * N + N * E + 2 * D * N)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c2", help="c1..c5 shape from BASELINE.json (default c2 = configs[1])")
+    ap.add_argument("--candidates-per-gpu", type=int, default=0, help="override B per GPU")
+    ap.add_argument("--points", type=int, default=0, help="override N")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import gp_mpc_amd
+    from gp_mpc_amd import sharding
+    from oracle import synth
+
+    n, d, a, h, b, tm = synth.SHAPES[args.workload]
+    N = args.points or n
+    Bg = args.candidates_per_gpu or min(b, 256 if args.workload == "c2" else b)
+    B_total = Bg * world
+    w = synth.make_workload(N, d, a, h, B_total, include_time=tm, seed=0)
+    _, D, A, E, H, _ = w.dims
+    lo, hi = sharding.shard_bounds(B_total, world, rank)
+
+    eng = gp_mpc_amd.HipEngine(local_rank)
+    eng.set_cost(w.target, w.W, w.W_T, w.kappa)
+    X = torch.as_tensor(w.X, device=device)
+    Y = torch.as_tensor(w.Y, device=device)
+    ls = torch.as_tensor(w.lengthscales, device=device)
+    osc = torch.as_tensor(w.outputscales, device=device)
+    nz = torch.as_tensor(w.noises, device=device)
+    actions = torch.as_tensor(w.actions[lo:hi], device=device).contiguous()
+
+    # prepare: once per control step, timed separately (median of 5 after 1 warm-up)
+    eng.prepare(X, Y, ls, osc, nz)
+    tp = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        eng.prepare(X, Y, ls, osc, nz)
+        torch.cuda.synchronize()
+        tp.append(time.perf_counter() - t0)
+    prepare_ms = float(np.median(tp) * 1e3)
+
+    def step():
+        out = eng.rollout(actions, w.mu0, w.S0, w.include_time, w.time0)
+
+        def ev(_):
+            return eng.argmin(out["J"], first_global_index=lo)
+        return sharding.sharded_argmin(ev, actions, lo, B_total, device), out
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        (best_J, best_i, best_act), out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    # kernel-only time of the dominant kernel: HIP events on the launch stream
+    kernel_ms, _ = eng.rollout_timed(actions, w.mu0, w.S0, max(3, min(args.steps, 20)), w.include_time, w.time0)
+
+    if rank == 0:
+        flops_launch = algorithmic_flops_per_rollout(N, D, A, E, H) * Bg
+        achieved_tflops = flops_launch / (kernel_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(f"{args.workload}:N{N}:B{Bg}")
+            except Exception:
+                traffic = None
+        result = {
+            "metric": "MPC trajectory rollouts/sec",
+            "value": B_total * args.steps / elapsed,
+            "unit": "rollouts/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"{args.workload}: GP-MPC rollouts N={N} D={D} A={A} E={E} H={H} B={Bg}/GPU fp64 "
+                                   f"(BASELINE.json configs[{list(synth.SHAPES).index(args.workload)}] shape)",
+                       "N": N, "D": D, "A": A, "H": H, "B_per_gpu": Bg, "B_total": B_total,
+                       "parallelism": f"candidates sharded x{world}, RCCL gather of (J, idx) only"},
+            "roofline": {"bound": "valu_f64", "achieved": achieved_tflops, "peak": PEAK_F64_VECTOR_TFLOPS,
+                         "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F64_VECTOR_TFLOPS, "traffic": traffic,
+                         "kernel": "rollout_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_flops_per_launch": flops_launch,
+                         "algorithmic_bytes_per_launch": algorithmic_bytes_per_rollout(N, D, E, H) * Bg,
+                         "note": "SURVEY 8(d) flop count (exp = 1 flop) x B candidates / HIP-event kernel time; "
+                                 "bound is fp64 VALU + software exp, not HBM (table T_a is L2-resident)"},
+            "prepare_ms": prepare_ms,
+            "control_step_ms": prepare_ms + elapsed / args.steps * 1e3,
+            "best_index": int(best_i), "best_J": float(best_J),
+        }
+        # parity spot check against the CPU oracle on identical inputs (not timed)
+        from oracle import gpmpc_oracle as orc
+        try:
+            sub = [0, Bg // 2, Bg - 1]
+            f = orc.Factors(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+            ref = orc.evaluate_candidates(f, w, actions=w.actions[lo:hi][sub])
+            mu = out["mu"].cpu().numpy()[sub]
+            Sg = out["Sig"].cpu().numpy()[sub]
+            result["parity"] = {"max_abs_dmean": float(np.max(np.abs(mu - ref["mu"]))),
+                                "max_rel_cov": float(np.max(np.abs(Sg - ref["Sig"])) / np.max(np.abs(ref["Sig"]))),
+                                "max_rel_J": float(np.max(np.abs(out["J"].cpu().numpy()[sub] - ref["J"]) / np.abs(ref["J"]))),
+                                "vs": "CPU oracle (validated against reference goldens), 3 candidates"}
+        except Exception as e:   # the bench number must not depend on the checker
+            result["parity"] = {"error": repr(e)}
+        if world == 1 and not args.no_cpu_baseline:
+            from oracle.unfused_torch import time_rollouts
+            wc = synth.make_workload(N, d, a, h, 8, include_time=tm, seed=0)
+            fc = orc.Factors(wc.X, wc.Y, wc.lengthscales, wc.outputscales, wc.noises)
+            rate, dt, _ = time_rollouts(wc, 4, fc)
+            n_roll = int(min(400, max(8, args.cpu_seconds * rate)))
+            rate, dt, _ = time_rollouts(wc, n_roll, fc)
+            result["cpu_baseline"] = {"value": rate, "unit": "rollouts/s", "cores": torch.get_num_threads(),
+                                      "kind": "port",
+                                      "sample": f"{n_roll} sequential forward rollouts (same N,D,H) of oracle/unfused_torch.py "
+                                                f"(reference op sequence, (D,D,N,N) temporaries, torch fp64, default threads) "
+                                                f"in {dt:.1f} s; os.cpu_count()={os.cpu_count()}"}
+            result["speedup_vs_cpu_baseline"] = result["value"] / rate
+        print(json.dumps(result))
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,8 +45,11 @@ SIGNATURES = {
     "gpmpc_set_cost": (C.c_int, [_P, _P, _P, _P, _D, _I, _P, _P, _I, _I]),
     "gpmpc_rollout": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P]),
     "gpmpc_rollout_timed": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _I, C.POINTER(C.c_float), _P]),
-    "gpmpc_argmin": (C.c_int, [_P, _P, _I, C.POINTER(_D), C.POINTER(C.c_longlong), _P]),
+    "gpmpc_argmin": (C.c_int, [_P, _P, _I, C.c_longlong, C.POINTER(_D), C.POINTER(C.c_longlong), _P]),
 }
+
+
+ABI_VERSION = 2
 
 
 def load(path=LIB_PATH):
@@ -59,6 +62,8 @@ def load(path=LIB_PATH):
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    if lib.gpmpc_abi_version() != ABI_VERSION:
+        raise ImportError(f"{path}: ABI version {lib.gpmpc_abi_version()} != expected {ABI_VERSION}; rebuild the HIP library")
     return lib
 
 

@@ -25,7 +25,7 @@ static void free_buf(Buf& b) {
 
 extern "C" {
 
-int gpmpc_abi_version(void) { return 1; }
+int gpmpc_abi_version(void) { return 2; }
 
 int gpmpc_create(gpmpc_t** out, int device_id) {
     if (!out) return GPMPC_ERR_ARG;
@@ -203,12 +203,12 @@ int gpmpc_rollout_timed(gpmpc_t* g, const double* actions, const double* mu0, co
     return rc;
 }
 
-int gpmpc_argmin(gpmpc_t* g, const double* J, int B, double* best_J, long long* best_idx, void* stream) {
-    if (!g || !J || B < 1) return bad(g, "bad argument");
+int gpmpc_argmin(gpmpc_t* g, const double* J, int B, long long first, double* best_J, long long* best_idx, void* stream) {
+    if (!g || !J || B < 1 || first < 0) return bad(g, "bad argument");
     Handle* h = H_(g);
     GPMPC_HIP_CHECK(h, hipSetDevice(h->device));
     hipStream_t s = (hipStream_t)stream;
-    int rc = launch_argmin(h, J, B, s);
+    int rc = launch_argmin(h, J, B, first, s);
     if (rc) return rc;
     double out[2];
     GPMPC_HIP_CHECK(h, hipMemcpyAsync(out, h->best.p, sizeof out, hipMemcpyDeviceToHost, s));

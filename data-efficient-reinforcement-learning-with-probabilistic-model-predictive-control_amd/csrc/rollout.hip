@@ -13,7 +13,7 @@ int launch_rollout_dp16(Handle*, RolloutArgs&, int, bool, size_t, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
 // Keep-the-best rule of gp_mpc_controller.py:146-148 over a vector (single workgroup).
-__global__ __launch_bounds__(1024) void argmin_kernel(const double* J, int B, double* out) {
+__global__ __launch_bounds__(1024) void argmin_kernel(const double* J, int B, long long first, double* out) {
     __shared__ double s_v[16];
     __shared__ long long s_i[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -36,17 +36,17 @@ __global__ __launch_bounds__(1024) void argmin_kernel(const double* J, int B, do
             const long long oi = s_i[w];
             if (oi >= 0 && (bi < 0 || ov < bv || (ov == bv && oi < bi))) { bv = ov; bi = oi; }
         }
-        if (B > 0 && J[0] != J[0]) { bv = J[0]; bi = 0; }      // NaN in slot 0 is adopted and stays
-        if (bi < 0) { bv = INFINITY; }                         // all-NaN tail: reference returns None
+        if (first == 0 && B > 0 && J[0] != J[0]) { bv = J[0]; bi = 0; }   // NaN in global slot 0 is adopted and stays
+        if (bi < 0) bv = INFINITY;                              // nothing selectable in this shard
         out[0] = bv;
-        reinterpret_cast<long long*>(out)[1] = bi;
+        reinterpret_cast<long long*>(out)[1] = (bi < 0) ? -1 : bi + first;
     }
 }
 
-int launch_argmin(Handle* h, const double* J, int B, hipStream_t s) {
+int launch_argmin(Handle* h, const double* J, int B, long long first, hipStream_t s) {
     int rc = grow(h, h->best, 2);
     if (rc) return rc;
-    hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, J, B, h->best.p);
+    hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, J, B, first, h->best.p);
     GPMPC_HIP_CHECK(h, hipGetLastError());
     return GPMPC_OK;
 }

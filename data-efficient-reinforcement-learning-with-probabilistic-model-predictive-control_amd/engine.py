@@ -156,9 +156,11 @@ class HipEngine:
         return float(ms.value), J
 
     # -- a8 ----------------------------------------------------------------------------
-    def argmin(self, J):
+    def argmin(self, J, first_global_index=0):
+        """Keep-the-best rule over J; returns (best_J, GLOBAL index) -- index -1 if nothing selectable."""
         J = self._dev(J)
         bj = C.c_double()
         bi = C.c_longlong()
-        self._check(self.lib.gpmpc_argmin(self._h, J.data_ptr(), J.numel(), C.byref(bj), C.byref(bi), self._stream()))
+        self._check(self.lib.gpmpc_argmin(self._h, J.data_ptr(), J.numel(), int(first_global_index), C.byref(bj),
+                                          C.byref(bi), self._stream()))
         return float(bj.value), int(bi.value)

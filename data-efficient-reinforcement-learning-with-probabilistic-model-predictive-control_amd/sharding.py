@@ -1,0 +1,83 @@
+"""Candidate sharding across the GPUs of one node (one process per GPU).
+
+Candidate action sequences are independent given the shared model and initial state, so rank r
+evaluates the contiguous slice [lo_r, hi_r) with no data-path collective.  The only exchange is
+the final argmin: one all_gather of (J, global index) = 16 bytes per rank over RCCL/xGMI
+(latency-bound), after which every rank knows the winner and its owner; the owner broadcasts
+the winning (H, A) sequence.  The reference has no distributed code; the rule reproduced here
+is its sequential keep-the-best loop (rl_gp_mpc/control_objects/controllers/
+gp_mpc_controller.py:146-148): lowest global index wins ties, a NaN in global slot 0 is
+adopted and never displaced, any other NaN is never selected.
+"""
+import math
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(num_candidates, world_size, rank):
+    """Contiguous balanced slice [lo, hi) of range(num_candidates) owned by `rank`."""
+    base, extra = divmod(int(num_candidates), int(world_size))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def owner_of(index, num_candidates, world_size):
+    for r in range(world_size):
+        lo, hi = shard_bounds(num_candidates, world_size, r)
+        if lo <= index < hi:
+            return r
+    raise ValueError(index)
+
+
+def combine_best(pairs):
+    """pairs: per-rank (J, global_index) in rank order; index -1 = nothing selectable.
+    Returns (J, index) of the global winner, or (inf, -1)."""
+    best_J, best_i = math.inf, -1
+    for J, i in pairs:
+        i = int(i)
+        if i < 0:
+            continue
+        if i == 0 and J != J:                  # NaN adopted in global slot 0: stays the winner
+            return J, 0
+        if best_i < 0 or J < best_J or (J == best_J and i < best_i):
+            best_J, best_i = J, i
+    return best_J, best_i
+
+
+def gather_best(local_J, local_index, device, group=None):
+    """all_gather of the per-rank (J, global index); returns combine_best over ranks."""
+    world = dist.get_world_size(group)
+    mine = torch.tensor([float(local_J), float(local_index)], dtype=torch.float64, device=device)
+    flat = torch.empty(world * 2, dtype=torch.float64, device=device)     # flat: accepted by gloo and RCCL
+    dist.all_gather_into_tensor(flat, mine, group=group)
+    allp = flat.view(world, 2).cpu().tolist()
+    return combine_best([(p[0], int(p[1])) for p in allp])
+
+
+def sharded_argmin(evaluate_slice, actions_local, lo, num_candidates, device, group=None):
+    """Evaluate this rank's slice and agree on the global winner.
+
+    evaluate_slice(actions_local) -> (best_J, best_GLOBAL_index or -1) for the local slice whose
+    first global index is `lo` (HipEngine.rollout + HipEngine.argmin(first_global_index=lo)).
+    Returns (best_J, best_index, best_actions (H, A) tensor on `device`).
+    """
+    if not (dist.is_available() and dist.is_initialized()):
+        J, i = evaluate_slice(actions_local)
+        if i < 0:
+            raise FloatingPointError("no selectable candidate (all objectives NaN)")
+        return J, i, actions_local[i - lo].clone()
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    J, i = evaluate_slice(actions_local)
+    J, i = gather_best(J, i, device, group)
+    if i < 0:
+        raise FloatingPointError("no selectable candidate (all objectives NaN)")
+    owner = owner_of(i, num_candidates, world)
+    H, A = actions_local.shape[1:]
+    win = torch.empty((H, A), dtype=torch.float64, device=device)
+    if rank == owner:
+        win.copy_(actions_local[i - lo])
+    src = dist.get_global_rank(group, owner) if group is not None else owner
+    dist.broadcast(win, src=src, group=group)
+    return J, i, win

@@ -123,11 +123,14 @@ int gpmpc_rollout(gpmpc_t* h, const double* actions_dev, const double* mu0_host,
 
 /*
  * gpmpc_argmin  <->  the keep-the-best rule of gp_mpc_controller.py:146-148 applied to a
- * vector of objective values: first strict minimum wins; a NaN in slot 0 is adopted and
- * never displaced.  Synchronises `stream`; results are written to HOST memory.
+ * vector of objective values: first strict minimum wins; a NaN in GLOBAL slot 0 is adopted
+ * and never displaced; any other NaN is never selected.  `first_global_index` is the global
+ * index of J_dev[0] (0 on one GPU; the shard offset when candidates are sharded over GPUs),
+ * the returned index is global.  A shard with no selectable value returns index -1, J = +inf.
+ * Synchronises `stream`; results are written to HOST memory.
  */
-int gpmpc_argmin(gpmpc_t* h, const double* J_dev, int B, double* best_J_host,
-                 long long* best_idx_host, void* stream);
+int gpmpc_argmin(gpmpc_t* h, const double* J_dev, int B, long long first_global_index,
+                 double* best_J_host, long long* best_idx_host, void* stream);
 
 /* Kernel-only timing helper for bench.py: runs `reps` rollouts back to back on `stream`
  * bracketed by HIP events recorded on THAT stream and returns the average milliseconds

@@ -100,3 +100,23 @@ def test_symmetric_psd_on_well_conditioned_data():
     Sig = g["Sig"]
     assert np.max(np.abs(Sig - Sig.transpose(0, 1, 3, 2))) < 1e-10
     assert np.linalg.eigvalsh(0.5 * (Sig + Sig.transpose(0, 1, 3, 2))).min() > 0
+
+
+@pytest.mark.parametrize("name", ["traj_c1", "traj_c4_time", "traj_c5class"])
+def test_unfused_torch_baseline_matches_reference(name):
+    """The CPU baseline of record (oracle/unfused_torch.py) reproduces the reference goldens."""
+    import torch
+    from oracle.unfused_torch import UnfusedTorchModel
+    g = load(name)
+    w = workload_of(g)
+    K = torch.as_tensor(orc.rbf_ard_gram(w.X, w.lengthscales, w.outputscales))
+    iK, beta = UnfusedTorchModel.factorize(K, torch.as_tensor(w.noises), torch.as_tensor(w.Y))
+    assert rel_err(beta.numpy(), g["beta"]) < 1e-9
+    m = UnfusedTorchModel(w.X, iK, beta, w.lengthscales, w.outputscales)
+    tt = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)  # noqa: E731
+    for b in range(min(2, w.actions.shape[0])):
+        mus, Sigs = m.predict_trajectory(tt(w.actions[b]), tt(w.mu0), tt(w.S0), w.include_time, w.time0)
+        assert rel_err(mus.numpy(), g["mu"][b]) < 1e-9
+        assert rel_err(Sigs.numpy(), g["Sig"][b]) < 1e-7
+        J = m.lcb(mus, Sigs, tt(w.actions[b]), tt(w.target), tt(w.W), tt(w.W_T), w.kappa)
+        assert abs(float(J) - g["J"][b]) < 1e-8 * max(1.0, abs(g["J"][b]))
