@@ -7,3 +7,5 @@ transition-model / controller interface for that path.
 """
 from ._lib import GpmpcError, NotPositiveDefiniteError, LIB_PATH  # noqa: F401
 from .engine import HipEngine  # noqa: F401
+from .control_objects.controllers.gp_mpc_controller import GpMpcController  # noqa: F401,E402
+from .control_objects.models.gp_model import GpStateTransitionModel  # noqa: F401,E402

@@ -1,0 +1,252 @@
+"""GpMpcController -- drop-in for rl_gp_mpc/control_objects/controllers/gp_mpc_controller.py.
+
+Same constructor and method set as the reference (what run_env_function.py:18-47 calls):
+get_action, get_iter_info, compute_cost_unnormalized, add_memory, check_and_close_processes,
+compute_mean_lcb_trajectory; `compute_action` is an alias of get_action.
+
+What changes is WHERE the work happens.  The reference evaluates one action sequence per Python
+call (:229-285) inside a sequential restart loop (:125-148).  Here every evaluation is a batch in
+ONE launch of the HIP rollout kernel:
+
+  * optimize=False (random shooting, :142-144): all `restarts_optim` candidates at once, argmin on
+    the device, candidates optionally sharded across GPUs (sharding.py);
+  * optimize=True (scipy L-BFGS-B with jac=True, :132-141): value + gradient per evaluation, the
+    gradient from a 4th-order central difference over the H*A model actions, i.e. 4*H*A + 1
+    candidates in one launch (the analytic adjoint kernel is SURVEY 8(f) row 1, not built yet).
+    The reference's two pass-through clamps (action clamp of DerivativeActionMapper, optional
+    clip of the UCB at 0) have identity backward; the finite difference is taken where those
+    clamps are transparent so the returned gradient has the same meaning.
+"""
+import multiprocessing
+
+import numpy as np
+import torch
+from scipy.optimize import minimize
+
+from ..actions_mappers.action_init_functions import (generate_mpc_action_init_frompreviousiter,
+                                                     generate_mpc_action_init_random)
+from ..actions_mappers.mappers import DerivativeActionMapper, NormalizationActionMapper
+from ..memories.gp_memory import Memory
+from ..models.gp_model import GpStateTransitionModel
+from ..observations_states_mappers.normalization_observation_state_mapper import NormalizationObservationStateMapper
+from ..states_reward_mappers.setpoint_distance_reward_mapper import SetpointStateRewardMapper
+from .abstract_controller import BaseControllerObject
+from .iteration_info_class import IterationInformation
+
+F64 = torch.float64
+FD_STEP = 1e-3           # 4th-order stencil: truncation ~ h^4, rounding ~ 1e-13 / h
+
+
+class GpMpcController(BaseControllerObject):
+    def __init__(self, observation_low, observation_high, action_low, action_high, config, engine=None, device=None):
+        self.config = config
+        self.observation_state_mapper = NormalizationObservationStateMapper(
+            config=config.observation, observation_low=observation_low, observation_high=observation_high)
+        Mapper = DerivativeActionMapper if config.actions.limit_action_change else NormalizationActionMapper
+        self.actions_mapper = Mapper(config=config.actions, action_low=action_low, action_high=action_high,
+                                     len_horizon=config.controller.len_horizon)
+        self.transition_model = GpStateTransitionModel(config=config.model,
+                                                       dim_state=self.observation_state_mapper.dim_observation,
+                                                       dim_action=self.actions_mapper.dim_action,
+                                                       engine=engine, device=device)
+        self.state_reward_mapper = SetpointStateRewardMapper(config=config.reward)
+        self.memory = Memory(config.memory, dim_input=self.transition_model.dim_input,
+                             dim_state=self.transition_model.dim_state,
+                             include_time_model=self.transition_model.config.include_time_model,
+                             step_model=config.controller.num_repeat_actions)
+        self.actions_mpc_previous_iter = None
+        self.iter_ctrl = 0
+        self.num_cores_main = multiprocessing.cpu_count()
+        self.ctx = multiprocessing.get_context("spawn")
+        self.queue_train = self.ctx.Queue()
+        self.info_iters = {}
+        self.num_rollouts = 0          # candidate trajectories evaluated so far (throughput accounting)
+
+    # ------------------------------------------------------------------------------ public
+    def get_action(self, obs_mu, obs_var=None, random=False):
+        """Reference :52-112.  Returns the raw (denormalised) action for the environment, shape (A,)."""
+        self.check_and_close_processes()
+        cc = self.config.controller
+        if self.iter_ctrl % cc.num_repeat_actions == 0:
+            self.memory.prepare_for_model()
+            state_mu, state_var = self.observation_state_mapper.get_state(obs=obs_mu, obs_var=obs_var, update_internals=True)
+            actions_model = self._get_random_actions(state_mu, state_var) if random \
+                else self._get_optimal_actions(state_mu, state_var)
+            actions_raw = self.actions_mapper.transform_action_model_to_action_raw(actions_model, update_internals=True)
+            next_action_raw = actions_raw[0]
+            reward, reward_var = self.state_reward_mapper.get_reward(state_mu, state_var, actions_model[0])
+            std_pred = torch.diagonal(self.states_var_pred, dim1=-2, dim2=-1).sqrt()
+            idx_pred = np.arange(self.iter_ctrl, self.iter_ctrl + cc.len_horizon * cc.num_repeat_actions,
+                                 cc.num_repeat_actions)
+            self.iter_info = IterationInformation(
+                iteration=self.iter_ctrl, state=self.states_mu_pred[0], cost=-reward.item(),
+                cost_std=reward_var.sqrt().item(),
+                mean_predicted_cost=np.min([-self.rewards_trajectory.mean().item(), 3]),
+                mean_predicted_cost_std=self.rewards_traj_var.sqrt().mean().item(),
+                lower_bound_mean_predicted_cost=self.cost_traj_mean_lcb.item(),
+                predicted_idxs=idx_pred, predicted_states=self.states_mu_pred, predicted_states_std=std_pred,
+                predicted_actions=actions_model, predicted_costs=-self.rewards_trajectory,
+                predicted_costs_std=self.rewards_traj_var.sqrt())
+            self.store_iter_info(self.iter_info)
+            self.past_action = next_action_raw
+        else:
+            next_action_raw = self.past_action
+        self.iter_ctrl += 1
+        return next_action_raw.detach().cpu().numpy().copy() if isinstance(next_action_raw, torch.Tensor) \
+            else np.array(next_action_raw)
+
+    compute_action = get_action      # the name BASELINE.json's north_star uses
+
+    def evaluate_candidates(self, actions_mpc_batch, obs_mu, obs_var, trajectories=False):
+        """Objective of B optimiser vectors (B, H*A) in one launch -> dict of device tensors + 'actions_model'."""
+        acts = self.actions_mapper.mpc_to_model_batch(np.asarray(actions_mpc_batch, dtype=np.float64))
+        self.transition_model.set_cost(self.config.reward)
+        out = self.transition_model.predict_trajectory_batch(
+            acts, obs_mu, obs_var, self.config.controller.len_horizon, self.iter_ctrl,
+            trajectories=trajectories, stage_costs=True)
+        self.num_rollouts += acts.shape[0]
+        out["actions_model"] = acts
+        return out
+
+    def compute_mean_lcb_trajectory(self, actions_mpc, obs_mu, obs_var):
+        """Reference :229-285: (mean-LCB cost, d cost / d actions_mpc) for ONE optimiser vector; also caches
+        the predicted trajectory and its costs on `self` for IterationInformation (:279-283)."""
+        H, A = self.config.controller.len_horizon, self.actions_mapper.dim_action
+        base = self.actions_mapper.mpc_to_model_batch(np.asarray(actions_mpc, dtype=np.float64).reshape(1, -1))[0]
+        n = H * A
+        cand = np.repeat(base[None], 4 * n + 1, axis=0)            # [base, +h, -h, +2h, -2h] per coordinate
+        flat = cand.reshape(4 * n + 1, n)
+        k = np.arange(n)
+        flat[1 + k, k] += FD_STEP
+        flat[1 + n + k, k] -= FD_STEP
+        flat[1 + 2 * n + k, k] += 2 * FD_STEP
+        flat[1 + 3 * n + k, k] -= 2 * FD_STEP
+        self.transition_model.set_cost(self.config.reward)
+        out = self.transition_model.predict_trajectory_batch(cand, obs_mu, obs_var, H, self.iter_ctrl,
+                                                             trajectories=True, stage_costs=True)
+        self.num_rollouts += cand.shape[0]
+        cm = out["cost_mu"].cpu().numpy()
+        cv = out["cost_var"].cpu().numpy()
+        J_clip = out["J"].cpu().numpy()
+        J_free = np.mean(cm - self.config.reward.exploration_factor * np.sqrt(cv), axis=1)   # clamp transparent
+        g_model = (8.0 * (J_free[1:1 + n] - J_free[1 + n:1 + 2 * n])
+                   - (J_free[1 + 2 * n:1 + 3 * n] - J_free[1 + 3 * n:])) / (12.0 * FD_STEP)
+        grad = self.actions_mapper.chain_grad_model_to_mpc(g_model.reshape(H, A))
+        self._cache_trajectory(out, 0)
+        return float(J_clip[0]), grad
+
+    def compute_cost_unnormalized(self, obs, action, obs_var=None):
+        """Reference :287-305: cost of an un-normalised (obs, action) pair -> (mean, variance)."""
+        state_mu, state_var = self.observation_state_mapper.get_state(obs=obs, obs_var=obs_var, update_internals=False)
+        action_model = self.actions_mapper.transform_action_raw_to_action_model(action)
+        r, v = self.state_reward_mapper.get_reward(state_mu, state_var, action_model)
+        return -r.item(), v.item()
+
+    def add_memory(self, obs, action, obs_new, reward, predicted_state=None, predicted_state_std=None):
+        """Reference :165-199."""
+        state_mu, _ = self.observation_state_mapper.get_state(obs=obs, update_internals=False)
+        state_mu_new, _ = self.observation_state_mapper.get_state(obs=obs_new, update_internals=False)
+        action_model = self.actions_mapper.transform_action_raw_to_action_model(action)
+        self.memory.add(state_mu, action_model, state_mu_new, reward, iter_ctrl=self.iter_ctrl - 1,
+                        predicted_state=predicted_state, predicted_state_std=predicted_state_std)
+        training_idle = not (hasattr(self, "p_train") and not self.p_train._closed)
+        if self.iter_ctrl % self.config.training.training_frequency == 0 and training_idle:
+            self.start_training_process()
+
+    def start_training_process(self):
+        saved_state = self.transition_model.save_state()
+        saved_state.to_arrays()
+        tc = self.config.training
+        self.p_train = self.ctx.Process(target=GpStateTransitionModel.train,
+                                        args=(self.queue_train, saved_state, tc.lr_train, tc.iter_train,
+                                              tc.clip_grad_value, tc.print_train, tc.step_print_train))
+        self.p_train.start()
+
+    def check_and_close_processes(self):
+        """Reference :216-227: collect finished training, load the new hyper-parameters, refactorise."""
+        if hasattr(self, "p_train") and not self.p_train._closed and not self.p_train.is_alive():
+            params = self.queue_train.get()
+            self.p_train.join()
+            for model, p in zip(self.transition_model.models, params):
+                model.initialize(**p)
+            self.p_train.close()
+            x_mem, y_mem = self.memory.get()
+            self.transition_model.prepare_inference(x_mem, y_mem)
+
+    def get_iter_info(self):
+        return self.iter_info
+
+    def store_iter_info(self, iter_info):
+        for key, val in vars(iter_info).items():
+            self.info_iters.setdefault(key, []).append(val)
+
+    # ---------------------------------------------------------------------------- internals
+    def _cache_trajectory(self, out, idx):
+        self.states_mu_pred = out["mu"][idx].cpu()
+        self.states_var_pred = out["Sig"][idx].cpu()
+        self.rewards_trajectory = -out["cost_mu"][idx].cpu()
+        self.rewards_traj_var = out["cost_var"][idx].cpu()
+        self.cost_traj_mean_lcb = -out["J"][idx].cpu()
+
+    def _prepare(self):
+        x_mem, y_mem = self.memory.get()
+        self.transition_model.prepare_inference(x_mem, y_mem)
+
+    def _get_optimal_actions(self, state_mu, state_var):
+        """Reference :114-153."""
+        self._prepare()
+        cc = self.config.controller
+        H, A = cc.len_horizon, self.actions_mapper.dim_action
+        if not cc.optimize:
+            return self._random_shooting(state_mu, state_var)
+        opt_fun, best = np.inf, None
+        for idx_restart in range(cc.restarts_optim):
+            if cc.init_from_previous_actions and self.actions_mpc_previous_iter is not None and idx_restart == 0:
+                x0 = generate_mpc_action_init_frompreviousiter(self.actions_mpc_previous_iter, dim_action=A)
+            else:
+                x0 = generate_mpc_action_init_random(len_horizon=H, dim_action=A)
+            res = minimize(fun=self.compute_mean_lcb_trajectory, x0=x0, jac=True, args=(state_mu, state_var),
+                           method="L-BFGS-B", bounds=self.actions_mapper.bounds, options=cc.actions_optimizer_params)
+            if res.fun < opt_fun or (best is None and np.isnan(res.fun)):
+                opt_fun, best = res.fun, res.x
+        self.actions_mpc_previous_iter = best.copy()
+        return self.actions_mapper.transform_action_mpc_to_action_model(best)
+
+    def _random_shooting(self, state_mu, state_var):
+        """optimize=False: the reference draws TWO sequences per restart and evaluates the second
+        (:127-130 then :143); reproduced so that a seeded run sees the same candidates."""
+        from ... import sharding
+        cc = self.config.controller
+        H, A = cc.len_horizon, self.actions_mapper.dim_action
+        cands = []
+        for idx_restart in range(cc.restarts_optim):
+            if cc.init_from_previous_actions and self.actions_mpc_previous_iter is not None and idx_restart == 0:
+                generate_mpc_action_init_frompreviousiter(self.actions_mpc_previous_iter, dim_action=A)
+            else:
+                generate_mpc_action_init_random(len_horizon=H, dim_action=A)
+            cands.append(generate_mpc_action_init_random(len_horizon=H, dim_action=A))
+        cands = np.stack(cands)
+        B = cands.shape[0]
+        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        rank = torch.distributed.get_rank() if world > 1 else 0
+        lo, hi = sharding.shard_bounds(B, world, rank)
+        out = self.evaluate_candidates(cands[lo:hi], state_mu, state_var, trajectories=True)
+        eng = self.transition_model.engine
+        local = torch.as_tensor(cands[lo:hi].reshape(hi - lo, H, A), device=eng.device)
+        J, best, win = sharding.sharded_argmin(lambda _: eng.argmin(out["J"], first_global_index=lo),
+                                               local, lo, B, eng.device)
+        # the reference caches the LAST evaluated trajectory, not the winner's (:279-283)
+        if world == 1 or rank == world - 1:
+            self._cache_trajectory(out, hi - lo - 1)
+        self.best_candidate_index, self.best_candidate_J = best, J
+        self.actions_mpc_previous_iter = win.cpu().numpy().reshape(-1).copy()
+        return self.actions_mapper.transform_action_mpc_to_action_model(self.actions_mpc_previous_iter)
+
+    def _get_random_actions(self, state_mu, state_var):
+        """Reference :155-163: one random sequence, evaluated only to fill the logging caches."""
+        H, A = self.config.controller.len_horizon, self.actions_mapper.dim_action
+        actions_mpc = generate_mpc_action_init_random(len_horizon=H, dim_action=A)
+        self._prepare()
+        out = self.evaluate_candidates(actions_mpc[None], state_mu, state_var, trajectories=True)
+        self._cache_trajectory(out, 0)
+        return self.actions_mapper.transform_action_mpc_to_action_model(actions_mpc)

@@ -1,0 +1,249 @@
+"""GpStateTransitionModel -- drop-in for rl_gp_mpc/control_objects/models/gp_model.py:39-315 whose
+arithmetic runs in the HIP library (C ABI of include/gpmpc.h):
+
+    prepare_inference   -> gpmpc_prepare   (K build, Cholesky, iK, beta; reference :182-191, 400-431)
+    predict_trajectory  -> gpmpc_rollout   (H-step moment matching;     reference :60-180)
+
+plus the batched entry points the reference lacks (`predict_trajectory_batch`,
+`evaluate_candidates`): B candidate action sequences per launch.
+
+No gpytorch: the three hyper-parameters the hot path reads (lengthscale (1,E), outputscale (),
+likelihood noise (1,), reference :189-190,427) live in small holder objects that keep the
+reference's attribute paths and its `initialize(**{...})` contract
+(controllers/gp_mpc_controller.py:223-224).  `train` (exact marginal likelihood, LBFGS, random
+re-initialisation inside the constraint box; reference :193-306) is host-side plain torch, off the
+hot path, and still runs in the spawned process the controller manages.
+"""
+import time
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from .abstract_model import AbstractStateTransitionModel
+
+F64 = torch.float64
+
+
+def _t(v):
+    return torch.as_tensor(np.asarray(v), dtype=F64) if not isinstance(v, torch.Tensor) else v.to(F64)
+
+
+class SavedState:
+    """In-memory snapshot shipped to the training process (reference gp_model.py:13-36)."""
+
+    def __init__(self, inputs, states_change, parameters, constraints_hyperparams):
+        self.inputs = inputs
+        self.states_change = states_change
+        self.parameters = parameters
+        self.constraints_hyperparams = constraints_hyperparams
+
+    def to_arrays(self):
+        self.inputs = np.asarray(self.inputs)
+        self.states_change = np.asarray(self.states_change)
+        self.parameters = [{k: np.asarray(v) for k, v in p.items()} for p in self.parameters]
+        self.constraints_hyperparams = {k: (v.numpy() if isinstance(v, torch.Tensor) else v)
+                                        for k, v in self.constraints_hyperparams.items()}
+
+    def to_tensors(self):
+        self.inputs = _t(self.inputs)
+        self.states_change = _t(self.states_change)
+        self.parameters = [{k: _t(v) for k, v in p.items()} for p in self.parameters]
+        self.constraints_hyperparams = {k: (_t(v) if isinstance(v, np.ndarray) else v)
+                                        for k, v in self.constraints_hyperparams.items()}
+
+
+class GpHyperParameters:
+    """One ExactGP's hyper-parameters under the reference's attribute paths
+    (covar_module.base_kernel.lengthscale (1,E), covar_module.outputscale (), likelihood.noise (1,))."""
+
+    KEYS = ("covar_module.base_kernel.lengthscale", "covar_module.outputscale", "likelihood.noise")
+
+    def __init__(self, lengthscale, outputscale, noise):
+        self.covar_module = SimpleNamespace(base_kernel=SimpleNamespace(lengthscale=None), outputscale=None)
+        self.likelihood = SimpleNamespace(noise=None)
+        self.initialize(**{self.KEYS[0]: lengthscale, self.KEYS[1]: outputscale, self.KEYS[2]: noise})
+
+    def initialize(self, **kwargs):
+        for key, val in kwargs.items():
+            v = _t(val)
+            if key == self.KEYS[0]:
+                self.covar_module.base_kernel.lengthscale = v.reshape(1, -1)
+            elif key == self.KEYS[1]:
+                self.covar_module.outputscale = v.reshape(())
+            elif key == self.KEYS[2]:
+                self.likelihood.noise = v.reshape(1)
+            else:
+                raise KeyError(key)
+        return self
+
+    def state_dict(self):
+        return {self.KEYS[0]: self.covar_module.base_kernel.lengthscale.clone(),
+                self.KEYS[1]: self.covar_module.outputscale.clone(),
+                self.KEYS[2]: self.likelihood.noise.clone()}
+
+    def eval(self):
+        return self
+
+
+def create_models(gp_init_dict, num_models, num_inputs):
+    """Hyper-parameter holders initialised from ModelConfig.gp_init (reference :318-384)."""
+    if isinstance(gp_init_dict, list):
+        return [GpHyperParameters(p[GpHyperParameters.KEYS[0]], p[GpHyperParameters.KEYS[1]], p[GpHyperParameters.KEYS[2]])
+                for p in gp_init_dict]
+    ls = _t(gp_init_dict["base_kernel.lengthscale"])
+    return [GpHyperParameters(ls[i].expand(num_inputs) if ls[i].ndim == 0 else ls[i],
+                              _t(gp_init_dict["outputscale"])[i], _t(gp_init_dict["noise_covar.noise"])[i])
+            for i in range(num_models)]
+
+
+class GpStateTransitionModel(AbstractStateTransitionModel):
+    def __init__(self, config, dim_state, dim_action, engine=None, device=None):
+        super().__init__(config, dim_state, dim_action)
+        if self.config.include_time_model:
+            self.dim_input += 1
+        self.config.extend_dimensions_params(dim_state=self.dim_state, dim_input=self.dim_input)
+        self.models = create_models(self.config.gp_init, self.dim_state, self.dim_input)
+        self._engine = engine
+        self._device = device
+        self.x_mem = None
+        self.y_mem = None
+        self._cost_key = None
+
+    # -- engine ------------------------------------------------------------------------
+    @property
+    def engine(self):
+        if self._engine is None:
+            from ...engine import HipEngine       # raises without a GPU / without the HIP library
+            self._engine = HipEngine(self._device)
+        return self._engine
+
+    @property
+    def lengthscales(self):
+        return torch.stack([m.covar_module.base_kernel.lengthscale[0] for m in self.models])
+
+    @property
+    def variances(self):
+        return torch.stack([m.covar_module.outputscale for m in self.models])
+
+    @property
+    def noises(self):
+        return torch.stack([m.likelihood.noise[0] for m in self.models])
+
+    @property
+    def iK(self):
+        return self.engine.factors()[0].cpu()
+
+    @property
+    def beta(self):
+        return self.engine.factors()[1].cpu()
+
+    # -- a1/a2 -------------------------------------------------------------------------
+    def prepare_inference(self, inputs, state_changes):
+        self.x_mem = inputs
+        self.y_mem = state_changes
+        self.engine.prepare(inputs, state_changes, self.lengthscales, self.variances, self.noises)
+
+    def set_cost(self, reward_config):
+        """Load the quadratic-cost / LCB settings into the engine (once per config)."""
+        key = (id(self), id(reward_config))
+        if self._cost_key == key and getattr(self.engine, "_cost_token", None) == key:
+            return
+        smin = reward_config.state_min if reward_config.use_constraints else None
+        smax = reward_config.state_max if reward_config.use_constraints else None
+        self.engine.set_cost(reward_config.target_state_action_norm.numpy(), reward_config.weight_matrix_cost.numpy(),
+                             reward_config.weight_matrix_cost_terminal.numpy(), float(reward_config.exploration_factor),
+                             bool(reward_config.clip_lower_bound_cost_to_0),
+                             None if smin is None else smin.numpy(), None if smax is None else smax.numpy())
+        self._cost_key = key
+        self.engine._cost_token = key          # engines can be shared between models: remember whose cost is loaded
+
+    # -- a3/a4 -------------------------------------------------------------------------
+    def predict_trajectory_batch(self, actions, obs_mu, obs_var, len_horizon=None, current_time_idx=0,
+                                 trajectories=True, stage_costs=True):
+        """actions (B,H,A) -> dict of DEVICE tensors: J (B,), mu (B,H+1,D), Sig (B,H+1,D,D),
+        cost_mu / cost_var (B,H+1).  Costs need set_cost() first."""
+        if self._cost_key is None:
+            raise RuntimeError("call set_cost(reward_config) before predicting")
+        actions = torch.as_tensor(np.asarray(actions) if not isinstance(actions, torch.Tensor) else actions, dtype=F64)
+        if len_horizon is not None and actions.shape[1] != len_horizon:
+            raise ValueError("actions.shape[1] != len_horizon")
+        return self.engine.rollout(actions, _t(obs_mu).numpy(), _t(obs_var).numpy(), self.config.include_time_model,
+                                   float(current_time_idx), trajectories, stage_costs)
+
+    def predict_trajectory(self, actions, obs_mu, obs_var, len_horizon, current_time_idx):
+        """Same signature / return shapes as the reference (:60-110): ((H+1,D), (H+1,D,D)) CPU tensors."""
+        out = self.predict_trajectory_batch(_t(actions)[None], obs_mu, obs_var, len_horizon, current_time_idx,
+                                            trajectories=True, stage_costs=False)
+        return out["mu"][0].cpu(), out["Sig"][0].cpu()
+
+    # -- state / training ------------------------------------------------------------------
+    def save_state(self):
+        return SavedState(inputs=self.x_mem, states_change=self.y_mem,
+                          parameters=[m.state_dict() for m in self.models],
+                          constraints_hyperparams={k: v for k, v in vars(self.config).items() if k != "gp_init"})
+
+    def load_state(self, saved_state):
+        for m, p in zip(self.models, saved_state.parameters):
+            m.initialize(**p)
+        self.prepare_inference(_t(saved_state.inputs), _t(saved_state.states_change))
+
+    @staticmethod
+    def train(queue, saved_state, lr_train, num_iter_train, clip_grad_value, print_train=False, step_print_train=25):
+        """Exact-MLL hyper-parameter search (reference :193-306), one GP at a time: random restart inside
+        the constraint box, LBFGS(strong_wolfe), keep the best, never return something worse than the
+        incoming parameters.  Runs in the spawned training process; CPU torch, fp64."""
+        t0 = time.time()
+        saved_state.to_tensors()
+        X, Y = saved_state.inputs, saved_state.states_change
+        cons = saved_state.constraints_hyperparams
+        N, E = X.shape
+        out = []
+        for a, p in enumerate(saved_state.parameters):
+            lo = {"ls": _t(cons["min_lengthscale"])[a], "os": _t(cons["min_outputscale"])[a],
+                  "nz": _t(cons["min_std_noise"])[a] ** 2}
+            hi = {"ls": _t(cons["max_lengthscale"])[a], "os": _t(cons["max_outputscale"])[a],
+                  "nz": _t(cons["max_std_noise"])[a] ** 2}
+            y = Y[:, a]
+
+            def neg_mll(ls, osc, nz):
+                d = (X[:, None, :] - X[None, :, :]) / ls
+                K = osc * torch.exp(-0.5 * (d * d).sum(-1)) + nz * torch.eye(N, dtype=F64)
+                L = torch.linalg.cholesky(K)
+                alpha = torch.cholesky_solve(y[:, None], L)[:, 0]
+                ll = -0.5 * (y @ alpha) - torch.log(torch.diagonal(L)).sum() - 0.5 * N * np.log(2 * np.pi)
+                return -ll / N
+
+            best = {"ls": p[GpHyperParameters.KEYS[0]].reshape(-1), "os": p[GpHyperParameters.KEYS[1]].reshape(()),
+                    "nz": p[GpHyperParameters.KEYS[2]].reshape(())}
+            try:
+                best_loss = float(neg_mll(best["ls"], best["os"], best["nz"]))
+            except Exception:
+                best_loss = float("inf")
+            raw = {k: torch.logit(torch.rand(best[k].shape, dtype=F64).clamp(1e-6, 1 - 1e-6)).requires_grad_(True)
+                   for k in ("ls", "os", "nz")}
+
+            def val(k):
+                return lo[k] + (hi[k] - lo[k]) * torch.sigmoid(raw[k])
+            opt = torch.optim.LBFGS(list(raw.values()), lr=lr_train, line_search_fn="strong_wolfe")
+            try:
+                for i in range(num_iter_train):
+                    def closure():
+                        opt.zero_grad()
+                        loss = neg_mll(val("ls"), val("os"), val("nz"))
+                        loss.backward()
+                        return loss
+                    loss = float(opt.step(closure))
+                    if print_train and i % step_print_train == 0:
+                        print(f"train gp {a} iter {i + 1}/{num_iter_train} loss {loss:.5f}")
+                    if loss < best_loss:
+                        best_loss = loss
+                        best = {k: val(k).detach().clone() for k in raw}
+            except Exception as e:         # keep the best found so far, like the reference (:289-290)
+                print(e)
+            out.append({GpHyperParameters.KEYS[0]: best["ls"].reshape(1, E).numpy(),
+                        GpHyperParameters.KEYS[1]: best["os"].reshape(()).numpy(),
+                        GpHyperParameters.KEYS[2]: best["nz"].reshape(1).numpy()})
+        if print_train:
+            print(f"training process: {time.time() - t0:.2f} s")
+        queue.put(out)

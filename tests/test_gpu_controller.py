@@ -1,0 +1,128 @@
+"""Tier 2/4 (GPU): the controller-level drop-in surface -- objective + gradient vs the reference's
+autograd goldens, the optimize=False candidate loop vs the reference's trace, get_action, the
+scipy L-BFGS-B path and a short closed loop on an own pendulum."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, workload_of, make_controller, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import gp_mpc_amd
+    eng = gp_mpc_amd.HipEngine(0)
+    yield eng
+    eng.close()
+
+
+@pytest.mark.parametrize("name,deriv", [("lcb_grad_norm", False), ("lcb_grad_deriv", True)])
+def test_objective_and_gradient_match_reference_autograd(engine, name, deriv):
+    g = load(name)
+    w = workload_of(g)
+    c = make_controller(w, limit_action_change=deriv, engine=engine)
+    if deriv:
+        c.actions_mapper.action_model_previous_iter = torch.as_tensor(g["action_prev"])
+    c._prepare()
+    for b in range(w.actions.shape[0]):
+        J, grad = c.compute_mean_lcb_trajectory(w.actions[b].reshape(-1), torch.as_tensor(w.mu0), torch.as_tensor(w.S0))
+        assert abs(J - g["J"][b]) < 1e-8 * abs(g["J"][b])
+        # 4th-order finite difference vs autograd: 1e-5 of the gradient's scale
+        assert rel_err(grad, g["grad"][b]) < 1e-5
+    assert rel_err(c.states_mu_pred.numpy(), g["mu_last"]) < 1e-8      # caches filled like the reference (:279-283)
+    assert c.states_var_pred.shape == g["Sig_last"].shape
+
+
+def test_clipped_objective_gradient_is_passthrough(engine):
+    """clip_lower_bound_cost_to_0: value is clipped, gradient is that of the unclipped mean (Clamp backward)."""
+    g = load("lcb_grad_norm")
+    w = workload_of(g)
+    c = make_controller(w, clip=True, engine=engine)
+    c._prepare()
+    J, grad = c.compute_mean_lcb_trajectory(w.actions[0].reshape(-1), torch.as_tensor(w.mu0), torch.as_tensor(w.S0))
+    assert J >= g["J"][0] - 1e-9
+    assert rel_err(grad, g["grad"][0]) < 1e-5
+
+
+def test_random_shooting_reproduces_reference_trace(engine):
+    g = load("argmin_trace")
+    w = workload_of(g)
+    c = make_controller(w, optimize=False, restarts=int(g["restarts"]), engine=engine)
+    np.random.seed(int(g["np_seed"]))
+    best = c._get_optimal_actions(torch.as_tensor(w.mu0), torch.as_tensor(w.S0))
+    assert np.array_equal(best.numpy(), g["best_actions"])
+    assert np.array_equal(c.actions_mpc_previous_iter, g["best_flat"])
+    assert abs(c.best_candidate_J - g["cand_J"].min()) < 1e-9
+    assert c.num_rollouts == int(g["restarts"])
+    # logging caches hold the LAST evaluated candidate, like the reference
+    last = make_controller(w, engine=engine)
+    last._prepare()
+    last.compute_mean_lcb_trajectory(g["cand_actions"][-1].reshape(-1), torch.as_tensor(w.mu0), torch.as_tensor(w.S0))
+    assert np.allclose(c.states_mu_pred.numpy(), last.states_mu_pred.numpy(), rtol=0, atol=1e-14)
+
+
+def test_get_action_fills_iteration_information(engine):
+    g = load("argmin_trace")
+    w = workload_of(g)
+    c = make_controller(w, optimize=False, restarts=32, engine=engine)
+    np.random.seed(1)
+    a = c.get_action(obs_mu=w.mu0, random=False)
+    assert a.shape == (1,) and 0.0 <= a[0] <= 1.0 and c.iter_ctrl == 1
+    info = c.get_iter_info()
+    H = w.actions.shape[1]
+    assert info.predicted_states.shape == (H + 1, 3) and info.predicted_states_std.shape == (H + 1, 3)
+    assert info.predicted_actions.shape == (H, 1) and info.predicted_costs.shape == (H + 1,)
+    assert len(info.predicted_idxs) == H and "iteration" in str(info)
+    assert c.compute_action.__func__ is c.get_action.__func__
+    a2 = c.get_action(obs_mu=w.mu0, random=True)
+    assert a2.shape == (1,)
+    cost, cost_var = c.compute_cost_unnormalized(w.mu0, a)
+    assert np.isfinite(cost) and cost_var >= 0
+
+
+def test_lbfgsb_path_improves_objective(engine):
+    g = load("lcb_grad_norm")
+    w = workload_of(g)
+    params = {"disp": None, "maxcor": 4, "ftol": 1e-15, "gtol": 1e-15, "eps": 1e-2, "maxfun": 6, "maxiter": 6,
+              "iprint": -1, "maxls": 6, "finite_diff_rel_step": None}
+    c = make_controller(w, optimize=True, restarts=2, engine=engine, optimizer_params=params)
+    np.random.seed(7)
+    x0 = np.random.uniform(size=w.actions.shape[1])
+    np.random.seed(7)
+    c._prepare()
+    J0, _ = c.compute_mean_lcb_trajectory(x0, torch.as_tensor(w.mu0), torch.as_tensor(w.S0))
+    best = c._get_optimal_actions(torch.as_tensor(w.mu0), torch.as_tensor(w.S0))
+    J1, _ = c.compute_mean_lcb_trajectory(c.actions_mpc_previous_iter, torch.as_tensor(w.mu0), torch.as_tensor(w.S0))
+    assert J1 < J0 and best.shape == (w.actions.shape[1], 1)
+    assert np.all(c.actions_mpc_previous_iter >= 0) and np.all(c.actions_mpc_previous_iter <= 1)
+
+
+def test_closed_loop_pendulum_with_training_process(engine):
+    """run_env on an own pendulum: random warm-up, memory admission, one spawned GP training, MPC steps."""
+    import gp_mpc_amd  # noqa: F401
+    from gp_mpc_amd.config_classes import (Config, ControllerConfig, ActionsConfig, RewardConfig, ObservationConfig,
+                                           MemoryConfig, ModelConfig, TrainingConfig)
+    from gp_mpc_amd.run_env_function import run_env
+    from gp_mpc_amd.envs.pendulum import PendulumEnv
+    cfg = Config(
+        observation_config=ObservationConfig([1e-6] * 3),
+        reward_config=RewardConfig(target_state_norm=[1, 0.5, 0.5], weight_state=[1, 0.1, 0.1],
+                                   weight_state_terminal=[5, 2, 2], target_action_norm=[0.5], weight_action=[1e-3],
+                                   exploration_factor=1),
+        actions_config=ActionsConfig(False, [0.3]),
+        model_config=ModelConfig(gp_init={"noise_covar.noise": [1e-5] * 3, "base_kernel.lengthscale": [0.5] * 3,
+                                          "outputscale": [5e-2] * 3}, min_std_noise=1e-3, max_std_noise=1e-2,
+                                 min_outputscale=1e-2, max_lengthscale=10.0),
+        memory_config=MemoryConfig(True, [3e-4] * 3, [3e-3] * 3, points_batch_memory=64),
+        training_config=TrainingConfig(lr_train=7e-3, iter_train=3, training_frequency=8),
+        controller_config=ControllerConfig(len_horizon=8, restarts_optim=128, optimize=False))
+    np.random.seed(0)
+    costs, ctrl = run_env(PendulumEnv(seed=0), cfg, None, random_actions_init=5, num_steps=22, verbose=False, engine=engine)
+    assert costs.shape == (22,) and np.isfinite(costs).all()
+    assert ctrl.memory.len_mem == 22 and ctrl.memory.len_mem_model >= 5
+    assert ctrl.num_rollouts >= 5 + 17 * 128
+    assert len(ctrl.info_iters["cost"]) == 22
+    ls = ctrl.transition_model.lengthscales
+    assert ls.shape == (3, 4) and torch.isfinite(ls).all()

@@ -1,0 +1,167 @@
+"""CPU tests of the host-side mirror (no GPU, no compute calls into the HIP library): the library
+loads and exports every symbol of include/gpmpc.h, config/mapper/memory logic, gradient chain rule."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, workload_of
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    import gp_mpc_amd
+    from gp_mpc_amd import _lib
+    header = open(os.path.join(ROOT, "include", "gpmpc.h")).read()
+    declared = set(re.findall(r"\b(gpmpc_[a-z_]+)\s*\(", header))
+    assert declared, "no declarations parsed"
+    lib = _lib.load()                      # raises if a bound symbol is missing
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.gpmpc_abi_version() == _lib.ABI_VERSION
+    assert os.path.basename(gp_mpc_amd.LIB_PATH) == "libgpmpc_hip.so"
+
+
+def test_no_cpu_fallback_without_gpu():
+    import gp_mpc_amd
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError):
+        gp_mpc_amd.HipEngine(0)
+
+
+def test_product_package_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing in the shipped package may import or load it."""
+    pkg = os.path.join(ROOT, "data-efficient-reinforcement-learning-with-probabilistic-model-predictive-control_amd")
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|oracle[./]", re.M)
+    seen = 0
+    for dirpath, _, files in os.walk(pkg):
+        if "build" in dirpath:
+            continue
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                seen += 1
+                assert not pat.search(open(os.path.join(dirpath, f)).read()), (dirpath, f)
+    assert seen > 10
+
+
+def test_derivative_mapper_matches_reference_golden():
+    g = load("lcb_grad_deriv")
+    w = workload_of(g)
+    from gp_mpc_amd.control_objects.actions_mappers.mappers import DerivativeActionMapper
+    from gp_mpc_amd.config_classes import ActionsConfig
+    N, D, A, E, H, B = w.dims
+    m = DerivativeActionMapper(np.zeros(A), np.ones(A), H, ActionsConfig(True, list(g["max_change"])))
+    m.action_model_previous_iter = torch.as_tensor(g["action_prev"])
+    got = m.mpc_to_model_batch(w.actions.reshape(B, -1))
+    assert np.allclose(got, g["actions_model"], rtol=0, atol=1e-15)
+    one = m.transform_action_mpc_to_action_model(w.actions[1].reshape(-1)).numpy()
+    assert np.array_equal(one, got[1])
+    # chain rule with pass-through clamp: d model[t] / d u[s] = 2 m for s <= t
+    gm = np.random.default_rng(0).standard_normal((H, A))
+    want = np.array([[2 * 0.3 * gm[s:, a].sum() for a in range(A)] for s in range(H)]).reshape(-1)
+    assert np.allclose(m.chain_grad_model_to_mpc(gm), want)
+
+
+def test_normalization_mapper_and_bounds():
+    from gp_mpc_amd.control_objects.actions_mappers.mappers import NormalizationActionMapper
+    from gp_mpc_amd.config_classes import ActionsConfig
+    m = NormalizationActionMapper(np.array([-2.0]), np.array([2.0]), 5, ActionsConfig())
+    u = np.linspace(0, 1, 5)
+    assert np.array_equal(m.transform_action_mpc_to_action_model(u).numpy(), u.reshape(5, 1))
+    assert m.bounds == [(0, 1)] * 5
+    raw = m.transform_action_model_to_action_raw(torch.as_tensor(u.reshape(5, 1)), update_internals=True)
+    assert np.allclose(raw.numpy().ravel(), -2 + 4 * u) and m.n_iter_ctrl == 1
+    assert np.allclose(m.transform_action_raw_to_action_model(np.array([0.0])).numpy(), [0.5])
+
+
+def test_config_broadcasting_like_reference():
+    from gp_mpc_amd.config_classes import ModelConfig
+    mc = ModelConfig(gp_init={"noise_covar.noise": [1e-5] * 3, "base_kernel.lengthscale": [0.5, 0.6, 0.7],
+                              "outputscale": [5e-2] * 3}, include_time_model=True, init_lengthscale_time=100)
+    mc.extend_dimensions_params(dim_state=3, dim_input=5)
+    ls = mc.gp_init["base_kernel.lengthscale"]
+    assert ls.shape == (3, 5) and torch.all(ls[:, -1] == 100) and torch.all(ls[1, :-1] == 0.6)
+    assert mc.min_lengthscale.shape == (3, 5) and mc.max_std_noise.shape == (3,)
+    mc2 = ModelConfig(gp_init={"noise_covar.noise": [1e-5] * 2, "base_kernel.lengthscale": [0.5, 0.5],
+                               "outputscale": [5e-2] * 2})
+    mc2.extend_dimensions_params(dim_state=2, dim_input=3)
+    assert mc2.gp_init["base_kernel.lengthscale"].shape == (2, 3)
+
+
+def test_reward_config_matrices():
+    from gp_mpc_amd.config_classes import RewardConfig
+    rc = RewardConfig(target_state_norm=[1, 0.5], weight_state=[1, 0.1], weight_state_terminal=[5, 2],
+                      target_action_norm=[0.5], weight_action=[1e-3])
+    assert rc.weight_matrix_cost.shape == (3, 3) and rc.weight_matrix_cost[2, 2] == 1e-3
+    assert torch.equal(rc.target_state_action_norm, torch.tensor([1, 0.5, 0.5], dtype=torch.float64))
+
+
+def test_memory_admission_growth_and_dummy_point():
+    from gp_mpc_amd.control_objects.memories.gp_memory import Memory
+    from gp_mpc_amd.config_classes import MemoryConfig
+    cfg = MemoryConfig(True, [1e-2, 1e-2], [1e-3, 1e-3], points_batch_memory=4)
+    mem = Memory(cfg, dim_input=3, dim_state=2)
+    x, y = mem.get()
+    assert x.shape == (1, 3) and y.shape == (1, 2) and not x.any() and not y.any()      # dummy zero point
+    s = torch.tensor([0.1, 0.2], dtype=torch.float64)
+    a = torch.tensor([0.5], dtype=torch.float64)
+    for k in range(11):                      # beyond points_batch_memory: the reference raises here
+        pred = s + (0.05 if k % 2 == 0 else 0.0)
+        mem.add(s, a, s + 0.01 * k, 0.0, iter_ctrl=k, predicted_state=pred, predicted_state_std=torch.tensor([0.1, 0.1]))
+    mem.prepare_for_model()
+    x, y = mem.get()
+    assert mem.len_mem == 11 and len(x) == mem.len_mem_model == int(mem.active_data_mask[:11].sum())
+    assert torch.allclose(y[0], mem.states_next[0] - s)
+    assert mem.get_mask_model_inputs().shape == (11,)
+
+
+def test_single_state_reward_matches_golden_rows():
+    """Host get_reward / get_reward_terminal (logging path) vs the reference's trajectory rewards."""
+    g = load("traj_c1")
+    w = workload_of(g)
+    from gp_mpc_amd.control_objects.states_reward_mappers.setpoint_distance_reward_mapper import SetpointStateRewardMapper
+    from gp_mpc_amd.config_classes import RewardConfig
+    D = 3
+    rc = RewardConfig(target_state_norm=list(w.target[:D]), weight_state=list(np.diag(w.W)[:D]),
+                      weight_state_terminal=list(np.diag(w.W_T)), target_action_norm=list(w.target[D:]),
+                      weight_action=list(np.diag(w.W)[D:]), exploration_factor=w.kappa)
+    rm = SetpointStateRewardMapper(rc)
+    mu, Sig, act = torch.as_tensor(g["mu"][0]), torch.as_tensor(g["Sig"][0]), torch.as_tensor(w.actions[0])
+    r, v = rm.get_rewards_trajectory(mu, Sig, act)
+    assert np.allclose(r.numpy(), g["rewards"][0], rtol=1e-12, atol=1e-15)
+    assert np.allclose(v.numpy(), g["reward_vars"][0], rtol=1e-10, atol=1e-18)
+
+
+def test_hyperparameter_holder_contract():
+    from gp_mpc_amd.control_objects.models.gp_model import GpHyperParameters
+    h = GpHyperParameters([0.5, 0.6], 0.05, 1e-5)
+    assert h.covar_module.base_kernel.lengthscale.shape == (1, 2) and h.likelihood.noise.shape == (1,)
+    h.initialize(**{"covar_module.base_kernel.lengthscale": np.array([[1.0, 2.0]]), "covar_module.outputscale": np.array(0.1),
+                    "likelihood.noise": np.array([1e-4])})
+    assert float(h.covar_module.outputscale) == 0.1 and h.covar_module.base_kernel.lengthscale[0, 1] == 2.0
+    assert set(h.state_dict()) == set(GpHyperParameters.KEYS)
+
+
+def test_training_improves_marginal_likelihood_cpu():
+    """GpStateTransitionModel.train is host-side torch: can run here."""
+    import queue
+    from gp_mpc_amd.control_objects.models.gp_model import GpStateTransitionModel, SavedState, GpHyperParameters
+    rng = np.random.default_rng(0)
+    X = rng.uniform(size=(40, 2))
+    Y = (0.3 * np.sin(4 * X[:, :1]) + 0.01 * rng.standard_normal((40, 1)))
+    p0 = GpHyperParameters([5.0, 5.0], 0.9, 0.09).state_dict()
+    st = SavedState(X, Y, [p0], {"min_lengthscale": np.full((1, 2), 4e-3), "max_lengthscale": np.full((1, 2), 10.0),
+                                 "min_outputscale": np.array([1e-3]), "max_outputscale": np.array([0.95]),
+                                 "min_std_noise": np.array([1e-3]), "max_std_noise": np.array([3e-1])})
+    st.to_arrays()
+    q = queue.Queue()
+    torch.manual_seed(0)
+    GpStateTransitionModel.train(q, st, 1e-1, 10, 1e-3)
+    (out,) = q.get()
+    assert out["covar_module.base_kernel.lengthscale"].shape == (1, 2) and out["likelihood.noise"].shape == (1,)
+    assert 4e-3 <= out["covar_module.base_kernel.lengthscale"].min() and out["likelihood.noise"][0] <= 0.09 + 1e-12
