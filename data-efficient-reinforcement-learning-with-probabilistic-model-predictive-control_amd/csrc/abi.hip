@@ -52,9 +52,10 @@ int gpmpc_destroy(gpmpc_t* g) {
     Handle* h = H_(g);
     (void)hipSetDevice(h->device);
     Buf* all[] = {&h->Xt, &h->beta, &h->iK, &h->Tm, &h->ils2, &h->var, &h->logvar, &h->gram,
-                  &h->linv, &h->zvec, &h->cost, &h->scratch, &h->best};
+                  &h->linv, &h->zvec, &h->cost, &h->scratch, &h->best, &h->xrange, &h->mono_w, &h->traj};
     for (Buf* b : all) free_buf(*b);
     if (h->info) (void)hipFree(h->info);
+    if (h->mono_exp) (void)hipFree(h->mono_exp);
     delete g;
     return GPMPC_OK;
 }
@@ -68,6 +69,8 @@ int gpmpc_set_option(gpmpc_t* g, const char* name, long long value) {
     else if (!strcmp(name, "threads")) h->opt_threads = (int)value;
     else if (!strcmp(name, "force_global_scratch")) h->opt_force_global = (int)value;
     else if (!strcmp(name, "rows_per_chunk")) h->opt_rows_per_chunk = (int)value;
+    else if (!strcmp(name, "force_path")) h->opt_force_path = (int)value;
+    else if (!strcmp(name, "force_separable")) h->opt_force_sep = (int)value;
     else return bad(g, "unknown option");
     return GPMPC_OK;
 }

@@ -40,10 +40,21 @@ struct RolloutArgs {
     double* cm_out;
     double* cv_out;
     double* J_out;
+    // Taylor / separable evaluation of exp(g.w)
+    const double* xrange;    // (2, E) per-input-dimension min and max of the memory points
+    const int* mono_exp;     // (CM, 4) exponents of the monomials, graded order
+    const double* mono_w;    // (CM) 1 / alpha!
+    int mono_cum[16];        // mono_cum[k] = number of monomials of degree <= k
+    int sep_kmax;            // highest degree the separable path supports (0 = disabled)
+    int CM;                  // monomial capacity per (pair, side) in LDS
+    int force_path;          // 0 auto, 1 always direct exp, 2 Taylor but never separable (tests)
+    int force_sep;           // 1: separable whenever the degree allows, ignoring the cost model (tests)
     // tiling
     int G;        // output pairs per group
     int CH;       // rows per chunk
     int RC;       // row chunks per column
+    unsigned magic_N;        // ceil(2^32 / N):   x / N   == umulhi(x, magic_N)   for the index ranges used
+    unsigned magic_wpp;      // ceil(2^32 / wpp): x / wpp == umulhi(x, magic_wpp)
     double* scratch;         // per-candidate global scratch (large-N variant)
     size_t scratch_stride;   // doubles per candidate
     // initial state distribution
@@ -77,6 +88,14 @@ struct Handle {
     Buf cost;     // target | W | W_T | smin | smax
     Buf scratch;  // per-candidate rollout scratch (large-N variant)
     Buf best;     // argmin result: [best_J, best_idx bits]
+    Buf traj;     // (B, H+1, D) + (B, H+1, D, D) when the caller does not want the trajectory
+    Buf xrange;   // (2, E) min / max of the inputs
+    Buf mono_w;   // (CM) 1 / alpha!
+    int* mono_exp = nullptr;    // (CM, 4)
+    int mono_D = -1;            // state dimension the monomial tables were built for
+    int mono_cum[16] = {0};
+    int sep_kmax = 0;
+    int mono_CM = 0;
     int* info = nullptr;        // (kMaxD) first non-positive pivot + 1, or 0
     // cost settings
     int cost_D = -1, cost_A = -1;
@@ -88,6 +107,8 @@ struct Handle {
     int opt_threads = 0;
     int opt_force_global = 0;
     int opt_rows_per_chunk = 0;
+    int opt_force_path = 0;
+    int opt_force_sep = 0;
     int lds_limit = 160 * 1024;
     int num_cu = 256;
 };

@@ -18,6 +18,7 @@ namespace gpmpc_hip {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int NB = 32;   // panel width
+constexpr int kTPadRows = 64;   // zero rows after every T_a (= kTPad of rollout_kernel.h)
 
 // ------------------------------------------------------------------------------------------
 __global__ void pack_inputs_kernel(const double* __restrict__ X, const double* __restrict__ ls,
@@ -31,6 +32,28 @@ __global__ void pack_inputs_kernel(const double* __restrict__ X, const double* _
     }
     if (idx < D * E) { const double l = ls[idx]; ils2[idx] = 1.0 / (l * l); }
     if (idx < D) { var[idx] = os[idx]; logvar[idx] = log(os[idx]); }
+}
+
+// per-input-dimension min / max over the memory points (bounds |x - m| in the rollout kernel)
+__global__ __launch_bounds__(256) void xrange_kernel(const double* __restrict__ X, int N, int E, double* __restrict__ xr) {
+    __shared__ double smin[4], smax[4];
+    const int e = blockIdx.x;
+    double lo = INFINITY, hi = -INFINITY;
+    for (int pt = threadIdx.x; pt < N; pt += 256) {
+        const double v = X[(size_t)pt * E + e];
+        lo = fmin(lo, v);
+        hi = fmax(hi, v);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        lo = fmin(lo, __shfl_xor(lo, off, 64));
+        hi = fmax(hi, __shfl_xor(hi, off, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        xr[e] = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+        xr[E + e] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+    }
 }
 
 // K[a][i][j], lanes along j (coalesced stores); x_i broadcast through the scalar path.
@@ -221,7 +244,7 @@ __global__ __launch_bounds__(256) void syrk_inverse_kernel(const double* __restr
     const int a = blockIdx.z;
     const double* Y = Yall + (size_t)a * N * N;
     double* iK = iKall + (size_t)a * N * N;
-    double* T = Tall + (size_t)a * N * N;
+    double* T = Tall + (size_t)a * (N + kTPadRows) * N;
     const double* be = beta + (size_t)a * N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i0 = ti * 32 + (wave >> 1) * 16;
@@ -244,8 +267,9 @@ __global__ __launch_bounds__(256) void syrk_inverse_kernel(const double* __restr
             double t = be[row] * be[col] - v;
             if (row == col) t *= 0.5;
             iK[(size_t)row * N + col] = v;
-            T[(size_t)row * N + col] = t;
-            if (row != col) { iK[(size_t)col * N + row] = v; T[(size_t)col * N + row] = t; }
+            // T keeps only its upper triangle (row index <= column index); the rest stays zero
+            T[(size_t)col * N + row] = t;
+            if (row != col) iK[(size_t)col * N + row] = v;
         }
     }
 }
@@ -260,7 +284,7 @@ __global__ __launch_bounds__(256) void tm_kernel(const double* __restrict__ iK, 
     const size_t o = ((size_t)a * N + i) * N + j;
     double t = beta[(size_t)a * N + i] * beta[(size_t)a * N + j] - iK[o];
     if (i == j) t *= 0.5;
-    T[o] = t;
+    T[((size_t)a * (N + kTPadRows) + i) * N + j] = (i <= j) ? t : 0.0;       // upper triangle only
 }
 
 // ------------------------------------------------------------------------------------------
@@ -278,12 +302,13 @@ int ensure_model_buffers(Handle* h, int N, int D, int E, bool need_factor_ws) {
     int rc;
     if ((rc = grow(h, h->Xt, EN))) return rc;
     if ((rc = grow(h, h->ils2, DE))) return rc;
+    if ((rc = grow(h, h->xrange, 2 * (size_t)kMaxE))) return rc;
     if ((rc = grow(h, h->var, kMaxD))) return rc;
     if ((rc = grow(h, h->logvar, kMaxD))) return rc;
     if ((rc = grow(h, h->beta, DN))) return rc;
     if ((rc = grow(h, h->zvec, DN))) return rc;
     if ((rc = grow(h, h->iK, NN))) return rc;
-    if ((rc = grow(h, h->Tm, NN))) return rc;
+    if ((rc = grow(h, h->Tm, (size_t)D * (N + kTPadRows) * N))) return rc;      // + zero rows per GP
     if (need_factor_ws) {
         if ((rc = grow(h, h->gram, NN))) return rc;
         if ((rc = grow(h, h->linv, NN))) return rc;
@@ -296,6 +321,7 @@ static int pack(Handle* h, const double* X, const double* ls, const double* os, 
     int n = N * E; if (D * E > n) n = D * E; if (D > n) n = D;
     hipLaunchKernelGGL(pack_inputs_kernel, dim3((n + 255) / 256), dim3(256), 0, s, X, ls, os, N, D, E,
                        h->Xt.p, h->ils2.p, h->var.p, h->logvar.p);
+    hipLaunchKernelGGL(xrange_kernel, dim3(E), dim3(256), 0, s, X, N, E, h->xrange.p);
     GPMPC_HIP_CHECK(h, hipGetLastError());
     return GPMPC_OK;
 }
@@ -307,6 +333,7 @@ int run_set_factors(Handle* h, const double* X, const double* iK, const double* 
     if ((rc = pack(h, X, ls, os, N, D, E, s))) return rc;
     GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->iK.p, iK, (size_t)D * N * N * sizeof(double), hipMemcpyDeviceToDevice, s));
     GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->beta.p, beta, (size_t)D * N * sizeof(double), hipMemcpyDeviceToDevice, s));
+    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->Tm.p, 0, (size_t)D * (N + kTPadRows) * N * sizeof(double), s));
     hipLaunchKernelGGL(tm_kernel, dim3((N + 63) / 64, (N + 3) / 4, D), dim3(256), 0, s, h->iK.p, h->beta.p, N, h->Tm.p);
     GPMPC_HIP_CHECK(h, hipGetLastError());
     h->N = N; h->D = D; h->E = E; h->ready = true;
@@ -321,6 +348,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     if ((rc = pack(h, X, ls, os, N, D, E, s))) return rc;
     GPMPC_HIP_CHECK(h, hipMemsetAsync(h->info, 0, kMaxD * sizeof(int), s));
     GPMPC_HIP_CHECK(h, hipMemsetAsync(h->linv.p, 0, (size_t)D * N * N * sizeof(double), s));
+    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->Tm.p, 0, (size_t)D * (N + kTPadRows) * N * sizeof(double), s));
     hipLaunchKernelGGL(gram_kernel, dim3((N + 63) / 64, (N + 3) / 4, D), dim3(256), 0, s,
                        h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
     GPMPC_HIP_CHECK(h, hipGetLastError());

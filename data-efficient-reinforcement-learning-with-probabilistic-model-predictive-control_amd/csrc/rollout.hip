@@ -12,6 +12,74 @@ int launch_rollout_dp8(Handle*, RolloutArgs&, int, bool, size_t, hipStream_t);
 int launch_rollout_dp16(Handle*, RolloutArgs&, int, bool, size_t, hipStream_t);
 
 // ------------------------------------------------------------------------------------------
+// Stage / terminal costs and the mean-LCB objective of every candidate, from the stored trajectory:
+// setpoint_distance_reward_mapper.py:36-66 (stage), :135-141 (terminal); gp_mpc_controller.py:270-276.
+// One wavefront per candidate, lanes over the H + 1 time steps; O(B H D^3) flops, negligible next to the
+// rollout kernel, and keeping it out of the horizon loop is what lets that kernel fit 128 VGPRs.
+__global__ __launch_bounds__(64) void traj_cost_kernel(const double* __restrict__ mu, const double* __restrict__ Sig,
+                                                       const double* __restrict__ actions, const double* __restrict__ cost,
+                                                       int D, int A, int H, double kappa, int clip, int use_constraints,
+                                                       double* __restrict__ cm_out, double* __restrict__ cv_out,
+                                                       double* __restrict__ J_out) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int DA = D + A;
+    const double* target = cost;
+    const double* W = cost + DA;
+    const double* WT = W + DA * DA;
+    const double* smin = WT + D * D;
+    const double* smax = smin + D;
+    double jsum = 0.0;
+    for (int t = lane; t <= H; t += 64) {
+        const bool terminal = (t == H);
+        const int n = terminal ? D : DA;
+        const double* Wm = terminal ? WT : W;
+        const double* m = mu + ((size_t)c * (H + 1) + t) * D;
+        const double* S = Sig + ((size_t)c * (H + 1) + t) * D * D;
+        const double* a = actions + ((size_t)c * H + (terminal ? 0 : t)) * A;
+        auto err = [&](int i) { return (i < D ? m[i] : a[i - D]) - target[i]; };
+        double cm = 0.0, cv = 0.0;
+        // tr(Sigma W) and e^T W e
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) cm = fma(S[i * D + j], Wm[j * n + i], cm);
+        for (int i = 0; i < n; ++i) {
+            const double ei = err(i);
+            for (int j = 0; j < n; ++j) cm = fma(ei * Wm[i * n + j], err(j), cm);
+        }
+        // tr(2 TS TS) with TS = W Sigma (state block), 4 (W^T e)^T Sigma (W e)
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) {
+                double tij = 0.0, tji = 0.0;
+                for (int k = 0; k < D; ++k) {
+                    tij = fma(Wm[i * n + k], S[k * D + j], tij);
+                    tji = fma(Wm[j * n + k], S[k * D + i], tji);
+                }
+                cv = fma(2.0 * tij, tji, cv);
+                double v1 = 0.0, v2 = 0.0;
+                for (int k = 0; k < n; ++k) {
+                    v1 = fma(err(k), Wm[k * n + i], v1);
+                    v2 = fma(Wm[j * n + k], err(k), v2);
+                }
+                cv = fma(4.0 * v1 * S[i * D + j], v2, cv);
+            }
+        if (use_constraints && !terminal) {
+            for (int d = 0; d < D; ++d) {
+                const double sg = S[d * D + d];              // the reference passes the VARIANCE as sigma (:63-64)
+                cm += 0.5 * (1.0 + erf((smin[d] - m[d]) / (sg * 1.4142135623730951)))
+                    + (1.0 - 0.5 * (1.0 + erf((smax[d] - m[d]) / (sg * 1.4142135623730951))));
+            }
+        }
+        double ucb = -cm + kappa * sqrt(cv);
+        if (clip) ucb = fmin(ucb, 0.0);
+        jsum -= ucb;
+        if (cm_out) cm_out[(size_t)c * (H + 1) + t] = cm;
+        if (cv_out) cv_out[(size_t)c * (H + 1) + t] = cv;
+    }
+    // fixed-order sum over lanes (lane l holds steps l, l + 64, ...)
+    for (int off = 32; off >= 1; off >>= 1) jsum += __shfl_xor(jsum, off, 64);
+    if (lane == 0 && J_out) J_out[c] = jsum / (double)(H + 1);
+}
+
+// ------------------------------------------------------------------------------------------
 // Keep-the-best rule of gp_mpc_controller.py:146-148 over a vector (single workgroup).
 __global__ __launch_bounds__(1024) void argmin_kernel(const double* J, int B, long long first, double* out) {
     __shared__ double s_v[16];
@@ -51,6 +119,52 @@ int launch_argmin(Handle* h, const double* J, int B, long long first, hipStream_
     return GPMPC_OK;
 }
 
+// Monomial exponent tables (graded order) for the separable evaluation, D <= 4.
+static int ensure_monomials(Handle* h, int D) {
+    if (h->mono_D == D) return GPMPC_OK;
+    h->sep_kmax = 0; h->mono_CM = 0;
+    for (int k = 0; k < 16; ++k) h->mono_cum[k] = 0;
+    h->mono_D = D;
+    if (D > 4) return GPMPC_OK;
+    static thread_local int ex[kMaxMono * 4];
+    static thread_local double wt[kMaxMono];
+    int count = 0, kmax = -1;
+    for (int k = 0; k <= kMaxTaylor; ++k) {
+        // count monomials of exact degree k in D variables
+        long long nk = 1;
+        for (int i = 1; i < D; ++i) nk = nk * (k + i) / i;
+        if (count + nk > kMaxMono) break;
+        int a[4] = {0, 0, 0, 0};
+        // enumerate compositions of k into D parts, lexicographic
+        a[0] = k;
+        for (;;) {
+            double w = 1.0;
+            for (int d = 0; d < 4; ++d) { ex[count * 4 + d] = a[d]; for (int e = 2; e <= a[d]; ++e) w /= (double)e; }
+            wt[count++] = w;
+            // next composition
+            int i = D - 2;
+            while (i >= 0 && a[i] == 0) --i;
+            if (i < 0) break;
+            a[i] -= 1;
+            int tail = a[D - 1];
+            a[D - 1] = 0;
+            a[i + 1] = tail + 1;
+            if (D == 1) break;
+        }
+        h->mono_cum[k] = count;
+        kmax = k;
+    }
+    for (int k = kmax + 1; k < 16; ++k) h->mono_cum[k] = count;
+    int rc = grow(h, h->mono_w, kMaxMono);
+    if (rc) return rc;
+    if (!h->mono_exp) GPMPC_HIP_CHECK(h, hipMalloc(&h->mono_exp, kMaxMono * 4 * sizeof(int)));
+    GPMPC_HIP_CHECK(h, hipMemcpy(h->mono_exp, ex, count * 4 * sizeof(int), hipMemcpyHostToDevice));
+    GPMPC_HIP_CHECK(h, hipMemcpy(h->mono_w.p, wt, count * sizeof(double), hipMemcpyHostToDevice));
+    h->sep_kmax = kmax < 1 ? 0 : kmax;
+    h->mono_CM = count;
+    return GPMPC_OK;
+}
+
 static int padded_dim(int D) {
     const int sizes[] = {2, 3, 4, 6, 8, 16};
     for (int v : sizes) if (D <= v) return v;
@@ -72,6 +186,15 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         else nt = (N >= 128) ? 512 : 256;
     }
     const int nw = nt / 64;
+    int rcm = ensure_monomials(h, D);
+    if (rcm) return rcm;
+    const int CM = (h->opt_force_path == 0) ? h->mono_CM : 0;
+    a.xrange = h->xrange.p; a.mono_exp = h->mono_exp; a.mono_w = h->mono_w.p;
+    for (int k = 0; k < 16; ++k) a.mono_cum[k] = h->mono_cum[k];
+    a.sep_kmax = (h->opt_force_path == 0) ? h->sep_kmax : 0;
+    a.CM = CM;
+    a.force_path = h->opt_force_path;
+    a.force_sep = h->opt_force_sep;
 
     // choose pairs-per-group G and row chunking for the LDS-resident variant
     bool gs = h->opt_force_global != 0;
@@ -79,20 +202,22 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     size_t lds_bytes = 0;
     auto chunking = [&](int g) {
         // aim for ~8 wave items per wave and group, chunks of at least 16 rows
-        long long want = 8LL * nw * 64;
+        long long want = 5LL * nw * 64;
         long long rc = (want + (long long)g * N - 1) / ((long long)g * N);
         int maxrc = (N + 15) / 16;
         if (rc > maxrc) rc = maxrc;
         if (rc < 1) rc = 1;
         if (h->opt_rows_per_chunk > 0) rc = (N + h->opt_rows_per_chunk - 1) / h->opt_rows_per_chunk;
         CH = (N + (int)rc - 1) / (int)rc;
+        CH = (CH + 3) & ~3;                      // rows are processed in groups of 4
+        if (CH > 64) CH = 64;                    // T_a carries 64 zero padding rows
         RC = (N + CH - 1) / CH;
     };
     if (!gs) {
         for (int g = P; g >= 1; --g) {
             chunking(g);
             const int wpp = (RC * N + 63) / 64;
-            Layout L = make_layout(N, D, A, E, g, DP, wpp, false);
+            Layout L = make_layout(N, D, A, E, g, DP, wpp, CM, CH, a.H * A, false);
             if ((size_t)L.lds_total * 8 <= (size_t)h->lds_limit) { G = g; lds_bytes = (size_t)L.lds_total * 8; break; }
         }
         if (G == 0) gs = true;
@@ -103,7 +228,7 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         for (int g = (P < 16 ? P : 16); g >= 1; --g) {
             chunking(g);
             const int wpp = (RC * N + 63) / 64;
-            Layout L = make_layout(N, D, A, E, g, DP, wpp, true);
+            Layout L = make_layout(N, D, A, E, g, DP, wpp, CM, CH, a.H * A, true);
             if ((size_t)L.lds_total * 8 <= (size_t)h->lds_limit) {
                 G = g; lds_bytes = (size_t)L.lds_total * 8;
                 const size_t need = (size_t)L.pp_total * a.B;
@@ -117,15 +242,48 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         if (G == 0) { h->err = "rollout: problem does not fit LDS even with global scratch"; return GPMPC_ERR_LIMIT; }
     }
     a.G = G; a.CH = CH; a.RC = RC;
-
-    switch (DP) {
-        case 2:  return launch_rollout_dp2(h, a, nt, gs, lds_bytes, s);
-        case 3:  return launch_rollout_dp3(h, a, nt, gs, lds_bytes, s);
-        case 4:  return launch_rollout_dp4(h, a, nt, gs, lds_bytes, s);
-        case 6:  return launch_rollout_dp6(h, a, nt, gs, lds_bytes, s);
-        case 8:  return launch_rollout_dp8(h, a, nt, gs, lds_bytes, s);
-        default: return launch_rollout_dp16(h, a, nt, gs, lds_bytes, s);
+    {
+        // exact division by multiply-high: for d >= 2, umulhi(x, ceil(2^32 / d)) == x / d whenever x * d < 2^32
+        // (magic 0 encodes d == 1: no division)
+        const unsigned wppv = (unsigned)((RC * N + 63) / 64);
+        auto magic = [](unsigned d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + d - 1) / d); };
+        a.magic_N = magic((unsigned)N);
+        a.magic_wpp = magic(wppv);
+        if ((unsigned long long)RC * N * N >= 0x100000000ULL || (unsigned long long)G * wppv * wppv >= 0x100000000ULL) {
+            h->err = "rollout: index range too large for the multiply-high division"; return GPMPC_ERR_LIMIT;
+        }
     }
+
+    // the propagation always stores the trajectory (the cost kernel reads it back): own buffers if
+    // the caller did not ask for them
+    double* user_cm = a.cm_out;
+    double* user_cv = a.cv_out;
+    double* user_J = a.J_out;
+    {
+        const size_t nmu = (size_t)a.B * (a.H + 1) * D, nS = nmu * D;
+        if (!a.mu_out || !a.Sig_out) {
+            int rc = grow(h, h->traj, nmu + nS);
+            if (rc) return rc;
+            if (!a.mu_out) a.mu_out = h->traj.p;
+            if (!a.Sig_out) a.Sig_out = h->traj.p + nmu;
+        }
+    }
+    int rc;
+    switch (DP) {
+        case 2:  rc = launch_rollout_dp2(h, a, nt, gs, lds_bytes, s); break;
+        case 3:  rc = launch_rollout_dp3(h, a, nt, gs, lds_bytes, s); break;
+        case 4:  rc = launch_rollout_dp4(h, a, nt, gs, lds_bytes, s); break;
+        case 6:  rc = launch_rollout_dp6(h, a, nt, gs, lds_bytes, s); break;
+        case 8:  rc = launch_rollout_dp8(h, a, nt, gs, lds_bytes, s); break;
+        default: rc = launch_rollout_dp16(h, a, nt, gs, lds_bytes, s); break;
+    }
+    if (rc) return rc;
+    if (user_cm || user_cv || user_J) {
+        hipLaunchKernelGGL(traj_cost_kernel, dim3(a.B), dim3(64), 0, s, a.mu_out, a.Sig_out, a.actions, a.cost, D, A, a.H,
+                           a.kappa, a.clip, a.use_constraints, user_cm, user_cv, user_J);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+    }
+    return GPMPC_OK;
 }
 
 }  // namespace gpmpc_hip

@@ -11,12 +11,15 @@ namespace gpmpc_hip {
 // ------------------------------------------------------------------------------------------
 template <int DP, int NT>
 static int launch_variant(Handle* h, RolloutArgs& a, bool global_scratch, size_t lds_bytes, hipStream_t s) {
-    auto kern = global_scratch ? rollout_kernel<DP, NT, true> : rollout_kernel<DP, NT, false>;
-    static thread_local const void* configured[2] = {nullptr, nullptr};
+    const bool exact = (a.D == DP) && !global_scratch;
+    auto kern = global_scratch ? rollout_kernel<DP, NT, true, 0>
+                               : (exact ? rollout_kernel<DP, NT, false, DP> : rollout_kernel<DP, NT, false, 0>);
+    static thread_local const void* configured[3] = {nullptr, nullptr, nullptr};
     const void* kp = reinterpret_cast<const void*>(kern);
-    if (configured[global_scratch] != kp) {
+    const int slot = global_scratch ? 2 : (exact ? 1 : 0);
+    if (configured[slot] != kp) {
         GPMPC_HIP_CHECK(h, hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit));
-        configured[global_scratch] = kp;
+        configured[slot] = kp;
     }
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(NT), lds_bytes, s, a);
     GPMPC_HIP_CHECK(h, hipGetLastError());

@@ -13,6 +13,13 @@
 //              with Z = R_ab^-1 Sigma (= 2Q, :163), u_i = nu_i/l_a^2, w_j = nu_j/l_b^2,
 //              ka'_i = k_ai + u_i^T Z u_i / 2, kb'_j = k_bj + w_j^T Z w_j / 2, g_i = Z u_i
 //     S_ab   = [sum_ij beta_ai L_ab,ij beta_bj - d_ab sum_ij iK_a,ij L_aa,ij]/sqrt|R_ab| ...   (:170-178)
+//   Because |g_i . w_j| <= cmax is bounded per (pair, step) from the data range and Z, the factor
+//   exp(g_i . w_j) is evaluated by a Taylor polynomial of the degree K that makes the truncation
+//   error < 2^-54 relative (exact to fp64 rounding), the other two factors exp(ka'_i), exp(kb'_j)
+//   are per-point; for an off-diagonal pair the double sum then separates over monomials,
+//     sum_ij ra_i rb_j exp(g_i . w_j) = sum_|alpha|<=K (sum_i ra_i g_i^alpha)(sum_j rb_j w_j^alpha)/alpha!,
+//   i.e. O(N C(D+K,D)) instead of O(N^2) (used for D <= 4); when cmax is too large for K <= 14 the
+//   pair falls back to the direct exp(ka' + kb' + g.w) evaluation.
 //   The (D,D,N,N) tensors of the reference (:166,169-171) never exist: the N x N pairwise
 //   work of each output pair a <= b is streamed through registers; for a == b the two sums
 //   are merged through T_a = beta_a beta_a^T - iK_a and only i <= j is visited (L_aa and T_a
@@ -25,8 +32,13 @@
 // followed by a fixed-order sum, so results are bitwise reproducible run to run.
 #pragma once
 #include "gpmpc_internal.h"
+#include <type_traits>
 
-#ifdef GPMPC_TRACE_ON
+#if defined(GPMPC_PROF_ON)
+// phase profile of workgroup 0 (debug build only): cycles between consecutive trace points, summed over steps
+#define GPMPC_TRACE(id) do { if (threadIdx.x == 0 && blockIdx.x == 0) { long long now_ = __builtin_readcyclecounter(); \
+    prof_acc[id] += now_ - prof_last; prof_last = now_; } } while (0)
+#elif defined(GPMPC_TRACE_ON)
 #define GPMPC_TRACE(id) do { if (threadIdx.x == 0 && blockIdx.x == 0) printf("trace %d t=%d\n", id, t_dbg); } while (0)
 #else
 #define GPMPC_TRACE(id) do {} while (0)
@@ -34,25 +46,30 @@
 
 namespace gpmpc_hip {
 
+
+constexpr int kMaxTaylor = 14;     // highest Taylor degree of exp(g.w); beyond that: direct exp path
+constexpr int kMaxMono = 256;      // most monomials of the separable (off-diagonal) evaluation
+
 // ------------------------------------------------------------------------------------------
 // LDS / scratch layout (offsets in doubles), shared by host (sizing) and device (carving).
 struct Layout {
-    int mu, Sig, m, M, cc, s1, Vs, Sp, TS, v1, v2, ev, misc, rdet, aug, part, ints;
+    int mu, Sig, m, M, cc, s1, Vs, Sp, TS, v1, v2, ev, misc, rdet, aug, part, mom, ints;
+    int c_ils2, c_logvar, c_var, c_xr, c_act, c_monow, c_monoe;    // read-only tables copied to LDS once
     int lds_total;     // doubles of LDS
     // per-point arrays: in LDS (offsets from smem) or in global scratch (offsets from base)
-    int nu, kk, lb, rows, kb;
+    int nu, lb, rows, kb;
     int pp_total;      // doubles of the per-point block
 };
 
 __host__ __device__ inline int rnd2(int x) { return (x + 1) & ~1; }
 
-__host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G, int DP, int wpp,
+__host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G, int DP, int wpp, int CM, int CH, int HA,
                                               bool global_scratch) {
     Layout L;
     const int P = D * (D + 1) / 2;
     int o = 0;
     L.mu = o;   o += rnd2(D);
-    L.Sig = o;  o += rnd2(D * D);
+    L.Sig = o;  o += 2 * rnd2(D * D);           // double-buffered
     L.m = o;    o += rnd2(E);
     L.M = o;    o += rnd2(D);
     L.cc = o;   o += rnd2(D);
@@ -65,15 +82,21 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     L.ev = o;   o += rnd2(D + A);
     L.misc = o; o += 8;
     L.rdet = o; o += rnd2(G);
-    const int nprob = D > G ? D : G;
-    L.aug = o;  o += nprob * 2 * D * D;
+    L.aug = o;  o += (D + G) * 2 * D * D;       // D mean problems + G pair problems, [A | RHS]
     L.part = o; o += rnd2(G * wpp);
-    L.ints = o; o += rnd2((2 * P + 4 + 1) / 2);   // pair tables pa[P], pb[P] + counter (ints)
+    L.mom = o;  o += G * 2 * rnd2(CM);
+    L.ints = o; o += rnd2((2 * P + G + 4 + 1) / 2);   // pa[P], pb[P], K[G], counter (ints)
+    L.c_ils2 = o;   o += rnd2(D * E);
+    L.c_logvar = o; o += rnd2(D);
+    L.c_var = o;    o += rnd2(D);
+    L.c_xr = o;     o += rnd2(2 * E);
+    L.c_act = o;    o += rnd2(HA);
+    L.c_monow = o;  o += rnd2(CM);
+    L.c_monoe = o;  o += rnd2((CM + 1) / 2);           // packed exponents, one int per monomial
     int q = global_scratch ? 0 : o;
     L.nu = q;   q += rnd2(D * N);
-    L.kk = q;   q += rnd2(D * N);
     L.lb = q;   q += rnd2(D * N);
-    L.rows = q; q += G * N * (DP + 2);
+    L.rows = q; q += G * (N + CH) * (DP + 2);       // + CH zero rows per pair (lanes of a wave share the trip count)
     L.kb = q;   q += rnd2(G * N);
     if (global_scratch) { L.lds_total = o; L.pp_total = q; }
     else                { L.lds_total = q; L.pp_total = q - o; }
@@ -81,10 +104,34 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
 }
 
 // ------------------------------------------------------------------------------------------
+// Wavefront sum on the DPP crossbar (no LDS round trips): inclusive scan inside each row of 16 lanes
+// (row_shr 1,2,4,8), then row_bcast:15 / row_bcast:31 carry the row totals up; lane 63 holds the
+// total, which is broadcast through an SGPR.  Fixed order => bitwise reproducible.
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_shifted(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
 __device__ inline double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v += dpp_shifted<0x111, 0xf>(v);      // row_shr:1
+    v += dpp_shifted<0x112, 0xf>(v);      // row_shr:2
+    v += dpp_shifted<0x114, 0xf>(v);      // row_shr:4
+    v += dpp_shifted<0x118, 0xf>(v);      // row_shr:8
+    v += dpp_shifted<0x142, 0xa>(v);      // row_bcast:15 -> rows 1, 3
+    v += dpp_shifted<0x143, 0xc>(v);      // row_bcast:31 -> rows 2, 3
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
+}
+
+// LDS hand-off between lanes of ONE wavefront (no workgroup barrier): LDS operations of a wave
+// complete in issue order; the fences keep the compiler from moving accesses across.
+__device__ inline void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // Gaussian elimination with partial pivoting on an augmented [A | RHS] block (row stride ld).
@@ -127,30 +174,274 @@ __device__ inline double gauss_solve(double* aug, int D, int nrhs, int ld) {
     return det;
 }
 
+// Register variant for small (padded) dimensions: [A | RHS] lives in registers, every loop is
+// unrolled, the pivot row is brought up with selects.  Rows/cols >= D are identity padding.
+template <int DP>
+__device__ inline double gauss_solve_reg(double (&a)[DP][2 * DP]) {
+    double det = 1.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+        // partial pivoting: choose the largest |a[r][k]|, r >= k
+        int piv = k;
+        double best = fabs(a[k][k]);
+#pragma unroll
+        for (int r = k + 1; r < DP; ++r) {
+            const double v = fabs(a[r][k]);
+            const bool better = v > best;
+            best = better ? v : best;
+            piv = better ? r : piv;
+        }
+#pragma unroll
+        for (int r = k + 1; r < DP; ++r) {
+            const bool sw = (piv == r);
+#pragma unroll
+            for (int c = 0; c < 2 * DP; ++c) {
+                const double x = a[k][c], y = a[r][c];
+                a[k][c] = sw ? y : x;
+                a[r][c] = sw ? x : y;
+            }
+        }
+        det = (piv != k) ? -det : det;
+        const double pv = a[k][k];
+        det *= pv;
+        const double ip = 1.0 / pv;
+#pragma unroll
+        for (int r = k + 1; r < DP; ++r) {
+            const double f = a[r][k] * ip;
+#pragma unroll
+            for (int c = k + 1; c < 2 * DP; ++c) a[r][c] = fma(-f, a[k][c], a[r][c]);
+        }
+    }
+#pragma unroll
+    for (int k = DP - 1; k >= 0; --k) {
+        const double ip = 1.0 / a[k][k];
+#pragma unroll
+        for (int c = DP; c < 2 * DP; ++c) {
+            double v = a[k][c];
+#pragma unroll
+            for (int r = k + 1; r < DP; ++r) v = fma(-a[k][r], a[r][c], v);
+            a[k][c] = v * ip;
+        }
+    }
+    return det;
+}
+
+// Closed-form (adjugate) solve for DP <= 3: the matrices on this path are Sigma + diag(l^2) and
+// Sigma diag(.) + I with Sigma small, i.e. far from singular, so cofactor expansion is accurate to a
+// few ulps and an order of magnitude shorter than elimination (the solve sits on the serial
+// per-step critical path of one wavefront).  [A | RHS] -> RHS := A^-1 RHS, returns det(A).
+template <int DP>
+__device__ inline double adjugate_solve(double (&a)[DP][2 * DP]) {
+    static_assert(DP == 2 || DP == 3, "closed form only for 2x2 / 3x3");
+    double inv[DP][DP];
+    double det;
+    if constexpr (DP == 2) {
+        det = fma(a[0][0], a[1][1], -(a[0][1] * a[1][0]));
+        const double id = 1.0 / det;
+        inv[0][0] = a[1][1] * id;  inv[0][1] = -a[0][1] * id;
+        inv[1][0] = -a[1][0] * id; inv[1][1] = a[0][0] * id;
+    } else {
+        const double c00 = fma(a[1][1], a[2][2], -(a[1][2] * a[2][1]));
+        const double c01 = fma(a[1][2], a[2][0], -(a[1][0] * a[2][2]));
+        const double c02 = fma(a[1][0], a[2][1], -(a[1][1] * a[2][0]));
+        det = fma(a[0][0], c00, fma(a[0][1], c01, a[0][2] * c02));
+        const double id = 1.0 / det;
+        inv[0][0] = c00 * id;
+        inv[1][0] = c01 * id;
+        inv[2][0] = c02 * id;
+        inv[0][1] = fma(a[0][2], a[2][1], -(a[0][1] * a[2][2])) * id;
+        inv[1][1] = fma(a[0][0], a[2][2], -(a[0][2] * a[2][0])) * id;
+        inv[2][1] = fma(a[0][1], a[2][0], -(a[0][0] * a[2][1])) * id;
+        inv[0][2] = fma(a[0][1], a[1][2], -(a[0][2] * a[1][1])) * id;
+        inv[1][2] = fma(a[0][2], a[1][0], -(a[0][0] * a[1][2])) * id;
+        inv[2][2] = fma(a[0][0], a[1][1], -(a[0][1] * a[1][0])) * id;
+    }
+    double out[DP][DP];
+#pragma unroll
+    for (int i = 0; i < DP; ++i)
+#pragma unroll
+        for (int j = 0; j < DP; ++j) {
+            double v = 0.0;
+#pragma unroll
+            for (int k = 0; k < DP; ++k) v = fma(inv[i][k], a[k][DP + j], v);
+            out[i][j] = v;
+        }
+#pragma unroll
+    for (int i = 0; i < DP; ++i)
+#pragma unroll
+        for (int j = 0; j < DP; ++j) a[i][DP + j] = out[i][j];
+    return det;
+}
+
+template <int DP>
+__device__ inline double small_solve(double (&a)[DP][2 * DP]) {
+    if constexpr (DP <= 3) return adjugate_solve<DP>(a);
+    else return gauss_solve_reg<DP>(a);
+}
+
 __device__ inline double norm_cdf_ref(double x, double mu, double sigma) {
     // normal_cdf of the reference (control_objects/utils/pytorch_utils.py:16-17)
     return 0.5 * (1.0 + erf((x - mu) / (sigma * 1.4142135623730951)));
 }
 
+// 1/k!
+__device__ constexpr double kInvFact[kMaxTaylor + 1] = {
+    1.0, 1.0, 0.5, 1.0 / 6, 1.0 / 24, 1.0 / 120, 1.0 / 720, 1.0 / 5040, 1.0 / 40320, 1.0 / 362880, 1.0 / 3628800,
+    1.0 / 39916800, 1.0 / 479001600, 1.0 / 6227020800.0, 1.0 / 87178291200.0};
+
+// kTaylorMaxArg[K] = largest c with c^(K+1)/(K+1)! * exp(2c) <= 2^-54  (computed offline, rounded down)
+__device__ constexpr double kTaylorMaxArg[kMaxTaylor + 1] = {
+    0.0, 1.052584e-08, 6.924801e-06, 1.908411e-04, 1.458895e-03, 5.830057e-03, 1.600533e-02, 3.463687e-02, 6.382214e-02, 1.049198e-01, 1.585847e-01, 2.249037e-01, 3.035549e-01, 3.939504e-01, 4.953495e-01};
+
+template <int K>
+__device__ inline double taylor_exp(double c) {
+    double p = kInvFact[K];
+#pragma unroll
+    for (int k = K - 1; k >= 0; --k) p = fma(p, c, kInvFact[k]);
+    return p;
+}
+
+constexpr int kTPad = 64;      // zero rows appended to every T_a (a wave may run up to CH <= 64 rows past the data)
+
+// One (pair, row-chunk, column) item of the pairwise work, Taylor form.  `nrows` is wave-uniform and a
+// multiple of 4; rows beyond the data are zero padding and T is zero below its diagonal, so the loop
+// body carries no predication (scalar loop, loads issue ahead of the math).
+//   diagonal pair : sum_i T[i][j] * ea_i * P_K(g_i . w_j)            (row record [0] = ea_i)
+//   off-diagonal  : sum_i ra_i * P_K(g_i . w_j)                      (row record [1] = beta_ai ea_i)
+template <int DP, int K>
+__device__ inline double item_taylor(const double* rec, int nrows, const double (&w)[DP], bool diag, const double* Tp, int N) {
+    constexpr int RS = DP + 2;
+    constexpr int U = 4;
+    double acc = 0.0;
+    if (diag) {
+        double tv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) tv[u] = Tp[(size_t)u * N];
+        for (int it = 0; it < nrows; it += U) {
+            double tn[U];
+            const bool more = it + U < nrows;                 // wave-uniform
+#pragma unroll
+            for (int u = 0; u < U; ++u) tn[u] = more ? Tp[(size_t)(U + u) * N] : 0.0;
+            double cc[U], ev[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double* r = rec + u * RS;
+                double c = r[2] * w[0];
+#pragma unroll
+                for (int d = 1; d < DP; ++d) c = fma(r[2 + d], w[d], c);
+                cc[u] = c;
+                ev[u] = r[0];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = fma(taylor_exp<K>(cc[u]) * ev[u], tv[u], acc);
+#pragma unroll
+            for (int u = 0; u < U; ++u) tv[u] = tn[u];
+            rec += U * RS;
+            Tp += (size_t)U * N;
+        }
+    } else {
+        for (int it = 0; it < nrows; it += U) {
+            double cc[U], rv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double* r = rec + u * RS;
+                double c = r[2] * w[0];
+#pragma unroll
+                for (int d = 1; d < DP; ++d) c = fma(r[2 + d], w[d], c);
+                cc[u] = c;
+                rv[u] = r[1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = fma(taylor_exp<K>(cc[u]), rv[u], acc);
+            rec += U * RS;
+        }
+    }
+    return acc;
+}
+
+// Same item, direct form exp(ka'_i + kb'_j + g_i . w_j)  (row record [0] = ka'_i, [1] = beta_ai).
+template <int DP>
+__device__ inline double item_exp(const double* rec, int nrows, const double (&w)[DP], double kbj, bool diag,
+                                  const double* Tp, int N) {
+    constexpr int RS = DP + 2;
+    constexpr int U = 2;
+    double acc = 0.0;
+    if (diag) {
+        for (int it = 0; it < nrows; it += U) {
+            double tv[U], aa[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) tv[u] = Tp[(size_t)u * N];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double* r = rec + u * RS;
+                double arg = r[0] + kbj;
+#pragma unroll
+                for (int d = 0; d < DP; ++d) arg = fma(r[2 + d], w[d], arg);
+                aa[u] = arg;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = fma(exp(aa[u]), tv[u], acc);
+            rec += U * RS;
+            Tp += (size_t)U * N;
+        }
+    } else {
+        for (int it = 0; it < nrows; it += U) {
+            double aa[U], bv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double* r = rec + u * RS;
+                double arg = r[0] + kbj;
+#pragma unroll
+                for (int d = 0; d < DP; ++d) arg = fma(r[2 + d], w[d], arg);
+                aa[u] = arg;
+                bv[u] = r[1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc = fma(exp(aa[u]), bv[u], acc);
+            rec += U * RS;
+        }
+    }
+    return acc;
+}
+
+__device__ inline int wave_max_i32(int v) {
+    auto step = [&](auto ctrl, auto rmask) {
+        const int o = __builtin_amdgcn_update_dpp(0, v, decltype(ctrl)::value, decltype(rmask)::value, 0xf, true);
+        v = o > v ? o : v;
+    };
+    step(std::integral_constant<int, 0x111>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x112>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x114>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x118>{}, std::integral_constant<int, 0xf>{});
+    step(std::integral_constant<int, 0x142>{}, std::integral_constant<int, 0xa>{});
+    step(std::integral_constant<int, 0x143>{}, std::integral_constant<int, 0xc>{});
+    return __builtin_amdgcn_readlane(v, 63);        // values are >= 0, so the zero fill is neutral
+}
+
 // ------------------------------------------------------------------------------------------
-template <int DP, int NT, bool GLOBAL>
+// DX = exact state dimension known at compile time (0: runtime p.D <= DP): folds every D-dependent
+// offset and small loop, which is what keeps the 128-VGPR budget of a 1024-thread workgroup.
+template <int DP, int NT, bool GLOBAL, int DX>
 __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NT / kWave;
-    constexpr int RS = DP + 2;              // row record: ka', beta_a, g[0..DP)
+    constexpr int RS = DP + 2;              // row record: [0] ea_i | ka'_i, [1] ra_i | beta_ai, [2..] g_i
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int c = blockIdx.x;
-    const int N = p.N, D = p.D, A = p.A, E = p.E, H = p.H, G = p.G;
+    const int D = (DX > 0) ? DX : p.D;
+    const int N = p.N, A = p.A, E = p.E, H = p.H, G = p.G, CM = p.CM;
     const int P = D * (D + 1) / 2;
     const int DA = D + A;
     const int LD = 2 * D;                   // row stride of an augmented block
-    const int wpp = (p.RC * N + 63) / 64;   // wave items per output pair
+    const int wpp = (p.RC * N + 63) / 64;   // work-item slots per output pair
+    const int SD2 = rnd2(D * D);
 
-    const Layout L = make_layout(N, D, A, E, G, DP, wpp, GLOBAL);
+    const Layout L = make_layout(N, D, A, E, G, DP, wpp, CM, p.CH, H * A, GLOBAL);
+    const int NR = N + p.CH;                // rows per pair in the row-record array (data + zero padding)
     double* s_mu = smem + L.mu;
-    double* s_Sig = smem + L.Sig;
+    double* s_Sig2 = smem + L.Sig;
     double* s_m = smem + L.m;
     double* s_M = smem + L.M;
     double* s_cc = smem + L.cc;
@@ -158,342 +449,460 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     double* s_Vs = smem + L.Vs;             // [k][a]
     double* s_Sp = smem + L.Sp;
     double* s_TS = smem + L.TS;
-    double* s_v1 = smem + L.v1;
-    double* s_v2 = smem + L.v2;
-    double* s_ev = smem + L.ev;
-    double* s_misc = smem + L.misc;         // [0] = running J
     double* s_rdet = smem + L.rdet;
-    double* s_aug = smem + L.aug;
+    double* s_aug = smem + L.aug;           // problems [0, D): mean part, [D, D+G): pairs of the group
     double* s_part = smem + L.part;
+    double* s_mom = smem + L.mom;           // [gq][side][CM]
     int* s_pa = reinterpret_cast<int*>(smem + L.ints);
     int* s_pb = s_pa + P;
-    int* s_counter = s_pb + P;
+    int* s_K = s_pb + P;                    // per pair of the group: Taylor degree, 0 = direct exp
+    int* s_counter = s_K + G;
 
     double* ppbase = GLOBAL ? (p.scratch + (size_t)c * p.scratch_stride) : smem;
     double* a_nu = ppbase + L.nu;           // [d][p]
-    double* a_kk = ppbase + L.kk;           // [a][p]
     double* a_lb = ppbase + L.lb;           // [a][p]
     double* a_rows = ppbase + L.rows;       // [gq][p][RS]
     double* a_kb = ppbase + L.kb;           // [gq][p]
 
-    const double* cost_target = p.cost;
-    const double* cost_W = p.cost + DA;
-    const double* cost_WT = cost_W + DA * DA;
-    const double* cost_smin = cost_WT + D * D;
-    const double* cost_smax = cost_smin + D;
+    double* c_ils2 = smem + L.c_ils2;
+    double* c_logvar = smem + L.c_logvar;
+    double* c_var = smem + L.c_var;
+    double* c_xr = smem + L.c_xr;
+    double* c_act = smem + L.c_act;
+    double* c_monow = smem + L.c_monow;
+    int* c_monoe = reinterpret_cast<int*>(smem + L.c_monoe);
     const double* act = p.actions + (size_t)c * H * A;
 
     [[maybe_unused]] int t_dbg = -1;
+#if defined(GPMPC_PROF_ON)
+    long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_last = __builtin_readcyclecounter();
+#endif
     // ---- init -----------------------------------------------------------------------
-    for (int i = tid; i < D; i += NT) s_mu[i] = p.mu0[i];
-    for (int i = tid; i < D * D; i += NT) s_Sig[i] = p.S0[i];
+    for (int i = tid; i < D; i += NT) { s_mu[i] = p.mu0[i]; c_logvar[i] = p.logvar[i]; c_var[i] = p.var[i]; }
+    for (int i = tid; i < D * D; i += NT) s_Sig2[i] = p.S0[i];
+    for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
+    for (int i = tid; i < 2 * E; i += NT) c_xr[i] = p.xrange[i];
+    for (int i = tid; i < H * A; i += NT) c_act[i] = act[i];
+    for (int i = tid; i < CM; i += NT) {
+        c_monow[i] = p.mono_w[i];
+        c_monoe[i] = p.mono_exp[i * 4] | (p.mono_exp[i * 4 + 1] << 8) | (p.mono_exp[i * 4 + 2] << 16) | (p.mono_exp[i * 4 + 3] << 24);
+    }
+    for (int i = tid; i < G * p.CH * RS; i += NT) {
+        const int gq = i / (p.CH * RS), k = i - gq * (p.CH * RS);
+        a_rows[((size_t)gq * NR + N) * RS + k] = 0.0;                      // zero padding rows
+    }
     if (tid == 0) {
-        s_misc[0] = 0.0;
         int q = 0;
         for (int a = 0; a < D; ++a)
             for (int b = a; b < D; ++b) { s_pa[q] = a; s_pb[q] = b; ++q; }
     }
     __syncthreads();
     GPMPC_TRACE(1);
-    if (p.mu_out)
-        for (int i = tid; i < D; i += NT) p.mu_out[((size_t)c * (H + 1)) * D + i] = s_mu[i];
-    if (p.Sig_out)
-        for (int i = tid; i < D * D; i += NT) p.Sig_out[((size_t)c * (H + 1)) * D * D + i] = s_Sig[i];
+    for (int i = tid; i < D; i += NT) p.mu_out[((size_t)c * (H + 1)) * D + i] = s_mu[i];
+    for (int i = tid; i < D * D; i += NT) p.Sig_out[((size_t)c * (H + 1)) * D * D + i] = s_Sig2[i];
 
-    for (int t = 0; t <= H; ++t) {
+    int cur = 0;
+    const int tid_outer = tid;
+    for (int t = 0; t < H; ++t) {
         t_dbg = t;
-        const bool terminal = (t == H);
-        // ---- stage / terminal cost of (mu_t, Sigma_t, a_t) ------------------------------
-        // setpoint_distance_reward_mapper.py:36-56 (stage), :135-141 (terminal)
-        {
-            const int n = terminal ? D : DA;
-            const double* Wm = terminal ? cost_WT : cost_W;
-            for (int i = tid; i < n; i += NT)
-                s_ev[i] = (i < D ? s_mu[i] : act[t * A + (i - D)]) - cost_target[i];
-            if (!terminal) {
+        // Re-derive the thread coordinates inside every step from an opaque copy: otherwise the compiler
+        // hoists dozens of per-thread address computations out of the horizon loop and keeps them live
+        // across all phases, which overflows the 128-VGPR budget of a 1024-thread workgroup (spills).
+        int tid_opaque = tid_outer;
+        asm volatile("" : "+v"(tid_opaque));
+        const int tid = tid_opaque;
+        const int lane = tid & 63;
+        const int wave = tid >> 6;
+        const double* s_Sig = s_Sig2 + cur * SD2;
+        double* s_SigNext = s_Sig2 + (cur ^ 1) * SD2;
+
+        for (int q0 = 0; q0 < P; q0 += G) {
+            const int Gc = (P - q0 < G) ? (P - q0) : G;
+            const bool first = (q0 == 0);
+            const int nmean = first ? D : 0;
+
+            // ---- P1: small D x D algebra, one thread per problem ------------------------------
+            if (first) {
                 // input mean of this step: [mu, a_t, (time)]  (gp_model.py:98-102)
                 for (int i = tid; i < E; i += NT) {
                     double v;
                     if (i < D) v = s_mu[i];
-                    else if (i < DA) v = act[t * A + (i - D)];
+                    else if (i < DA) v = c_act[t * A + (i - D)];
                     else v = p.time0 + (double)t;
                     s_m[i] = v;
                 }
             }
+            if (tid < nmean) {
+                // A_a = Sigma + diag(l_a^2) -> A_a^-1, det  (restated B of gp_model.py:141)
+                const int a = tid;
+                double* aug = s_aug + a * (D * LD);
+                double prodil = 1.0;
+                double detA;
+                if constexpr (DP <= 4) {
+                    double m[DP][2 * DP];
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) {
+                        const double il2 = (i < D) ? c_ils2[a * E + i] : 1.0;
+                        prodil *= il2;
+#pragma unroll
+                        for (int j = 0; j < DP; ++j) {
+                            const bool in = (i < D && j < D);
+                            m[i][j] = (in ? s_Sig[i * D + j] : 0.0) + (i == j ? 1.0 / il2 : 0.0);
+                            m[i][DP + j] = (in && i == j) ? 1.0 : 0.0;
+                        }
+                    }
+                    detA = small_solve<DP>(m);
+#pragma unroll
+                    for (int i = 0; i < DP; ++i)
+#pragma unroll
+                        for (int j = 0; j < DP; ++j)
+                            if (i < D && j < D) aug[i * LD + D + j] = m[i][DP + j];
+                } else {
+                    for (int i = 0; i < D; ++i) {
+                        const double il2 = c_ils2[a * E + i];
+                        prodil *= il2;
+                        for (int j = 0; j < D; ++j) {
+                            aug[i * LD + j] = s_Sig[i * D + j] + (i == j ? 1.0 / il2 : 0.0);
+                            aug[i * LD + D + j] = (i == j ? 1.0 : 0.0);
+                        }
+                    }
+                    detA = gauss_solve(aug, D, D, LD);
+                }
+                s_cc[a] = c_var[a] / sqrt(detA * prodil);            // c_a = var_a / sqrt(det B_a)  (:150)
+            } else if (tid < nmean + Gc) {
+                const int gq = tid - nmean;
+                const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
+                double* aug = s_aug + (D + gq) * (D * LD);
+                double detR;
+                double cmax = 0.0;
+                // |g_i . w_j| <= sum_dd' |Z_dd'| umax_d wmax_d' with the data range of the memory points
+                if constexpr (DP <= 4) {
+                    double m[DP][2 * DP];
+#pragma unroll
+                    for (int i = 0; i < DP; ++i)
+#pragma unroll
+                        for (int j = 0; j < DP; ++j) {
+                            const bool in = (i < D && j < D);
+                            const double sg = in ? s_Sig[i * D + j] : 0.0;
+                            const double dab = in ? c_ils2[a * E + j] + c_ils2[b * E + j] : 0.0;
+                            m[i][j] = sg * dab + (i == j ? 1.0 : 0.0);                   // R (:156-159)
+                            m[i][DP + j] = sg;
+                        }
+                    detR = small_solve<DP>(m);                                            // Z = R^-1 Sigma = 2Q (:163)
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) {
+                        const double mi = (i < D) ? s_mu[i] : 0.0;
+                        const double ui = (i < D) ? fmax(fabs(c_xr[i] - mi), fabs(c_xr[E + i] - mi)) * c_ils2[a * E + i] : 0.0;
+#pragma unroll
+                        for (int j = 0; j < DP; ++j) {
+                            if (i < D && j < D) {
+                                aug[i * LD + D + j] = m[i][DP + j];
+                                const double mj = s_mu[j];
+                                const double wj = fmax(fabs(c_xr[j] - mj), fabs(c_xr[E + j] - mj)) * c_ils2[b * E + j];
+                                cmax = fma(fabs(m[i][DP + j]) * ui, wj, cmax);
+                            }
+                        }
+                    }
+                } else {
+                    for (int i = 0; i < D; ++i)
+                        for (int j = 0; j < D; ++j) {
+                            const double dab = c_ils2[a * E + j] + c_ils2[b * E + j];
+                            aug[i * LD + j] = s_Sig[i * D + j] * dab + (i == j ? 1.0 : 0.0);
+                            aug[i * LD + D + j] = s_Sig[i * D + j];
+                        }
+                    detR = gauss_solve(aug, D, D, LD);
+                    const double* Z = aug + D;
+                    for (int i = 0; i < D; ++i) {
+                        const double mi = s_mu[i];
+                        const double ui = fmax(fabs(c_xr[i] - mi), fabs(c_xr[E + i] - mi)) * c_ils2[a * E + i];
+                        for (int j = 0; j < D; ++j) {
+                            const double mj = s_mu[j];
+                            const double wj = fmax(fabs(c_xr[j] - mj), fabs(c_xr[E + j] - mj)) * c_ils2[b * E + j];
+                            cmax = fma(fabs(Z[i * LD + j]) * ui, wj, cmax);
+                        }
+                    }
+                }
+                s_rdet[gq] = 1.0 / sqrt(detR);                                           // (:176)
+                // smallest K with cmax^(K+1)/(K+1)! * exp(2 cmax) <= 2^-54 (truncation below fp64 rounding)
+                int K = 0;
+                if (p.force_path != 1 && cmax <= kTaylorMaxArg[kMaxTaylor]) {
+                    K = 1;
+#pragma unroll
+                    for (int k = 1; k < kMaxTaylor; ++k) K += (cmax > kTaylorMaxArg[k]) ? 1 : 0;
+                }
+                // separable (moment) evaluation of an off-diagonal pair when it is the cheaper one
+                if (a != b && K > 0 && K <= p.sep_kmax && p.force_path == 0) {
+                    const long long C = p.mono_cum[K];
+                    const long long cost_sep = 2 * C * (((N + 63) / 64) * 12 + 24);
+                    const long long cost_el = (long long)N * N * (D + K + 1) / 64;
+                    if (p.force_sep || cost_sep < cost_el) K |= 64;
+                }
+                s_K[gq] = K;
+            }
+#if defined(GPMPC_PROF_ON)
+            if (threadIdx.x == 0 && blockIdx.x == 0) { long long now_ = __builtin_readcyclecounter(); prof_acc[7] += now_ - prof_last; }
+#endif
+            if (tid == NT - 1) *s_counter = 0;
             __syncthreads();
             GPMPC_TRACE(2);
-            for (int idx = tid; idx < D * D; idx += NT) {
-                const int i = idx / D, j = idx - i * D;
-                double s = 0.0;
-                for (int k = 0; k < D; ++k) s = fma(Wm[i * n + k], s_Sig[k * D + j], s);
-                s_TS[idx] = s;                                   // TS = W Sigma  (:52 / :138)
-            }
-            for (int k = tid; k < 2 * D; k += NT) {
-                double s = 0.0;
-                if (k < D) { for (int i = 0; i < n; ++i) s = fma(s_ev[i], Wm[i * n + k], s); s_v1[k] = s; }
-                else { const int kk = k - D; for (int j = 0; j < n; ++j) s = fma(Wm[kk * n + j], s_ev[j], s); s_v2[kk] = s; }
+
+            // ---- P2: per-point quantities ------------------------------------------------------
+            for (int it = tid; it < (nmean + Gc) * N; it += NT) {
+                const int prob = it / N, pt = it - prob * N;
+                double nu[DP];
+#pragma unroll
+                for (int d = 0; d < DP; ++d) nu[d] = (d < D) ? (p.Xt[d * N + pt] - s_m[d]) : 0.0;
+                if (prob < nmean) {
+                    const int a = prob;
+                    const double* Ai = s_aug + a * (D * LD) + D;          // A_a^-1
+                    double q = 0.0;
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) {
+                        if (i < D) {
+                            double r = 0.0;
+#pragma unroll
+                            for (int j = 0; j < DP; ++j)
+                                if (j < D) r = fma(Ai[i * LD + j], nu[j], r);
+                            q = fma(nu[i], r, q);
+                        }
+                    }
+                    for (int e = D; e < E; ++e) {
+                        const double v = p.Xt[e * N + pt] - s_m[e];
+                        q = fma(v * v, c_ils2[a * E + e], q);
+                    }
+                    a_lb[a * N + pt] = exp(-0.5 * q) * p.beta[a * N + pt];                 // lb (:148)
+                    if (a == 0) {
+#pragma unroll
+                        for (int d = 0; d < DP; ++d)
+                            if (d < D) a_nu[d * N + pt] = nu[d];
+                    }
+                } else {
+                    const int gq = prob - nmean;
+                    const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
+                    const int K = s_K[gq] & 63;
+                    const double* Z = s_aug + (D + gq) * (D * LD) + D;
+                    double u[DP], w[DP], g[DP];
+                    double ksa = 0.0, ksb = 0.0;                                          // sum_e nu_e^2 / l_e^2
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) {
+                        const double ia = (d < D) ? c_ils2[a * E + d] : 0.0;
+                        const double ib = (d < D) ? c_ils2[b * E + d] : 0.0;
+                        u[d] = nu[d] * ia;
+                        w[d] = nu[d] * ib;
+                        ksa = fma(nu[d], u[d], ksa);
+                        ksb = fma(nu[d], w[d], ksb);
+                        g[d] = 0.0;
+                    }
+                    for (int e = D; e < E; ++e) {
+                        const double v = p.Xt[e * N + pt] - s_m[e];
+                        ksa = fma(v * v, c_ils2[a * E + e], ksa);
+                        ksb = fma(v * v, c_ils2[b * E + e], ksb);
+                    }
+                    double qa = 0.0, qb = 0.0;
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) {
+                        if (i < D) {
+                            double zu = 0.0, zw = 0.0;
+#pragma unroll
+                            for (int j = 0; j < DP; ++j)
+                                if (j < D) {
+                                    const double z = Z[i * LD + j];
+                                    zu = fma(z, u[j], zu);
+                                    zw = fma(z, w[j], zw);
+                                    g[j] = fma(z, u[i], g[j]);      // g = Z^T u: cross term u^T Z w = g . w
+                                }
+                            qa = fma(u[i], zu, qa);
+                            qb = fma(w[i], zw, qb);
+                        }
+                    }
+                    const double ka = c_logvar[a] - 0.5 * ksa + 0.5 * qa;                 // k_a (:168) + u^T Q u
+                    const double kb = c_logvar[b] - 0.5 * ksb + 0.5 * qb;
+                    const double ba = p.beta[a * N + pt];
+                    double* rec = a_rows + ((size_t)gq * NR + pt) * RS;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) rec[2 + d] = g[d];
+                    if (K > 0) {
+                        const double ea = exp(ka);
+                        rec[0] = ea;
+                        rec[1] = ea * ba;
+                        a_kb[gq * N + pt] = (a == b) ? ea : exp(kb) * p.beta[b * N + pt];
+                    } else {
+                        rec[0] = ka;
+                        rec[1] = ba;
+                        a_kb[gq * N + pt] = kb;
+                    }
+                }
             }
             __syncthreads();
             GPMPC_TRACE(3);
-            if (wave == NW - 1) {
-                double cm = 0.0, cv = 0.0;
-                for (int idx = lane; idx < D * D; idx += 64) {
-                    const int i = idx / D, j = idx - i * D;
-                    cm = fma(s_Sig[idx], Wm[j * n + i], cm);                       // tr(Sigma W)
-                    cv = fma(2.0 * s_TS[idx], s_TS[j * D + i], cv);                // tr(2 TS TS)
-                    cv = fma(4.0 * s_v1[i] * s_Sig[idx], s_v2[j], cv);             // 4 e^T TS W e
-                }
-                for (int idx = lane; idx < n * n; idx += 64) {
-                    const int i = idx / n, j = idx - i * n;
-                    cm = fma(s_ev[i] * Wm[idx], s_ev[j], cm);                      // e^T W e
-                }
-                if (p.use_constraints && !terminal) {                               // :58-66
-                    for (int d = lane; d < D; d += 64) {
-                        const double sg = s_Sig[d * D + d];   // reference passes the VARIANCE as sigma
-                        cm += norm_cdf_ref(cost_smin[d], s_mu[d], sg) + (1.0 - norm_cdf_ref(cost_smax[d], s_mu[d], sg));
-                    }
-                }
-                cm = wave_sum(cm);
-                cv = wave_sum(cv);
-                if (lane == 0) {
-                    double ucb = -cm + p.kappa * sqrt(cv);                          // gp_mpc_controller.py:270
-                    if (p.clip) ucb = fmin(ucb, 0.0);                               // :272-274
-                    s_misc[0] -= ucb;
-                    if (p.cm_out) p.cm_out[(size_t)c * (H + 1) + t] = cm;
-                    if (p.cv_out) p.cv_out[(size_t)c * (H + 1) + t] = cv;
-                }
-            }
-        }
-        if (terminal) break;
 
-        // ---- Phase A: mean part -------------------------------------------------------
-        // A_a = Sigma + diag(l_a^2) -> A_a^-1, det  (restated B of gp_model.py:141)
-        if (tid < D) {
-            const int a = tid;
-            double* aug = s_aug + a * (D * LD);
-            double prodil = 1.0;
-            for (int i = 0; i < D; ++i) {
-                const double il2 = p.ils2[a * E + i];
-                prodil *= il2;
-                for (int j = 0; j < D; ++j) {
-                    aug[i * LD + j] = s_Sig[i * D + j] + (i == j ? 1.0 / il2 : 0.0);
-                    aug[i * LD + D + j] = (i == j ? 1.0 : 0.0);
-                }
-            }
-            const double detA = gauss_solve(aug, D, D, LD);
-            s_cc[a] = p.var[a] / sqrt(detA * prodil);            // c_a = var_a / sqrt(det B_a)  (:150)
-        }
-        __syncthreads();
-        GPMPC_TRACE(4);
-        // per point: nu, k_a, lb_a
-        for (int it = tid; it < D * N; it += NT) {
-            const int a = it / N, pt = it - a * N;
-            double nu[DP];
-#pragma unroll
-            for (int d = 0; d < DP; ++d) nu[d] = (d < D) ? (p.Xt[d * N + pt] - s_m[d]) : 0.0;
-            const double* Ai = s_aug + a * (D * LD) + D;          // A_a^-1 [i][j] at Ai[i*LD + j]
-            double q = 0.0, ks = 0.0;
-#pragma unroll
-            for (int i = 0; i < DP; ++i) {
-                if (i < D) {
-                    double r = 0.0;
-#pragma unroll
-                    for (int j = 0; j < DP; ++j)
-                        if (j < D) r = fma(Ai[i * LD + j], nu[j], r);
-                    q = fma(nu[i], r, q);
-                    ks = fma(nu[i] * nu[i], p.ils2[a * E + i], ks);
-                }
-            }
-            for (int e = D; e < E; ++e) {
-                const double v = p.Xt[e * N + pt] - s_m[e];
-                const double w2 = v * v * p.ils2[a * E + e];
-                q += w2;
-                ks += w2;
-            }
-            a_kk[it] = p.logvar[a] - 0.5 * ks;                                       // k_a  (:168)
-            a_lb[it] = exp(-0.5 * q) * p.beta[it];                                   // lb   (:148)
-            if (a == 0) {
-#pragma unroll
-                for (int d = 0; d < DP; ++d)
-                    if (d < D) a_nu[d * N + pt] = nu[d];
-            }
-        }
-        __syncthreads();
-        GPMPC_TRACE(5);
-        // s1[a][0] = sum_p lb, s1[a][1+d] = sum_p lb nu_d   (fixed order: lane-strided + butterfly)
-        for (int s = wave; s < D * (D + 1); s += NW) {
-            const int a = s / (D + 1), dd = s - a * (D + 1);
-            double v = 0.0;
-            if (dd == 0) { for (int pt = lane; pt < N; pt += 64) v += a_lb[a * N + pt]; }
-            else { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt], a_nu[(dd - 1) * N + pt], v); }
-            v = wave_sum(v);
-            if (lane == 0) s_s1[s] = v;
-        }
-        __syncthreads();
-        GPMPC_TRACE(6);
-        if (tid < D) s_M[tid] = s_cc[tid] * s_s1[tid * (D + 1)];                     // M_a (:152)
-        for (int idx = tid; idx < D * D; idx += NT) {
-            const int k = idx / D, a = idx - k * D;
-            const double* Ai = s_aug + a * (D * LD) + D;
-            double s = 0.0;
-            for (int j = 0; j < D; ++j) s = fma(Ai[k * LD + j], s_s1[a * (D + 1) + 1 + j], s);
-            s_Vs[idx] = s_cc[a] * s;                                                 // state rows of V (:153)
-        }
-        __syncthreads();
-        GPMPC_TRACE(7);
-
-        // ---- Phase B: covariance part, output pairs in groups of G ----------------------
-        for (int q0 = 0; q0 < P; q0 += G) {
-            const int Gc = (P - q0 < G) ? (P - q0) : G;
-            if (tid < Gc) {
-                const int a = s_pa[q0 + tid], b = s_pb[q0 + tid];
-                double* aug = s_aug + tid * (D * LD);
-                for (int i = 0; i < D; ++i)
-                    for (int j = 0; j < D; ++j) {
-                        const double dab = p.ils2[a * E + j] + p.ils2[b * E + j];
-                        aug[i * LD + j] = s_Sig[i * D + j] * dab + (i == j ? 1.0 : 0.0);   // R (:156-159)
-                        aug[i * LD + D + j] = s_Sig[i * D + j];
-                    }
-                const double detR = gauss_solve(aug, D, D, LD);                      // Z = R^-1 Sigma = 2Q (:163)
-                s_rdet[tid] = 1.0 / sqrt(detR);                                      // (:176)
-            }
-            if (tid == NT - 1) *s_counter = 0;
-            __syncthreads();
-            GPMPC_TRACE(8);
-            for (int it = tid; it < Gc * N; it += NT) {
-                const int gq = it / N, pt = it - gq * N;
-                const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
-                const double* Z = s_aug + gq * (D * LD) + D;
-                double u[DP], w[DP];
-#pragma unroll
-                for (int d = 0; d < DP; ++d) {
-                    const double v = (d < D) ? a_nu[d * N + pt] : 0.0;
-                    u[d] = (d < D) ? v * p.ils2[a * E + d] : 0.0;
-                    w[d] = (d < D) ? v * p.ils2[b * E + d] : 0.0;
-                }
-                double qa = 0.0, qb = 0.0;
-                double g[DP];
-#pragma unroll
-                for (int d = 0; d < DP; ++d) g[d] = 0.0;
-                double* rec = a_rows + ((size_t)gq * N + pt) * RS;
-#pragma unroll
-                for (int i = 0; i < DP; ++i) {
-                    if (i < D) {
-                        double zu = 0.0, zw = 0.0;
-#pragma unroll
-                        for (int j = 0; j < DP; ++j)
-                            if (j < D) {
-                                const double z = Z[i * LD + j];
-                                zu = fma(z, u[j], zu);
-                                zw = fma(z, w[j], zw);
-                                g[j] = fma(z, u[i], g[j]);      // g = Z^T u: cross term u^T Z w = g . w
-                            }
-                        qa = fma(u[i], zu, qa);
-                        qb = fma(w[i], zw, qb);
-                    }
-                }
-#pragma unroll
-                for (int d = 0; d < DP; ++d) rec[2 + d] = g[d];
-                rec[0] = a_kk[a * N + pt] + 0.5 * qa;
-                rec[1] = p.beta[a * N + pt];
-                a_kb[gq * N + pt] = a_kk[b * N + pt] + 0.5 * qb;
-            }
-            __syncthreads();
-            GPMPC_TRACE(9);
-            // pairwise N x N work: waves pull (pair, row chunk, 64 columns) items
-            const int total = Gc * wpp;
+            // ---- P3: work queue: pairwise items, moment sums, mean sums, stage cost ----------------
+            const int npair = Gc * wpp;
+            const int nextra = first ? D : 0;                // items 0..D-1: mean sums (pulled first)
+            const int total = nextra + npair;
             auto pull_item = [&]() -> int {
                 int pulled = 0;
                 if (lane == 0) pulled = __hip_atomic_fetch_add(s_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return __builtin_amdgcn_readfirstlane(pulled);       // wave-uniform (SGPR) work item
             };
-            for (int wi = pull_item(); wi < total; wi = pull_item()) {
-                const int gq = wi / wpp;
-                const int flat = (wi - gq * wpp) * 64 + lane;
+            for (int wq = pull_item(); wq < total; wq = pull_item()) {
+                if (wq < nextra) {
+                    // s1[a][0] = sum_p lb, s1[a][1+d] = sum_p lb nu_d  (fixed order)
+                    const int a = wq;
+                    for (int dd = 0; dd <= D; ++dd) {
+                        double v = 0.0;
+                        if (dd == 0) { for (int pt = lane; pt < N; pt += 64) v += a_lb[a * N + pt]; }
+                        else { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt], a_nu[(dd - 1) * N + pt], v); }
+                        v = wave_sum(v);
+                        if (lane == 0) s_s1[a * (D + 1) + dd] = v;
+                    }
+                    continue;
+                }
+                const int wi = wq - nextra;
+                const int gq = p.magic_wpp ? (int)__umulhi((unsigned)wi, p.magic_wpp) : wi;   // wi / wpp (magic 0: wpp == 1)
+                const int slot = wi - gq * wpp;
                 const int a = __builtin_amdgcn_readfirstlane(s_pa[q0 + gq]);
                 const int b = __builtin_amdgcn_readfirstlane(s_pb[q0 + gq]);
+                const int Kraw = __builtin_amdgcn_readfirstlane(s_K[gq]);
+                const int K = Kraw & 63;
                 const bool diag = (a == b);
+                if (Kraw & 64) {
+                    // separable evaluation: moments  G_alpha = sum_i ra_i g_i^alpha,  W_alpha = sum_j rb_j w_j^alpha
+                    const int C = p.mono_cum[K];
+                    for (int mI = slot; mI < 2 * C; mI += wpp) {
+                        const int side = mI >= C;
+                        const int al = mI - side * C;
+                        const int packed = c_monoe[al];
+                        int ex[4];
+#pragma unroll
+                        for (int d = 0; d < 4; ++d) ex[d] = (packed >> (8 * d)) & 255;
+                        double v = 0.0;
+                        for (int pt = lane; pt < N; pt += 64) {
+                            double x[DP];
+                            double wt;
+                            if (side == 0) {
+                                const double* rec = a_rows + ((size_t)gq * NR + pt) * RS;
+                                wt = rec[1];
+#pragma unroll
+                                for (int d = 0; d < DP; ++d) x[d] = rec[2 + d];
+                            } else {
+                                wt = a_kb[gq * N + pt];
+#pragma unroll
+                                for (int d = 0; d < DP; ++d) x[d] = (d < D) ? a_nu[d * N + pt] * c_ils2[b * E + d] : 0.0;
+                            }
+#pragma unroll
+                            for (int d = 0; d < (DP < 4 ? DP : 4); ++d)
+                                for (int e = 0; e < ex[d]; ++e) wt *= x[d];
+                            v += wt;
+                        }
+                        v = wave_sum(v);
+                        if (lane == 0) s_mom[(gq * 2 + side) * rnd2(CM) + al] = v;
+                    }
+                    continue;
+                }
+                const int flat = slot * 64 + lane;
                 const bool valid = flat < p.RC * N;
-                const int r = valid ? flat / N : 0;
+                const int r = valid ? (p.magic_N ? (int)__umulhi((unsigned)flat, p.magic_N) : flat) : 0;   // flat / N
                 const int j = valid ? flat - r * N : 0;
-                const int i0 = r * p.CH;
+                const int i0 = r * p.CH;                      // CH is a multiple of 4
                 int i1 = i0 + p.CH;
                 if (i1 > N) i1 = N;
                 if (diag && i1 > j + 1) i1 = j + 1;
-                const int len = valid ? (i1 - i0) : 0;
+                const int len = (valid && i1 > i0) ? (i1 - i0) : 0;
+                const int nrows = (wave_max_i32(len) + 3) & ~3;    // wave-uniform, zero padding absorbs the overshoot
                 double acc = 0.0;
-                if (len > 0) {
+                if (nrows > 0) {
                     double w[DP];
 #pragma unroll
-                    for (int d = 0; d < DP; ++d) w[d] = (d < D) ? a_nu[d * N + j] * p.ils2[b * E + d] : 0.0;
+                    for (int d = 0; d < DP; ++d) w[d] = (d < D) ? a_nu[d * N + j] * c_ils2[b * E + d] : 0.0;
                     const double kbj = a_kb[gq * N + j];
-                    const double* rec = a_rows + ((size_t)gq * N + i0) * RS;
-                    if (diag) {
-                        const double* Tp = p.Tm + ((size_t)a * N + i0) * N + j;
-                        for (int it = 0; it < len; ++it) {
-                            double arg = rec[0] + kbj;
-#pragma unroll
-                            for (int d = 0; d < DP; ++d) arg = fma(rec[2 + d], w[d], arg);
-                            acc = fma(exp(arg), *Tp, acc);
-                            rec += RS;
-                            Tp += N;
-                        }
-                        acc *= 2.0;
+                    const double* rec = a_rows + ((size_t)gq * NR + i0) * RS;
+                    const double* Tp = p.Tm + ((size_t)a * (N + kTPad) + i0) * N + j;
+                    if (K == 0) {
+                        acc = item_exp<DP>(rec, nrows, w, kbj, diag, Tp, N);
+                        acc *= diag ? 2.0 : p.beta[b * N + j];
                     } else {
-                        for (int it = 0; it < len; ++it) {
-                            double arg = rec[0] + kbj;
-#pragma unroll
-                            for (int d = 0; d < DP; ++d) arg = fma(rec[2 + d], w[d], arg);
-                            acc = fma(exp(arg), rec[1], acc);
-                            rec += RS;
-                        }
-                        acc *= p.beta[b * N + j];
+                        if (K <= 2) acc = item_taylor<DP, 2>(rec, nrows, w, diag, Tp, N);
+                        else if (K == 3) acc = item_taylor<DP, 3>(rec, nrows, w, diag, Tp, N);
+                        else if (K == 4) acc = item_taylor<DP, 4>(rec, nrows, w, diag, Tp, N);
+                        else if (K == 5) acc = item_taylor<DP, 5>(rec, nrows, w, diag, Tp, N);
+                        else if (K == 6) acc = item_taylor<DP, 6>(rec, nrows, w, diag, Tp, N);
+                        else if (K == 7) acc = item_taylor<DP, 7>(rec, nrows, w, diag, Tp, N);
+                        else if (K == 8) acc = item_taylor<DP, 8>(rec, nrows, w, diag, Tp, N);
+                        else if (K <= 10) acc = item_taylor<DP, 10>(rec, nrows, w, diag, Tp, N);
+                        else if (K <= 12) acc = item_taylor<DP, 12>(rec, nrows, w, diag, Tp, N);
+                        else acc = item_taylor<DP, 14>(rec, nrows, w, diag, Tp, N);
+                        acc *= diag ? 2.0 * kbj : kbj;
                     }
+                    acc = valid ? acc : 0.0;
                 }
                 acc = wave_sum(acc);
                 if (lane == 0) s_part[wi] = acc;
             }
             __syncthreads();
-            GPMPC_TRACE(10);
-            if (tid < Gc) {
-                double s = 0.0;
-                for (int k = 0; k < wpp; ++k) s += s_part[tid * wpp + k];
-                s_Sp[q0 + tid] = s * s_rdet[tid];
+            GPMPC_TRACE(4);
+
+            // ---- P4: per-pair totals (one wave per pair, fixed order), M and V -------------------
+            for (int gq = wave; gq < Gc; gq += NW) {
+                const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
+                const int Kraw = s_K[gq];
+                double v = 0.0;
+                if (Kraw & 64) {
+                    const int C = p.mono_cum[Kraw & 63];
+                    const double* Gm = s_mom + (gq * 2) * rnd2(CM);
+                    const double* Wm = Gm + rnd2(CM);
+                    for (int al = lane; al < C; al += 64) v = fma(Gm[al] * Wm[al], c_monow[al], v);
+                } else {
+                    for (int k = lane; k < wpp; k += 64) v += s_part[gq * wpp + k];
+                }
+                v = wave_sum(v);
+                if (lane == 0) s_Sp[q0 + gq] = v * s_rdet[gq];
+            }
+            if (first) {
+                if (tid < D) s_M[tid] = s_cc[tid] * s_s1[tid * (D + 1)];                 // M_a (:152)
+                for (int idx = tid; idx < D * D; idx += NT) {
+                    const int k = idx / D, a = idx - k * D;
+                    const double* Ai = s_aug + a * (D * LD) + D;
+                    double s = 0.0;
+                    for (int j = 0; j < D; ++j) s = fma(Ai[k * LD + j], s_s1[a * (D + 1) + 1 + j], s);
+                    s_Vs[idx] = s_cc[a] * s;                                             // state rows of V (:153)
+                }
             }
             __syncthreads();
-            GPMPC_TRACE(11);
+            GPMPC_TRACE(5);
         }
 
-        // ---- Phase C: state update  (gp_model.py:105-108, 177-178) -------------------------
+        // ---- P5: state update  (gp_model.py:105-108, 177-178) ---------------------------------
         for (int idx = tid; idx < D * D; idx += NT) {
             const int i = idx / D, j = idx - i * D;
             const int a = i < j ? i : j, b = i < j ? j : i;
             const int q = a * D - (a * (a - 1)) / 2 + (b - a);
-            double S = s_Sp[q] - s_M[i] * s_M[j] + (i == j ? p.var[i] : 0.0);
+            const double S = s_Sp[q] - s_M[i] * s_M[j] + (i == j ? c_var[i] : 0.0);
             double cij = 0.0, cji = 0.0;
             for (int k = 0; k < D; ++k) {
                 cij = fma(s_Sig[i * D + k], s_Vs[k * D + j], cij);
                 cji = fma(s_Sig[j * D + k], s_Vs[k * D + i], cji);
             }
-            s_TS[idx] = S + s_Sig[idx] + (cij + cji);   // (cij + cji) commutes: Sigma stays exactly symmetric
-        }
-        __syncthreads();
-        GPMPC_TRACE(12);
-        for (int idx = tid; idx < D * D; idx += NT) {
-            s_Sig[idx] = s_TS[idx];
-            if (p.Sig_out) p.Sig_out[((size_t)c * (H + 1) + (t + 1)) * D * D + idx] = s_TS[idx];
+            const double v = S + s_Sig[idx] + (cij + cji);   // (cij + cji) commutes: Sigma stays exactly symmetric
+            s_SigNext[idx] = v;
+            p.Sig_out[((size_t)c * (H + 1) + (t + 1)) * D * D + idx] = v;
         }
         for (int i = tid; i < D; i += NT) {
             const double v = s_mu[i] + s_M[i];
             s_mu[i] = v;
-            if (p.mu_out) p.mu_out[((size_t)c * (H + 1) + (t + 1)) * D + i] = v;
+            p.mu_out[((size_t)c * (H + 1) + (t + 1)) * D + i] = v;
         }
+        cur ^= 1;
         __syncthreads();
-        GPMPC_TRACE(13);
+        GPMPC_TRACE(6);
     }
-    __syncthreads();
-    GPMPC_TRACE(14);
-    if (tid == (NW - 1) * 64 && p.J_out) p.J_out[c] = s_misc[0] / (double)(H + 1);     // mean over H+1 (:275-276)
+#if defined(GPMPC_PROF_ON)
+    if (threadIdx.x == 0 && blockIdx.x == 0) printf("PROF wave0 small algebra cycles %lld\n", prof_acc[7]);
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        printf("PROF cycles: init %lld | P1 %lld | P2 %lld | P3 %lld | P4 %lld | P5 %lld\n", prof_acc[1], prof_acc[2],
+               prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6]);
+#endif
 }
 
 }  // namespace gpmpc_hip

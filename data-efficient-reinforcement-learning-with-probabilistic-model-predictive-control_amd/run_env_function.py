@@ -25,6 +25,8 @@ def run_env(env, control_config, visu_config=None, random_actions_init=10, num_s
         obs = obs_new
         if verbose:
             print(str(iter_info))
+    if hasattr(ctrl, "p_train") and not ctrl.p_train._closed:
+        ctrl.p_train.join()                       # do not orphan a training process at episode end
     ctrl.check_and_close_processes()
     if hasattr(env, "__exit__"):
         env.__exit__()

@@ -118,6 +118,48 @@ def test_rollout_variants_agree(engine, threads, force_global):
         engine.set_option("force_global_scratch", 0)
 
 
+@pytest.mark.parametrize("force_path", [0, 1, 2, 3])
+@pytest.mark.parametrize("name", ["traj_c1", "traj_c2", "traj_c4", "traj_c4_time", "traj_c5class", "traj_bigvar", "traj_n1_dummy"])
+def test_exp_taylor_and_separable_paths_agree_with_reference(engine, name, force_path):
+    """0 = automatic (Taylor degree from the |g.w| bound; separable moments for off-diagonal pairs when
+    D <= 4), 1 = always the direct exp(ka' + kb' + g.w) evaluation, 2 = Taylor but element-wise."""
+    g = load(name)
+    w = workload_of(g)
+    f = factors_of(w)
+    engine.set_option("force_path", force_path % 3)
+    engine.set_option("force_separable", int(force_path == 3))      # 3 = automatic degree, separable forced on
+    try:
+        engine.set_factors(w.X, f.iK, f.beta, w.lengthscales, w.outputscales)
+        _set_cost(engine, w, g)
+        out = engine.rollout(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+        _check_traj(out, g, name)
+    finally:
+        engine.set_option("force_path", 0)
+        engine.set_option("force_separable", 0)
+
+
+def test_large_input_variance_uses_high_degree_or_exp(engine):
+    """Input covariances from 1e-8 to 0.3 sweep the Taylor degree up to the exp fallback; all three
+    evaluation paths must agree with the CPU oracle."""
+    for s0 in [1e-8, 1e-4, 1e-2, 1e-1, 3e-1]:
+        w = synth.make_workload(90, 3, 1, 4, 6, seed=11, s0=s0, noise_var=1e-4)
+        f = factors_of(w)
+        ref = orc.evaluate_candidates(f, w)
+        for force_path in (0, 1, 2, 3):
+            engine.set_option("force_path", force_path % 3)
+            engine.set_option("force_separable", int(force_path == 3))
+            try:
+                engine.set_factors(w.X, f.iK, f.beta, w.lengthscales, w.outputscales)
+                _set_cost(engine, w)
+                out = engine.rollout(w.actions, w.mu0, w.S0)
+            finally:
+                engine.set_option("force_path", 0)
+                engine.set_option("force_separable", 0)
+            assert rel_err(out["mu"].cpu().numpy(), ref["mu"]) < 1e-9, (s0, force_path)
+            assert rel_err(out["Sig"].cpu().numpy(), ref["Sig"]) < 1e-7, (s0, force_path)
+            assert rel_err(out["J"].cpu().numpy(), ref["J"]) < 1e-8, (s0, force_path)
+
+
 def test_rollout_is_bitwise_reproducible(engine):
     w = synth.make_workload(120, 3, 1, 10, 64, seed=5)
     engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
