@@ -182,15 +182,25 @@ def main():
             from oracle.unfused_torch import time_rollouts
             wc = synth.make_workload(N, d, a, h, 8, include_time=tm, seed=0)
             fc = orc.Factors(wc.X, wc.Y, wc.lengthscales, wc.outputscales, wc.noises)
-            rate, dt, _ = time_rollouts(wc, 4, fc)
-            n_roll = int(min(400, max(8, args.cpu_seconds * rate)))
-            rate, dt, _ = time_rollouts(wc, n_roll, fc)
-            result["cpu_baseline"] = {"value": rate, "unit": "rollouts/s", "cores": torch.get_num_threads(),
-                                      "kind": "port",
-                                      "sample": f"{n_roll} sequential forward rollouts (same N,D,H) of oracle/unfused_torch.py "
-                                                f"(reference op sequence, (D,D,N,N) temporaries, torch fp64, default threads) "
-                                                f"in {dt:.1f} s; os.cpu_count()={os.cpu_count()}"}
-            result["speedup_vs_cpu_baseline"] = result["value"] / rate
+            # default intra-op threads (what the reference runs with) and 8 threads (a workstation-sized
+            # setting; on a many-core host the default oversubscribes these small ops); best one is `value`
+            trials = {}
+            default_threads = torch.get_num_threads()
+            for nthr in sorted({default_threads, min(8, default_threads)}):
+                torch.set_num_threads(nthr)
+                rate, dt, _ = time_rollouts(wc, 3, fc)
+                n_roll = int(min(400, max(6, 0.5 * args.cpu_seconds * rate)))
+                rate, dt, _ = time_rollouts(wc, n_roll, fc)
+                trials[nthr] = (rate, dt, n_roll)
+            torch.set_num_threads(default_threads)
+            best = max(trials, key=lambda k: trials[k][0])
+            result["cpu_baseline"] = {
+                "value": trials[best][0], "unit": "rollouts/s", "cores": best, "kind": "port",
+                "sample": "sequential forward rollouts (same N,D,H) of oracle/unfused_torch.py (reference op sequence, "
+                          "(D,D,N,N) temporaries, torch fp64): " +
+                          "; ".join(f"{k} threads: {v[2]} rollouts in {v[1]:.1f} s = {v[0]:.2f}/s" for k, v in trials.items()) +
+                          f"; os.cpu_count()={os.cpu_count()}"}
+            result["speedup_vs_cpu_baseline"] = result["value"] / trials[best][0]
         print(json.dumps(result))
     eng.close()
     if world > 1:

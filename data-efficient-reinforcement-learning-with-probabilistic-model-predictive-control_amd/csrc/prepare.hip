@@ -18,7 +18,7 @@ namespace gpmpc_hip {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int NB = 32;   // panel width
-constexpr int kTPadRows = 64;   // zero rows after every T_a (= kTPad of rollout_kernel.h)
+constexpr int kTPadRows = 72;   // zero rows after every T_a (= kTPad of rollout_kernel.h)
 
 // ------------------------------------------------------------------------------------------
 __global__ void pack_inputs_kernel(const double* __restrict__ X, const double* __restrict__ ls,

@@ -301,7 +301,7 @@ __device__ inline double taylor_exp(double c) {
     return p;
 }
 
-constexpr int kTPad = 64;      // zero rows appended to every T_a (a wave may run up to CH <= 64 rows past the data)
+constexpr int kTPad = 72;      // zero rows appended to every T_a: a wave may run CH <= 64 rows past the data and prefetches 4 more
 
 // One (pair, row-chunk, column) item of the pairwise work, Taylor form.  `nrows` is wave-uniform and a
 // multiple of 4; rows beyond the data are zero padding and T is zero below its diagonal, so the loop
@@ -318,10 +318,11 @@ __device__ inline double item_taylor(const double* rec, int nrows, const double 
 #pragma unroll
         for (int u = 0; u < U; ++u) tv[u] = Tp[(size_t)u * N];
         for (int it = 0; it < nrows; it += U) {
+            // next group's T values: in flight during this group's math (reading past the last group only
+            // touches the zero padding rows of T)
             double tn[U];
-            const bool more = it + U < nrows;                 // wave-uniform
 #pragma unroll
-            for (int u = 0; u < U; ++u) tn[u] = more ? Tp[(size_t)(U + u) * N] : 0.0;
+            for (int u = 0; u < U; ++u) tn[u] = Tp[(size_t)(U + u) * N];
             double cc[U], ev[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {

@@ -160,6 +160,37 @@ def test_large_input_variance_uses_high_degree_or_exp(engine):
             assert rel_err(out["J"].cpu().numpy(), ref["J"]) < 1e-8, (s0, force_path)
 
 
+@pytest.mark.parametrize("name", ["traj_c5class", "traj_c4_time", "traj_c2"])
+def test_large_n_variant_on_reference_goldens(engine, name):
+    """The global-scratch (large-N) variant of the kernel, forced at small N, against the reference."""
+    g = load(name)
+    w = workload_of(g)
+    f = factors_of(w)
+    engine.set_option("force_global_scratch", 1)
+    try:
+        engine.set_factors(w.X, f.iK, f.beta, w.lengthscales, w.outputscales)
+        _set_cost(engine, w, g)
+        out = engine.rollout(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+        _check_traj(out, g, name)
+    finally:
+        engine.set_option("force_global_scratch", 0)
+
+
+def test_config5_shape_class_runs_and_matches_oracle(engine):
+    """D=16, E=20 at N=1024 (needs the global-scratch variant: per-point arrays exceed LDS), 2 steps;
+    oracle on one candidate."""
+    w = synth.make_workload(1024, 16, 4, 2, 8, seed=31)
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    _set_cost(engine, w)
+    out = engine.rollout(w.actions, w.mu0, w.S0)
+    f = factors_of(w)
+    assert rel_err(engine.factors()[1].cpu().numpy(), f.beta) < 1e-7
+    ref = orc.evaluate_candidates(f, w, actions=w.actions[:1])
+    assert rel_err(out["mu"].cpu().numpy()[:1], ref["mu"]) < 1e-8
+    assert rel_err(out["Sig"].cpu().numpy()[:1], ref["Sig"]) < 1e-5
+    assert rel_err(out["J"].cpu().numpy()[:1], ref["J"]) < 1e-7
+
+
 def test_rollout_is_bitwise_reproducible(engine):
     w = synth.make_workload(120, 3, 1, 10, 64, seed=5)
     engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
