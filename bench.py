@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--candidates-per-gpu", type=int, default=0, help="override B per GPU")
     ap.add_argument("--points", type=int, default=0, help="override N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (exercises the N > 1 code path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -63,8 +64,9 @@ def main():
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import gp_mpc_amd
@@ -108,17 +110,18 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    use_dist = dist.is_initialized()
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         (best_J, best_i, best_act), out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -203,7 +206,7 @@ def main():
             result["speedup_vs_cpu_baseline"] = result["value"] / trials[best][0]
         print(json.dumps(result))
     eng.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -101,15 +101,16 @@ __global__ __launch_bounds__(NB * NB) void potrf_diag_kernel(double* __restrict_
         __syncthreads();
     }
     if (in && c <= r) K[(size_t)(k0 + r) * N + (k0 + c)] = s[r][c];
-    // inverse of the lower-triangular block: thread column c solves L y = e_c
-    if (r == 0 && c < nb) {
-        for (int i = 0; i < nb; ++i) {
-            double v = (i == c) ? 1.0 : 0.0;
-            for (int m = c; m < i; ++m) v -= s[i][m] * y[m][c];
-            y[i][c] = (i < c) ? 0.0 : v / s[i][i];
-        }
-    }
+    // inverse of the lower-triangular block by forward substitution on the identity, one row of Y per
+    // step, the whole nb x nb thread grid applying the rank-1 update (depth nb instead of nb^2 / 2)
+    y[r][c] = (r == c) ? 1.0 : 0.0;
     __syncthreads();
+    for (int k = 0; k < nb; ++k) {
+        if (r == k && c <= k) y[k][c] /= s[k][k];
+        __syncthreads();
+        if (in && r > k && c <= k) y[r][c] -= s[r][k] * y[k][c];
+        __syncthreads();
+    }
     if (in) Y[(size_t)(k0 + r) * N + (k0 + c)] = (c <= r) ? y[r][c] : 0.0;
 }
 
@@ -230,9 +231,17 @@ __global__ __launch_bounds__(256) void beta_kernel(const double* __restrict__ Ya
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= N) return;
     const double* Y = Yall + (size_t)a * N * N;
-    double s = 0.0;
-    for (int p = i; p < N; ++p) s = fma(Y[(size_t)p * N + i], z[(size_t)a * N + p], s);
-    beta[(size_t)a * N + i] = s;
+    // four independent partial sums keep several loads in flight (fixed order: reproducible)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int p = i;
+    for (; p + 3 < N; p += 4) {
+        s0 = fma(Y[(size_t)p * N + i], z[(size_t)a * N + p], s0);
+        s1 = fma(Y[(size_t)(p + 1) * N + i], z[(size_t)a * N + p + 1], s1);
+        s2 = fma(Y[(size_t)(p + 2) * N + i], z[(size_t)a * N + p + 2], s2);
+        s3 = fma(Y[(size_t)(p + 3) * N + i], z[(size_t)a * N + p + 3], s3);
+    }
+    for (; p < N; ++p) s0 = fma(Y[(size_t)p * N + i], z[(size_t)a * N + p], s0);
+    beta[(size_t)a * N + i] = (s0 + s1) + (s2 + s3);
 }
 
 // iK = Y^T Y on lower-triangular 32x32 blocks (mirrored on store), plus T = beta beta^T - iK
