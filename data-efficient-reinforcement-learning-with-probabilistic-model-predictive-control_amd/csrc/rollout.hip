@@ -177,14 +177,11 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     const int DP = padded_dim(D);
     if (DP < 0) { h->err = "D exceeds GPMPC_MAX_D"; return GPMPC_ERR_LIMIT; }
 
-    // workgroup size: one candidate per workgroup; 16 waves when the batch does not
-    // oversubscribe the 256 CUs, fewer (more workgroups per CU) when it does.
+    // workgroup size: one candidate per workgroup.  Measured on MI355X (config 2..4 shapes, B = 256..2048):
+    // 16 waves per candidate beat 8 even when the batch oversubscribes the 256 CUs (340k vs 265k
+    // rollouts/s at B = 2048), so 1024 threads unless asked otherwise.
     int nt = h->opt_threads;
-    if (nt != 256 && nt != 512 && nt != 1024) {
-        if (a.B <= h->num_cu) nt = 1024;
-        else if (a.B <= 2 * h->num_cu) nt = 512;
-        else nt = (N >= 128) ? 512 : 256;
-    }
+    if (nt != 256 && nt != 512 && nt != 1024) nt = 1024;
     const int nw = nt / 64;
     int rcm = ensure_monomials(h, D);
     if (rcm) return rcm;
@@ -201,9 +198,12 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     int G = 0, CH = 0, RC = 0;
     size_t lds_bytes = 0;
     auto chunking = [&](int g) {
-        // aim for ~8 wave items per wave and group, chunks of at least 16 rows
-        long long want = 5LL * nw * 64;
+        // row chunks of up to 64 rows (fewer, longer items amortise the per-item prologue: 0.76 vs 0.80 ms at
+        // config 2), but at least ~2 items per wave so that the queue can balance
+        long long want = 2LL * nw * 64;
         long long rc = (want + (long long)g * N - 1) / ((long long)g * N);
+        const long long rc64 = (N + 63) / 64;
+        if (rc < rc64) rc = rc64;
         int maxrc = (N + 15) / 16;
         if (rc > maxrc) rc = maxrc;
         if (rc < 1) rc = 1;
