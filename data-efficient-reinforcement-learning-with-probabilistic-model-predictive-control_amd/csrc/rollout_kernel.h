@@ -54,7 +54,7 @@ constexpr int kMaxMono = 256;      // most monomials of the separable (off-diago
 // LDS / scratch layout (offsets in doubles), shared by host (sizing) and device (carving).
 struct Layout {
     int mu, Sig, m, M, cc, s1, Vs, Sp, TS, v1, v2, ev, misc, rdet, aug, part, mom, ints;
-    int c_ils2, c_logvar, c_var, c_xr, c_act, c_monow, c_monoe;    // read-only tables copied to LDS once
+    int c_ils2, c_logvar, c_var, c_xr, c_act, c_exptab, c_monow, c_monoe;    // read-only tables copied to LDS once
     int lds_total;     // doubles of LDS
     // per-point arrays: in LDS (offsets from smem) or in global scratch (offsets from base)
     int nu, lb, rows, kb;
@@ -91,6 +91,7 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     L.c_var = o;    o += rnd2(D);
     L.c_xr = o;     o += rnd2(2 * E);
     L.c_act = o;    o += rnd2(HA);
+    L.c_exptab = o; o += 64;
     L.c_monow = o;  o += rnd2(CM);
     L.c_monoe = o;  o += rnd2((CM + 1) / 2);           // packed exponents, one int per monomial
     int q = global_scratch ? 0 : o;
@@ -360,12 +361,47 @@ __device__ inline double item_taylor(const double* rec, int nrows, const double 
     return acc;
 }
 
+// exp(x) for the direct (fallback) evaluation: x = (64 m + j) ln2/64 + r, |r| <= ln2/128,
+// exp(x) = 2^m * 2^(j/64) * (1 + r + r^2/2 + ... + r^5/120); 2^(j/64) from a 64-entry table, truncation
+// 3.5e-17, total error ~1 ulp.  No overflow/underflow special-casing: arguments on this path are sums of
+// log-kernel terms (<= a few units), and ldexp flushes tiny results to zero like exp does.
+__device__ const double kExp2Tab[64] = {
+    0x1.0000000000000p+0, 0x1.02c9a3e778061p+0, 0x1.059b0d3158574p+0, 0x1.0874518759bc8p+0,
+    0x1.0b5586cf9890fp+0, 0x1.0e3ec32d3d1a2p+0, 0x1.11301d0125b51p+0, 0x1.1429aaea92de0p+0,
+    0x1.172b83c7d517bp+0, 0x1.1a35beb6fcb75p+0, 0x1.1d4873168b9aap+0, 0x1.2063b88628cd6p+0,
+    0x1.2387a6e756238p+0, 0x1.26b4565e27cddp+0, 0x1.29e9df51fdee1p+0, 0x1.2d285a6e4030bp+0,
+    0x1.306fe0a31b715p+0, 0x1.33c08b26416ffp+0, 0x1.371a7373aa9cbp+0, 0x1.3a7db34e59ff7p+0,
+    0x1.3dea64c123422p+0, 0x1.4160a21f72e2ap+0, 0x1.44e086061892dp+0, 0x1.486a2b5c13cd0p+0,
+    0x1.4bfdad5362a27p+0, 0x1.4f9b2769d2ca7p+0, 0x1.5342b569d4f82p+0, 0x1.56f4736b527dap+0,
+    0x1.5ab07dd485429p+0, 0x1.5e76f15ad2148p+0, 0x1.6247eb03a5585p+0, 0x1.6623882552225p+0,
+    0x1.6a09e667f3bcdp+0, 0x1.6dfb23c651a2fp+0, 0x1.71f75e8ec5f74p+0, 0x1.75feb564267c9p+0,
+    0x1.7a11473eb0187p+0, 0x1.7e2f336cf4e62p+0, 0x1.82589994cce13p+0, 0x1.868d99b4492edp+0,
+    0x1.8ace5422aa0dbp+0, 0x1.8f1ae99157736p+0, 0x1.93737b0cdc5e5p+0, 0x1.97d829fde4e50p+0,
+    0x1.9c49182a3f090p+0, 0x1.a0c667b5de565p+0, 0x1.a5503b23e255dp+0, 0x1.a9e6b5579fdbfp+0,
+    0x1.ae89f995ad3adp+0, 0x1.b33a2b84f15fbp+0, 0x1.b7f76f2fb5e47p+0, 0x1.bcc1e904bc1d2p+0,
+    0x1.c199bdd85529cp+0, 0x1.c67f12e57d14bp+0, 0x1.cb720dcef9069p+0, 0x1.d072d4a07897cp+0,
+    0x1.d5818dcfba487p+0, 0x1.da9e603db3285p+0, 0x1.dfc97337b9b5fp+0, 0x1.e502ee78b3ff6p+0,
+    0x1.ea4afa2a490dap+0, 0x1.efa1bee615a27p+0, 0x1.f50765b6e4540p+0, 0x1.fa7c1819e90d8p+0};
+
+__device__ inline double fast_exp(double x, const double* tab /* kExp2Tab copied to LDS */) {
+    const double n = __builtin_rint(x * 0x1.71547652b82fep+6);
+    double r = fma(n, -0x1.62e42fefa0000p-7, x);
+    r = fma(n, -0x1.cf79abc9e3b3ap-46, r);
+    const int ni = (int)n;
+    const double t = tab[ni & 63];
+    double q = fma(r, 0x1.1111111111111p-7, 0x1.5555555555555p-5);     // 1/120, 1/24
+    q = fma(q, r, 0x1.5555555555555p-3);                                 // 1/6
+    q = fma(q, r, 0.5);
+    const double p = fma(q * r, r, r);                                    // e^r - 1
+    return ldexp(fma(t, p, t), ni >> 6);
+}
+
 // Same item, direct form exp(ka'_i + kb'_j + g_i . w_j)  (row record [0] = ka'_i, [1] = beta_ai).
 template <int DP>
 __device__ inline double item_exp(const double* rec, int nrows, const double (&w)[DP], double kbj, bool diag,
-                                  const double* Tp, int N) {
+                                  const double* Tp, int N, const double* tab) {
     constexpr int RS = DP + 2;
-    constexpr int U = 2;
+    constexpr int U = 4;
     double acc = 0.0;
     if (diag) {
         for (int it = 0; it < nrows; it += U) {
@@ -381,7 +417,7 @@ __device__ inline double item_exp(const double* rec, int nrows, const double (&w
                 aa[u] = arg;
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc = fma(exp(aa[u]), tv[u], acc);
+            for (int u = 0; u < U; ++u) acc = fma(fast_exp(aa[u], tab), tv[u], acc);
             rec += U * RS;
             Tp += (size_t)U * N;
         }
@@ -398,7 +434,7 @@ __device__ inline double item_exp(const double* rec, int nrows, const double (&w
                 bv[u] = r[1];
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) acc = fma(exp(aa[u]), bv[u], acc);
+            for (int u = 0; u < U; ++u) acc = fma(fast_exp(aa[u], tab), bv[u], acc);
             rec += U * RS;
         }
     }
@@ -470,6 +506,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     double* c_var = smem + L.c_var;
     double* c_xr = smem + L.c_xr;
     double* c_act = smem + L.c_act;
+    double* c_exptab = smem + L.c_exptab;
     double* c_monow = smem + L.c_monow;
     int* c_monoe = reinterpret_cast<int*>(smem + L.c_monoe);
     const double* act = p.actions + (size_t)c * H * A;
@@ -485,6 +522,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
     for (int i = tid; i < 2 * E; i += NT) c_xr[i] = p.xrange[i];
     for (int i = tid; i < H * A; i += NT) c_act[i] = act[i];
+    for (int i = tid; i < 64; i += NT) c_exptab[i] = kExp2Tab[i];
     for (int i = tid; i < CM; i += NT) {
         c_monow[i] = p.mono_w[i];
         c_monoe[i] = p.mono_exp[i * 4] | (p.mono_exp[i * 4 + 1] << 8) | (p.mono_exp[i * 4 + 2] << 16) | (p.mono_exp[i * 4 + 3] << 24);
@@ -821,7 +859,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     const double* rec = a_rows + ((size_t)gq * NR + i0) * RS;
                     const double* Tp = p.Tm + ((size_t)a * (N + kTPad) + i0) * N + j;
                     if (K == 0) {
-                        acc = item_exp<DP>(rec, nrows, w, kbj, diag, Tp, N);
+                        acc = item_exp<DP>(rec, nrows, w, kbj, diag, Tp, N, c_exptab);
                         acc *= diag ? 2.0 : p.beta[b * N + j];
                     } else {
                         if (K <= 2) acc = item_taylor<DP, 2>(rec, nrows, w, diag, Tp, N);

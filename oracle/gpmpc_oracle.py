@@ -28,10 +28,17 @@ def rbf_ard_gram(X, lengthscales, outputscales):
 
     X (N,E), lengthscales (D,E), outputscales (D,) -> K (D,N,N) without noise.
     """
-    Xs = X[None, :, :] / lengthscales[:, None, :]                 # (D,N,E)
-    diff = Xs[:, :, None, :] - Xs[:, None, :, :]                  # (D,N,N,E)
-    sq = np.sum(diff * diff, axis=-1)
-    return outputscales[:, None, None] * np.exp(-0.5 * sq)
+    D, E = lengthscales.shape
+    N = X.shape[0]
+    K = np.empty((D, N, N))
+    for a in range(D):                                            # one (N,N) temporary at a time
+        sq = np.zeros((N, N))
+        for e in range(E):
+            xe = X[:, e] / lengthscales[a, e]
+            d = xe[:, None] - xe[None, :]
+            sq += d * d
+        K[a] = outputscales[a] * np.exp(-0.5 * sq)
+    return K
 
 
 def factorize(X, Y, lengthscales, outputscales, noises, K=None):
