@@ -191,6 +191,31 @@ def test_config5_shape_class_runs_and_matches_oracle(engine):
     assert rel_err(out["J"].cpu().numpy()[:1], ref["J"]) < 1e-7
 
 
+@pytest.mark.parametrize("N,D,A,H,B,tm", [(70, 1, 1, 4, 3, False), (60, 5, 2, 3, 3, False), (48, 7, 1, 3, 2, True),
+                                          (40, 3, 1, 1, 1, False), (33, 12, 3, 2, 2, False)])
+def test_padded_and_odd_shapes_against_oracle(engine, N, D, A, H, B, tm):
+    """State dimensions that are not compiled exactly run on the next padded size (D=1->2, 5->6, 7->8,
+    12->16, runtime D < DP); plus H = 1, B = 1 and a time input."""
+    w = synth.make_workload(N, D, A, H, B, include_time=tm, seed=100 + D, time0=float(N) if tm else 0.0)
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    _set_cost(engine, w)
+    f = factors_of(w)
+    ref = orc.evaluate_candidates(f, w)
+    for force_path in (0, 1):
+        engine.set_option("force_path", force_path)
+        try:
+            out = engine.rollout(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+        finally:
+            engine.set_option("force_path", 0)
+        assert rel_err(out["mu"].cpu().numpy(), ref["mu"]) < 1e-9, force_path
+        # covariances: 1e-7 relative on top of the 1e-11 absolute cancellation floor of the method
+        dS = np.max(np.abs(out["Sig"].cpu().numpy() - ref["Sig"]))
+        assert dS < 1e-7 * np.max(np.abs(ref["Sig"])) + 2e-11, (force_path, dS)
+        assert rel_err(out["cost_mu"].cpu().numpy(), ref["cost_mu"]) < 1e-9, force_path
+        assert rel_err(out["cost_var"].cpu().numpy(), ref["cost_var"]) < 1e-5, force_path
+        assert rel_err(out["J"].cpu().numpy(), ref["J"]) < 1e-8, force_path
+
+
 def test_rollout_is_bitwise_reproducible(engine):
     w = synth.make_workload(120, 3, 1, 10, 64, seed=5)
     engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
