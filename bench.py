@@ -101,12 +101,11 @@ def main():
         tp.append(time.perf_counter() - t0)
     prepare_ms = float(np.median(tp) * 1e3)
 
-    def step():
-        out = eng.rollout(actions, w.mu0, w.S0, w.include_time, w.time0)
+    bufs = {"out": None}
 
-        def ev(_):
-            return eng.argmin(out["J"], first_global_index=lo)
-        return sharding.sharded_argmin(ev, actions, lo, B_total, device), out
+    def step():
+        out = bufs["out"] = eng.rollout(actions, w.mu0, w.S0, w.include_time, w.time0, out=bufs["out"])
+        return sharding.select_best_on_device(eng, out["J"], actions, lo, B_total), out
 
     for _ in range(args.warmup):
         step()

@@ -233,13 +233,12 @@ class GpMpcController(BaseControllerObject):
         out = self.evaluate_candidates(cands[lo:hi], state_mu, state_var, trajectories=True)
         eng = self.transition_model.engine
         local = torch.as_tensor(cands[lo:hi].reshape(hi - lo, H, A), device=eng.device)
-        J, best, win = sharding.sharded_argmin(lambda _: eng.argmin(out["J"], first_global_index=lo),
-                                               local, lo, B, eng.device)
+        J, best, win = sharding.select_best_on_device(eng, out["J"], local, lo, B)
         # the reference caches the LAST evaluated trajectory, not the winner's (:279-283)
         if world == 1 or rank == world - 1:
             self._cache_trajectory(out, hi - lo - 1)
         self.best_candidate_index, self.best_candidate_J = best, J
-        self.actions_mpc_previous_iter = win.cpu().numpy().reshape(-1).copy()
+        self.actions_mpc_previous_iter = win.numpy().reshape(-1).copy()
         return self.actions_mapper.transform_action_mpc_to_action_model(self.actions_mpc_previous_iter)
 
     def _get_random_actions(self, state_mu, state_var):

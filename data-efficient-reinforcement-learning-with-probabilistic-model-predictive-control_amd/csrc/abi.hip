@@ -25,7 +25,7 @@ static void free_buf(Buf& b) {
 
 extern "C" {
 
-int gpmpc_abi_version(void) { return 2; }
+int gpmpc_abi_version(void) { return 4; }
 
 int gpmpc_create(gpmpc_t** out, int device_id) {
     if (!out) return GPMPC_ERR_ARG;
@@ -219,6 +219,14 @@ int gpmpc_argmin(gpmpc_t* g, const double* J, int B, long long first, double* be
     if (best_J) *best_J = out[0];
     if (best_idx) memcpy(best_idx, &out[1], sizeof(long long));
     return GPMPC_OK;
+}
+
+int gpmpc_argmin_async(gpmpc_t* g, const double* J, int B, long long first, const double* actions, int HA, double* out_dev,
+                       void* stream) {
+    if (!g || !J || !out_dev || B < 1 || first < 0 || HA < 0) return bad(g, "bad argument");
+    Handle* h = H_(g);
+    GPMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    return launch_argmin_to(h, J, B, first, actions, HA, out_dev, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -125,6 +125,8 @@ struct Handle {
 // rollout.hip
 int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s);
 int launch_argmin(Handle* h, const double* J, int B, long long first, hipStream_t s);
+int launch_argmin_to(Handle* h, const double* J, int B, long long first, const double* actions, int HA, double* out_dev,
+                     hipStream_t s);
 // prepare.hip
 int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, const double* os,
                 const double* noise, int N, int D, int E, hipStream_t s);

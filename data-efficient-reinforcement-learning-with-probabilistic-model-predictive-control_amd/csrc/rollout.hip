@@ -81,7 +81,9 @@ __global__ __launch_bounds__(64) void traj_cost_kernel(const double* __restrict_
 
 // ------------------------------------------------------------------------------------------
 // Keep-the-best rule of gp_mpc_controller.py:146-148 over a vector (single workgroup).
-__global__ __launch_bounds__(1024) void argmin_kernel(const double* J, int B, long long first, double* out) {
+__global__ __launch_bounds__(1024) void argmin_kernel(const double* J, int B, long long first, double* out, int index_as_double,
+                                                     const double* actions, int HA) {
+    __shared__ long long s_best;
     __shared__ double s_v[16];
     __shared__ long long s_i[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -107,14 +109,29 @@ __global__ __launch_bounds__(1024) void argmin_kernel(const double* J, int B, lo
         if (first == 0 && B > 0 && J[0] != J[0]) { bv = J[0]; bi = 0; }   // NaN in global slot 0 is adopted and stays
         if (bi < 0) bv = INFINITY;                              // nothing selectable in this shard
         out[0] = bv;
-        reinterpret_cast<long long*>(out)[1] = (bi < 0) ? -1 : bi + first;
+        const long long gi = (bi < 0) ? -1 : bi + first;
+        if (index_as_double) out[1] = (double)gi;
+        else reinterpret_cast<long long*>(out)[1] = gi;
+        s_best = bi < 0 ? 0 : bi;
     }
+    if (actions) {                      // append the winner's action sequence to the record
+        __syncthreads();
+        const long long w = s_best;
+        for (int k = tid; k < HA; k += 1024) out[2 + k] = actions[w * HA + k];
+    }
+}
+
+int launch_argmin_to(Handle* h, const double* J, int B, long long first, const double* actions, int HA, double* out_dev,
+                     hipStream_t s) {
+    hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, J, B, first, out_dev, 1, actions, HA);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    return GPMPC_OK;
 }
 
 int launch_argmin(Handle* h, const double* J, int B, long long first, hipStream_t s) {
     int rc = grow(h, h->best, 2);
     if (rc) return rc;
-    hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, J, B, first, h->best.p);
+    hipLaunchKernelGGL(argmin_kernel, dim3(1), dim3(1024), 0, s, J, B, first, h->best.p, 0, (const double*)nullptr, 0);
     GPMPC_HIP_CHECK(h, hipGetLastError());
     return GPMPC_OK;
 }

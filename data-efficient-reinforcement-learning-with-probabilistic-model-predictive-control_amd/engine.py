@@ -120,20 +120,24 @@ class HipEngine:
         self._cost = (D, A)
 
     # -- a3-a5 -------------------------------------------------------------------------
-    def rollout(self, actions, mu0, S0, include_time=False, time0=0.0, trajectories=True, stage_costs=True):
-        """actions (B,H,A) -> dict(J (B,), [mu (B,H+1,D), Sig (B,H+1,D,D)], [cost_mu, cost_var (B,H+1)])."""
+    def rollout(self, actions, mu0, S0, include_time=False, time0=0.0, trajectories=True, stage_costs=True, out=None):
+        """actions (B,H,A) -> dict(J (B,), [mu (B,H+1,D), Sig (B,H+1,D,D)], [cost_mu, cost_var (B,H+1)]).
+        `out` = the dict of a previous call with the same shapes: its tensors are overwritten (no allocation)."""
         actions = self._dev(actions)
         B, H, A = actions.shape
         D = self.D
         mu0 = _host(mu0, (D,))
         S0 = _host(S0, (D, D))
-        out = {"J": torch.empty(B, dtype=torch.float64, device=self.device)}
-        if trajectories:
-            out["mu"] = torch.empty((B, H + 1, D), dtype=torch.float64, device=self.device)
-            out["Sig"] = torch.empty((B, H + 1, D, D), dtype=torch.float64, device=self.device)
-        if stage_costs:
-            out["cost_mu"] = torch.empty((B, H + 1), dtype=torch.float64, device=self.device)
-            out["cost_var"] = torch.empty((B, H + 1), dtype=torch.float64, device=self.device)
+        if out is None:
+            out = {"J": torch.empty(B, dtype=torch.float64, device=self.device)}
+            if trajectories:
+                out["mu"] = torch.empty((B, H + 1, D), dtype=torch.float64, device=self.device)
+                out["Sig"] = torch.empty((B, H + 1, D, D), dtype=torch.float64, device=self.device)
+            if stage_costs:
+                out["cost_mu"] = torch.empty((B, H + 1), dtype=torch.float64, device=self.device)
+                out["cost_var"] = torch.empty((B, H + 1), dtype=torch.float64, device=self.device)
+        elif out["J"].shape != (B,) or ("mu" in out and out["mu"].shape != (B, H + 1, D)):
+            raise ValueError("`out` does not match the batch shape")
 
         def ptr(k):
             return out[k].data_ptr() if k in out else None
@@ -156,6 +160,18 @@ class HipEngine:
         return float(ms.value), J
 
     # -- a8 ----------------------------------------------------------------------------
+    def argmin_async(self, J, first_global_index=0, actions=None, out=None):
+        """Device-side keep-the-best, no host synchronisation: returns the device record
+        [best J, global index as double (-1: none), winning action sequence (H*A values, if `actions` given)]."""
+        J = self._dev(J)
+        ha = 0 if actions is None else int(actions[0].numel())
+        if out is None:
+            out = torch.empty(2 + ha, dtype=torch.float64, device=self.device)
+        self._check(self.lib.gpmpc_argmin_async(self._h, J.data_ptr(), J.numel(), int(first_global_index),
+                                                None if actions is None else actions.data_ptr(), ha,
+                                                out.data_ptr(), self._stream()))
+        return out
+
     def argmin(self, J, first_global_index=0):
         """Keep-the-best rule over J; returns (best_J, GLOBAL index) -- index -1 if nothing selectable."""
         J = self._dev(J)

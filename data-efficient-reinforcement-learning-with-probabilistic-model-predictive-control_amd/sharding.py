@@ -81,3 +81,24 @@ def sharded_argmin(evaluate_slice, actions_local, lo, num_candidates, device, gr
     src = dist.get_global_rank(group, owner) if group is not None else owner
     dist.broadcast(win, src=src, group=group)
     return J, i, win
+
+
+def select_best_on_device(engine, J, actions_local, lo, num_candidates, group=None):
+    """Device-resident variant of sharded_argmin for the HIP engine: local keep-the-best on the GPU
+    (gpmpc_argmin_async), the record [J, global index, winning (H*A) sequence] packed on the device, ONE
+    RCCL all_gather of 16 + 8*H*A bytes per rank, one device-to-host copy, the cross-rank rule applied on
+    the host.  Returns (best_J, best_index, best_actions (H, A) host tensor)."""
+    n, H, A = actions_local.shape
+    rec = engine.argmin_async(J, first_global_index=lo, actions=actions_local)     # one kernel: rule + gather
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        flat = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)
+        dist.all_gather_into_tensor(flat, rec, group=group)
+    else:
+        world, flat = 1, rec
+    host = flat.cpu().view(world, rec.numel())
+    bJ, bi = combine_best([(float(host[r, 0]), int(host[r, 1])) for r in range(world)])
+    if bi < 0:
+        raise FloatingPointError("no selectable candidate (all objectives NaN)")
+    owner = [r for r in range(world) if int(host[r, 1]) == bi][0]
+    return bJ, bi, host[owner, 2:].view(H, A).clone()

@@ -132,6 +132,13 @@ int gpmpc_rollout(gpmpc_t* h, const double* actions_dev, const double* mu0_host,
 int gpmpc_argmin(gpmpc_t* h, const double* J_dev, int B, long long first_global_index,
                  double* best_J_host, long long* best_idx_host, void* stream);
 
+/* Asynchronous form of gpmpc_argmin for the multi-GPU path: same rule, no host synchronisation; writes
+ * the record out_dev[0] = best J, out_dev[1] = (double) global index (-1.0 if nothing selectable) and, when
+ * actions_dev (B, HA) is given, out_dev[2 .. 2+HA) = the winning action sequence, on `stream` -- ready to
+ * be all-gathered over RCCL as is. */
+int gpmpc_argmin_async(gpmpc_t* h, const double* J_dev, int B, long long first_global_index,
+                       const double* actions_dev, int HA, double* out_dev, void* stream);
+
 /* Kernel-only timing helper for bench.py: runs `reps` rollouts back to back on `stream`
  * bracketed by HIP events recorded on THAT stream and returns the average milliseconds
  * per launch in *ms_host (outputs as gpmpc_rollout; synchronises). */

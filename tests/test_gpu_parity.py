@@ -216,6 +216,22 @@ def test_padded_and_odd_shapes_against_oracle(engine, N, D, A, H, B, tm):
         assert rel_err(out["J"].cpu().numpy(), ref["J"]) < 1e-8, force_path
 
 
+def test_config5_full_size_step_against_oracle_fixture(engine):
+    """BASELINE configs[4] at full size (N=4096, D=16, A=4, E=20): K build + factorisation + one
+    moment-matched step for 2 candidates vs tests/golden/oracle_c5_step.npz (CPU oracle, tools/gen_golden_c5.py;
+    the reference formulation cannot run this size)."""
+    g = load("oracle_c5_step")
+    w = synth.make_workload(int(g["N"]), int(g["D"]), int(g["A"]), int(g["H"]), int(g["B"]), seed=int(g["seed"]))
+    assert np.allclose([w.X.sum(), w.Y.sum(), w.actions.sum()], g["x_checksum"], rtol=0, atol=1e-9)   # same inputs
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    assert rel_err(engine.factors()[1].cpu().numpy()[:, :64], g["beta_head"]) < 1e-6
+    _set_cost(engine, w)
+    out = engine.rollout(w.actions, w.mu0, w.S0)
+    assert rel_err(out["mu"].cpu().numpy(), g["mu"]) < 1e-8
+    assert rel_err(out["Sig"].cpu().numpy(), g["Sig"]) < 1e-5
+    assert rel_err(out["J"].cpu().numpy(), g["J"]) < 1e-7
+
+
 def test_rollout_is_bitwise_reproducible(engine):
     w = synth.make_workload(120, 3, 1, 10, 64, seed=5)
     engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
@@ -246,6 +262,22 @@ def test_argmin_trace_matches_reference(engine):
     best_J, best = engine.argmin(out["J"])
     assert np.array_equal(g["cand_actions"][best], g["best_actions"])
     assert best_J == out["J"].cpu().numpy()[best]
+
+
+def test_device_side_winner_selection(engine):
+    """gpmpc_argmin_async + packed record == the synchronous argmin (single rank)."""
+    import torch
+    from gp_mpc_amd import sharding
+    rng = np.random.default_rng(3)
+    J = rng.uniform(size=300)
+    J[[41, 250]] = J.min() - 1.0
+    acts = torch.as_tensor(rng.uniform(size=(300, 5, 2)), device=engine.device)
+    bJ, bi, win = sharding.select_best_on_device(engine, torch.as_tensor(J, device=engine.device), acts, lo=1000, num_candidates=5000)
+    assert bi == 1041 and bJ == J[41] and np.array_equal(win.numpy(), acts[41].cpu().numpy())
+    assert engine.argmin(J, first_global_index=1000) == (J[41], 1041)
+    Jn = J.copy(); Jn[0] = np.nan
+    assert sharding.select_best_on_device(engine, torch.as_tensor(Jn, device=engine.device), acts, 0, 300)[1] == 0
+    assert sharding.select_best_on_device(engine, torch.as_tensor(Jn, device=engine.device), acts, 7, 300)[1] == 48
 
 
 def test_argmin_rule(engine):
