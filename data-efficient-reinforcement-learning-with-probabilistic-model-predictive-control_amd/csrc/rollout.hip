@@ -1,6 +1,6 @@
 // rollout.hip -- host-side dispatch of the rollout kernel (tiling choice, LDS sizing) and the
 // argmin kernel.  The kernel itself lives in rollout_kernel.h / rollout_dp.hip.
-#include "rollout_kernel.h"
+#include "rollout_stream_kernel.h"
 
 namespace gpmpc_hip {
 
@@ -240,23 +240,14 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         if (G == 0) gs = true;
     }
     if (gs) {
-        // large-N variant: per-point arrays in per-candidate global scratch (L2 resident),
-        // small algebra in LDS
-        for (int g = (P < 16 ? P : 16); g >= 1; --g) {
-            chunking(g);
-            const int wpp = (RC * N + 63) / 64;
-            Layout L = make_layout(N, D, A, E, g, DP, wpp, CM, CH, a.H * A, true);
-            if ((size_t)L.lds_total * 8 <= (size_t)h->lds_limit) {
-                G = g; lds_bytes = (size_t)L.lds_total * 8;
-                const size_t need = (size_t)L.pp_total * a.B;
-                int rc = grow(h, h->scratch, need);
-                if (rc) return rc;
-                a.scratch = h->scratch.p;
-                a.scratch_stride = (size_t)L.pp_total;
-                break;
-            }
-        }
-        if (G == 0) { h->err = "rollout: problem does not fit LDS even with global scratch"; return GPMPC_ERR_LIMIT; }
+        // large-N variant (rollout_stream_kernel.h): column factors + a double-buffered 64-row stage in LDS
+        CH = (N >= 64) ? 64 : ((N + 3) & ~3);
+        RC = (N + CH - 1) / CH;
+        G = 1;
+        StreamLayout SL = make_stream_layout(N, D, A, E, DP, CH, a.H * A);
+        lds_bytes = (size_t)SL.total * 8;
+        if (lds_bytes > (size_t)h->lds_limit) { h->err = "rollout: N too large for the LDS column-factor array"; return GPMPC_ERR_LIMIT; }
+        nt = 1024;
     }
     a.G = G; a.CH = CH; a.RC = RC;
     {

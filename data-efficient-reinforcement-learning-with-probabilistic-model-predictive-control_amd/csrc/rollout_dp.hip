@@ -1,6 +1,6 @@
 // rollout_dp.hip -- one translation unit per padded state dimension (compiled with
 // -DGPMPC_DP=<n>) so that the template instantiations build in parallel.
-#include "rollout_kernel.h"
+#include "rollout_stream_kernel.h"
 
 #ifndef GPMPC_DP
 #error "compile with -DGPMPC_DP=<padded state dimension>"
@@ -11,9 +11,21 @@ namespace gpmpc_hip {
 // ------------------------------------------------------------------------------------------
 template <int DP, int NT>
 static int launch_variant(Handle* h, RolloutArgs& a, bool global_scratch, size_t lds_bytes, hipStream_t s) {
-    const bool exact = (a.D == DP) && !global_scratch;
-    auto kern = global_scratch ? rollout_kernel<DP, NT, true, 0>
-                               : (exact ? rollout_kernel<DP, NT, false, DP> : rollout_kernel<DP, NT, false, 0>);
+    if (global_scratch) {
+        // large-N variant: nothing per-point is materialised (rollout_stream_kernel.h); always 1024 threads
+        auto sk = rollout_stream_kernel<DP, 1024>;
+        static thread_local bool stream_configured = false;
+        if (!stream_configured) {
+            GPMPC_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(sk),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit));
+            stream_configured = true;
+        }
+        hipLaunchKernelGGL(sk, dim3(a.B), dim3(1024), lds_bytes, s, a);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+        return GPMPC_OK;
+    }
+    const bool exact = (a.D == DP);
+    auto kern = exact ? rollout_kernel<DP, NT, false, DP> : rollout_kernel<DP, NT, false, 0>;
     static thread_local const void* configured[3] = {nullptr, nullptr, nullptr};
     const void* kp = reinterpret_cast<const void*>(kern);
     const int slot = global_scratch ? 2 : (exact ? 1 : 0);

@@ -1,0 +1,368 @@
+// rollout_stream_kernel.h -- large-N variant of the GP-MPC inner loop for gfx950 (MI355X, CDNA4).
+//
+// Same mathematics, same C ABI entry and the same item loops as rollout_kernel.h, for memory sizes whose
+// per-point arrays (nu, lb, row records: O(N (2D + G(D+2))) doubles) no longer fit the 160 KiB LDS of a
+// CU (config 5: N = 4096, D = 16).  Nothing per-point is materialised:
+//   * mean part, one output dimension a at a time: every thread streams its points (coalesced reads of
+//     X^T), keeps the D + 1 partial sums  sum lb_a [1, nu]  in registers, one block reduction per a;
+//   * pairs (a, b) one at a time: the N column factors go to LDS (8 N bytes); the row records
+//     {ea_i | ka'_i, ra_i | beta_ai, g_i} are produced on the fly for one chunk of <= 64 rows at a time
+//     into a double-buffered LDS stage (the chunk after next is filled while the current one is consumed:
+//     one workgroup barrier per chunk); each wave owns the 64-column blocks w, w + NW, ... and keeps ONE
+//     accumulator across all row chunks, so a pair costs a single wavefront reduction.
+// Row operands are therefore LDS broadcasts exactly as in the LDS-resident kernel (the first round-1
+// version of this variant re-read the records from L2 for every wave and ran ~7x off its VALU bound).
+#pragma once
+#include "rollout_kernel.h"
+
+namespace gpmpc_hip {
+
+struct StreamLayout {
+    int mu, Sig, m, M, cc, s1, Vs, Sp, aug, red, kb, stage, ints;
+    int c_ils2, c_logvar, c_var, c_xr, c_act, c_exptab;
+    int total;     // doubles
+};
+
+__host__ __device__ inline StreamLayout make_stream_layout(int N, int D, int A, int E, int DP, int CH, int HA) {
+    StreamLayout L;
+    const int P = D * (D + 1) / 2;
+    int o = 0;
+    L.mu = o;       o += rnd2(D);
+    L.Sig = o;      o += 2 * rnd2(D * D);
+    L.m = o;        o += rnd2(E);
+    L.M = o;        o += rnd2(D);
+    L.cc = o;       o += rnd2(D);
+    L.s1 = o;       o += rnd2(D * (D + 1));
+    L.Vs = o;       o += rnd2(D * D);
+    L.Sp = o;       o += rnd2(P);
+    L.aug = o;      o += 2 * D * D;
+    L.red = o;      o += rnd2(16 * (DP + 1));
+    L.kb = o;       o += rnd2(N);
+    L.stage = o;    o += 2 * CH * (DP + 2);
+    L.ints = o;     o += 4;
+    L.c_ils2 = o;   o += rnd2(D * E);
+    L.c_logvar = o; o += rnd2(D);
+    L.c_var = o;    o += rnd2(D);
+    L.c_xr = o;     o += rnd2(2 * E);
+    L.c_act = o;    o += rnd2(HA);
+    L.c_exptab = o; o += 64;
+    L.total = o;
+    return L;
+}
+
+template <int DP, int NT>
+__global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NW = NT / kWave;
+    constexpr int RS = DP + 2;
+    constexpr int DPC = DP <= 2 ? 2 : (DP <= 4 ? 4 : (DP <= 8 ? 8 : 16));     // lanes that share one row record
+    static_assert(NT == 1024, "stage fill maps 64 rows x 16 components onto 1024 threads");
+    const int tid0 = threadIdx.x;
+    const int c = blockIdx.x;
+    const int D = p.D, N = p.N, A = p.A, E = p.E, H = p.H, CH = p.CH;
+    const int P = D * (D + 1) / 2;
+    const int DA = D + A;
+    const int LD = 2 * D;
+    const int SD2 = rnd2(D * D);
+    const int RC = (N + CH - 1) / CH;
+    const int NCB = (N + 63) / 64;
+
+    const StreamLayout L = make_stream_layout(N, D, A, E, DP, CH, H * A);
+    double* s_mu = smem + L.mu;
+    double* s_Sig2 = smem + L.Sig;
+    double* s_m = smem + L.m;
+    double* s_M = smem + L.M;
+    double* s_cc = smem + L.cc;
+    double* s_s1 = smem + L.s1;
+    double* s_Vs = smem + L.Vs;
+    double* s_Sp = smem + L.Sp;
+    double* s_aug = smem + L.aug;
+    double* s_red = smem + L.red;
+    double* s_kb = smem + L.kb;
+    double* s_stage = smem + L.stage;
+    int* s_int = reinterpret_cast<int*>(smem + L.ints);      // [0] Taylor degree of the current pair
+    double* s_rdet = smem + L.ints + 2;
+    double* c_ils2 = smem + L.c_ils2;
+    double* c_logvar = smem + L.c_logvar;
+    double* c_var = smem + L.c_var;
+    double* c_xr = smem + L.c_xr;
+    double* c_act = smem + L.c_act;
+    double* c_exptab = smem + L.c_exptab;
+    const double* act = p.actions + (size_t)c * H * A;
+
+    for (int i = tid0; i < D; i += NT) { s_mu[i] = p.mu0[i]; c_logvar[i] = p.logvar[i]; c_var[i] = p.var[i]; }
+    for (int i = tid0; i < D * D; i += NT) s_Sig2[i] = p.S0[i];
+    for (int i = tid0; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
+    for (int i = tid0; i < 2 * E; i += NT) c_xr[i] = p.xrange[i];
+    for (int i = tid0; i < H * A; i += NT) c_act[i] = act[i];
+    for (int i = tid0; i < 64; i += NT) c_exptab[i] = kExp2Tab[i];
+    __syncthreads();
+    for (int i = tid0; i < D; i += NT) p.mu_out[((size_t)c * (H + 1)) * D + i] = s_mu[i];
+    for (int i = tid0; i < D * D; i += NT) p.Sig_out[((size_t)c * (H + 1)) * D * D + i] = s_Sig2[i];
+
+    int cur = 0;
+    for (int t = 0; t < H; ++t) {
+        int tid_opaque = tid0;
+        asm volatile("" : "+v"(tid_opaque));          // see rollout_kernel.h: stops invariant hoisting
+        const int tid = tid_opaque;
+        const int lane = tid & 63;
+        const int wave = tid >> 6;
+        const double* s_Sig = s_Sig2 + cur * SD2;
+        double* s_SigNext = s_Sig2 + (cur ^ 1) * SD2;
+
+        for (int i = tid; i < E; i += NT) {
+            double v;
+            if (i < D) v = s_mu[i];
+            else if (i < DA) v = c_act[t * A + (i - D)];
+            else v = p.time0 + (double)t;
+            s_m[i] = v;
+        }
+        __syncthreads();
+
+        // ---- mean part: M_a, V_a for one output dimension at a time (gp_model.py:140-153) -------------------
+        for (int a = 0; a < D; ++a) {
+            if (tid == 0) {
+                double prodil = 1.0;
+                for (int i = 0; i < D; ++i) {
+                    const double il2 = c_ils2[a * E + i];
+                    prodil *= il2;
+                    for (int j = 0; j < D; ++j) {
+                        s_aug[i * LD + j] = s_Sig[i * D + j] + (i == j ? 1.0 / il2 : 0.0);
+                        s_aug[i * LD + D + j] = (i == j ? 1.0 : 0.0);
+                    }
+                }
+                const double detA = gauss_solve(s_aug, D, D, LD);
+                s_cc[a] = c_var[a] / sqrt(detA * prodil);
+            }
+            __syncthreads();
+            double acc[DP + 1];
+#pragma unroll
+            for (int k = 0; k <= DP; ++k) acc[k] = 0.0;
+            const double* Ai = s_aug + D;
+            for (int pt = tid; pt < N; pt += NT) {
+                double nu[DP];
+#pragma unroll
+                for (int d = 0; d < DP; ++d) nu[d] = (d < D) ? (p.Xt[(size_t)d * N + pt] - s_m[d]) : 0.0;
+                double q = 0.0;
+#pragma unroll
+                for (int i = 0; i < DP; ++i) {
+                    if (i < D) {
+                        double r = 0.0;
+#pragma unroll
+                        for (int j = 0; j < DP; ++j)
+                            if (j < D) r = fma(Ai[i * LD + j], nu[j], r);
+                        q = fma(nu[i], r, q);
+                    }
+                }
+                for (int e = D; e < E; ++e) {
+                    const double v = p.Xt[(size_t)e * N + pt] - s_m[e];
+                    q = fma(v * v, c_ils2[a * E + e], q);
+                }
+                const double lb = exp(-0.5 * q) * p.beta[(size_t)a * N + pt];
+                acc[0] += lb;
+#pragma unroll
+                for (int d = 0; d < DP; ++d) acc[1 + d] = fma(lb, nu[d], acc[1 + d]);
+            }
+#pragma unroll
+            for (int k = 0; k <= DP; ++k) {
+                const double v = wave_sum(acc[k]);
+                if (lane == 0) s_red[wave * (DP + 1) + k] = v;
+            }
+            __syncthreads();
+            if (tid <= D) {
+                double s = 0.0;
+                for (int w = 0; w < NW; ++w) s += s_red[w * (DP + 1) + tid];
+                s_s1[a * (D + 1) + tid] = s;
+            }
+            __syncthreads();
+            if (tid < D) {
+                double s = 0.0;
+                for (int j = 0; j < D; ++j) s = fma(Ai[tid * LD + j], s_s1[a * (D + 1) + 1 + j], s);
+                s_Vs[tid * D + a] = s_cc[a] * s;                        // state rows of V (:153)
+                if (tid == 0) s_M[a] = s_cc[a] * s_s1[a * (D + 1)];     // M_a (:152)
+            }
+            __syncthreads();
+        }
+
+        // ---- covariance part: one output pair at a time (gp_model.py:156-178) ------------------------------
+        int q = 0;
+        for (int a = 0; a < D; ++a) {
+            for (int b = a; b < D; ++b, ++q) {
+                const bool diag = (a == b);
+                if (tid == 0) {
+                    for (int i = 0; i < D; ++i)
+                        for (int j = 0; j < D; ++j) {
+                            const double dab = c_ils2[a * E + j] + c_ils2[b * E + j];
+                            s_aug[i * LD + j] = s_Sig[i * D + j] * dab + (i == j ? 1.0 : 0.0);
+                            s_aug[i * LD + D + j] = s_Sig[i * D + j];
+                        }
+                    const double detR = gauss_solve(s_aug, D, D, LD);
+                    s_rdet[0] = 1.0 / sqrt(detR);
+                    const double* Z = s_aug + D;
+                    double cmax = 0.0;
+                    for (int i = 0; i < D; ++i) {
+                        const double mi = s_mu[i];
+                        const double ui = fmax(fabs(c_xr[i] - mi), fabs(c_xr[E + i] - mi)) * c_ils2[a * E + i];
+                        for (int j = 0; j < D; ++j) {
+                            const double mj = s_mu[j];
+                            const double wj = fmax(fabs(c_xr[j] - mj), fabs(c_xr[E + j] - mj)) * c_ils2[b * E + j];
+                            cmax = fma(fabs(Z[i * LD + j]) * ui, wj, cmax);
+                        }
+                    }
+                    int K = 0;
+                    if (p.force_path != 1 && cmax <= kTaylorMaxArg[kMaxTaylor]) {
+                        K = 1;
+                        for (int k = 1; k < kMaxTaylor; ++k) K += (cmax > kTaylorMaxArg[k]) ? 1 : 0;
+                    }
+                    s_int[0] = K;
+                }
+                __syncthreads();
+                const int K = __builtin_amdgcn_readfirstlane(s_int[0]);
+                const double* Z = s_aug + D;
+
+                // column factors: exp(kb'_j) beta_bj  (Taylor form), kb'_j (direct form); diagonal pair: ea_j
+                for (int j = tid; j < N; j += NT) {
+                    double w[DP];
+                    double ks = 0.0;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) {
+                        const double nu = (d < D) ? (p.Xt[(size_t)d * N + j] - s_m[d]) : 0.0;
+                        w[d] = (d < D) ? nu * c_ils2[b * E + d] : 0.0;
+                        ks = fma(nu, w[d], ks);
+                    }
+                    for (int e = D; e < E; ++e) {
+                        const double v = p.Xt[(size_t)e * N + j] - s_m[e];
+                        ks = fma(v * v, c_ils2[b * E + e], ks);
+                    }
+                    double qb = 0.0;
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) {
+                        if (i < D) {
+                            double zw = 0.0;
+#pragma unroll
+                            for (int jj = 0; jj < DP; ++jj)
+                                if (jj < D) zw = fma(Z[i * LD + jj], w[jj], zw);
+                            qb = fma(w[i], zw, qb);
+                        }
+                    }
+                    const double kb = c_logvar[b] - 0.5 * ks + 0.5 * qb;
+                    s_kb[j] = (K > 0) ? (diag ? exp(kb) : exp(kb) * p.beta[(size_t)b * N + j]) : kb;
+                }
+
+                // row records of one chunk -> LDS stage; DPC lanes share a row (lane group = one record)
+                auto fill_stage = [&](int r, double* stage) {
+                    const int trow = tid / DPC, comp = tid - trow * DPC;
+                    if (trow < CH) {
+                        const int i = r * CH + trow;
+                        double gcomp = 0.0, part = 0.0, ks = 0.0;
+                        if (i < N) {
+                            for (int d = 0; d < D; ++d) {
+                                const double nu = p.Xt[(size_t)d * N + i] - s_m[d];
+                                const double u = nu * c_ils2[a * E + d];
+                                ks = fma(nu, u, ks);
+                                if (comp < D) gcomp = fma(Z[d * LD + comp], u, gcomp);      // g = Z^T u
+                                if (d == comp) part = u;
+                            }
+                            for (int e = D; e < E; ++e) {
+                                const double v = p.Xt[(size_t)e * N + i] - s_m[e];
+                                ks = fma(v * v, c_ils2[a * E + e], ks);
+                            }
+                            part *= gcomp;                                                   // u_comp g_comp
+                        }
+                        double qa = part;                                                    // u^T Z u over the DPC lanes
+#pragma unroll
+                        for (int off = 1; off < DPC; off <<= 1) qa += __shfl_xor(qa, off, 64);
+                        double* rec = stage + (size_t)trow * RS;
+                        if (comp < DP) rec[2 + comp] = gcomp;
+                        if (comp == 0) {
+                            double r0 = 0.0, r1 = 0.0;
+                            if (i < N) {
+                                const double ka = c_logvar[a] - 0.5 * ks + 0.5 * qa;
+                                const double ba = p.beta[(size_t)a * N + i];
+                                if (K > 0) { r0 = exp(ka); r1 = r0 * ba; } else { r0 = ka; r1 = ba; }
+                            }
+                            rec[0] = r0;
+                            rec[1] = r1;
+                        }
+                    }
+                };
+                fill_stage(0, s_stage);
+                __syncthreads();
+
+                double acc = 0.0;
+                for (int r = 0; r < RC; ++r) {
+                    if (r + 1 < RC) fill_stage(r + 1, s_stage + ((r + 1) & 1) * CH * RS);
+                    const double* rec = s_stage + (r & 1) * CH * RS;
+                    int nch = N - r * CH;
+                    if (nch > CH) nch = CH;
+                    nch = (nch + 3) & ~3;                                   // rows past the data are zero records
+                    for (int cb = wave; cb < NCB; cb += NW) {
+                        const int j0 = cb * 64;
+                        if (diag && j0 + 63 < r * CH) continue;             // T is zero below its diagonal
+                        int nrows = nch;
+                        if (diag) { const int lim = (j0 + 64 - r * CH + 3) & ~3; if (lim < nrows) nrows = lim; }
+                        const int j = j0 + lane;
+                        const bool valid = j < N;
+                        const int jc = valid ? j : N - 1;
+                        double w[DP];
+#pragma unroll
+                        for (int d = 0; d < DP; ++d) w[d] = (d < D) ? (p.Xt[(size_t)d * N + jc] - s_m[d]) * c_ils2[b * E + d] : 0.0;
+                        const double kbj = s_kb[jc];
+                        const double* Tp = p.Tm + ((size_t)a * (N + kTPad) + (size_t)r * CH) * N + jc;
+                        double v;
+                        if (K == 0) {
+                            v = item_exp<DP>(rec, nrows, w, kbj, diag, Tp, N, c_exptab);
+                            v *= diag ? 2.0 : p.beta[(size_t)b * N + jc];
+                        } else {
+                            if (K <= 2) v = item_taylor<DP, 2>(rec, nrows, w, diag, Tp, N);
+                            else if (K <= 4) v = item_taylor<DP, 4>(rec, nrows, w, diag, Tp, N);
+                            else if (K == 5) v = item_taylor<DP, 5>(rec, nrows, w, diag, Tp, N);
+                            else if (K == 6) v = item_taylor<DP, 6>(rec, nrows, w, diag, Tp, N);
+                            else if (K <= 8) v = item_taylor<DP, 8>(rec, nrows, w, diag, Tp, N);
+                            else if (K <= 10) v = item_taylor<DP, 10>(rec, nrows, w, diag, Tp, N);
+                            else if (K <= 12) v = item_taylor<DP, 12>(rec, nrows, w, diag, Tp, N);
+                            else v = item_taylor<DP, 14>(rec, nrows, w, diag, Tp, N);
+                            v *= diag ? 2.0 * kbj : kbj;
+                        }
+                        acc += valid ? v : 0.0;
+                    }
+                    __syncthreads();
+                }
+                acc = wave_sum(acc);
+                if (lane == 0) s_red[wave] = acc;
+                __syncthreads();
+                if (tid == 0) {
+                    double s = 0.0;
+                    for (int w = 0; w < NW; ++w) s += s_red[w];
+                    s_Sp[q] = s * s_rdet[0];
+                }
+                __syncthreads();
+            }
+        }
+
+        // ---- state update (gp_model.py:105-108, 177-178) -------------------------------------------------
+        for (int idx = tid; idx < D * D; idx += NT) {
+            const int i = idx / D, j = idx - i * D;
+            const int a = i < j ? i : j, b = i < j ? j : i;
+            const int qq = a * D - (a * (a - 1)) / 2 + (b - a);
+            const double S = s_Sp[qq] - s_M[i] * s_M[j] + (i == j ? c_var[i] : 0.0);
+            double cij = 0.0, cji = 0.0;
+            for (int k = 0; k < D; ++k) {
+                cij = fma(s_Sig[i * D + k], s_Vs[k * D + j], cij);
+                cji = fma(s_Sig[j * D + k], s_Vs[k * D + i], cji);
+            }
+            const double v = S + s_Sig[idx] + (cij + cji);
+            s_SigNext[idx] = v;
+            p.Sig_out[((size_t)c * (H + 1) + (t + 1)) * D * D + idx] = v;
+        }
+        for (int i = tid; i < D; i += NT) {
+            const double v = s_mu[i] + s_M[i];
+            s_mu[i] = v;
+            p.mu_out[((size_t)c * (H + 1) + (t + 1)) * D + i] = v;
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+}
+
+}  // namespace gpmpc_hip
