@@ -52,7 +52,7 @@ int gpmpc_destroy(gpmpc_t* g) {
     Handle* h = H_(g);
     (void)hipSetDevice(h->device);
     Buf* all[] = {&h->Xt, &h->beta, &h->iK, &h->Tm, &h->ils2, &h->var, &h->logvar, &h->gram,
-                  &h->linv, &h->zvec, &h->cost, &h->scratch, &h->best, &h->xrange, &h->mono_w, &h->traj};
+                  &h->linv, &h->zvec, &h->cost, &h->best, &h->xrange, &h->mono_w, &h->traj};
     for (Buf* b : all) free_buf(*b);
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);

@@ -55,8 +55,6 @@ struct RolloutArgs {
     int RC;       // row chunks per column
     unsigned magic_N;        // ceil(2^32 / N):   x / N   == umulhi(x, magic_N)   for the index ranges used
     unsigned magic_wpp;      // ceil(2^32 / wpp): x / wpp == umulhi(x, magic_wpp)
-    double* scratch;         // per-candidate global scratch (large-N variant)
-    size_t scratch_stride;   // doubles per candidate
     // initial state distribution
     double mu0[kMaxD];
     double S0[kMaxD * kMaxD];
@@ -86,7 +84,6 @@ struct Handle {
     Buf linv;     // (D, N, N)  L^-1 (prepare workspace)
     Buf zvec;     // (D, N)     temp for beta
     Buf cost;     // target | W | W_T | smin | smax
-    Buf scratch;  // per-candidate rollout scratch (large-N variant)
     Buf best;     // argmin result: [best_J, best_idx bits]
     Buf traj;     // (B, H+1, D) + (B, H+1, D, D) when the caller does not want the trajectory
     Buf xrange;   // (2, E) min / max of the inputs

@@ -234,7 +234,7 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         for (int g = P; g >= 1; --g) {
             chunking(g);
             const int wpp = (RC * N + 63) / 64;
-            Layout L = make_layout(N, D, A, E, g, DP, wpp, CM, CH, a.H * A, false);
+            Layout L = make_layout(N, D, A, E, g, DP, wpp, CM, CH, a.H * A);
             if ((size_t)L.lds_total * 8 <= (size_t)h->lds_limit) { G = g; lds_bytes = (size_t)L.lds_total * 8; break; }
         }
         if (G == 0) gs = true;

@@ -25,7 +25,7 @@ static int launch_variant(Handle* h, RolloutArgs& a, bool global_scratch, size_t
         return GPMPC_OK;
     }
     const bool exact = (a.D == DP);
-    auto kern = exact ? rollout_kernel<DP, NT, false, DP> : rollout_kernel<DP, NT, false, 0>;
+    auto kern = exact ? rollout_kernel<DP, NT, DP> : rollout_kernel<DP, NT, 0>;
     static thread_local const void* configured[3] = {nullptr, nullptr, nullptr};
     const void* kp = reinterpret_cast<const void*>(kern);
     const int slot = global_scratch ? 2 : (exact ? 1 : 0);

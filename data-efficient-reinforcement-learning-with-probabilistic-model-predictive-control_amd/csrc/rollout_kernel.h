@@ -56,15 +56,14 @@ struct Layout {
     int mu, Sig, m, M, cc, s1, Vs, Sp, TS, v1, v2, ev, misc, rdet, aug, part, mom, ints;
     int c_ils2, c_logvar, c_var, c_xr, c_act, c_exptab, c_monow, c_monoe;    // read-only tables copied to LDS once
     int lds_total;     // doubles of LDS
-    // per-point arrays: in LDS (offsets from smem) or in global scratch (offsets from base)
+    // per-point arrays (LDS)
     int nu, lb, rows, kb;
     int pp_total;      // doubles of the per-point block
 };
 
 __host__ __device__ inline int rnd2(int x) { return (x + 1) & ~1; }
 
-__host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G, int DP, int wpp, int CM, int CH, int HA,
-                                              bool global_scratch) {
+__host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G, int DP, int wpp, int CM, int CH, int HA) {
     Layout L;
     const int P = D * (D + 1) / 2;
     int o = 0;
@@ -94,13 +93,13 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     L.c_exptab = o; o += 64;
     L.c_monow = o;  o += rnd2(CM);
     L.c_monoe = o;  o += rnd2((CM + 1) / 2);           // packed exponents, one int per monomial
-    int q = global_scratch ? 0 : o;
+    int q = o;
     L.nu = q;   q += rnd2(D * N);
     L.lb = q;   q += rnd2(D * N);
     L.rows = q; q += G * (N + CH) * (DP + 2);       // + CH zero rows per pair (lanes of a wave share the trip count)
     L.kb = q;   q += rnd2(G * N);
-    if (global_scratch) { L.lds_total = o; L.pp_total = q; }
-    else                { L.lds_total = q; L.pp_total = q - o; }
+    L.lds_total = q;
+    L.pp_total = q - o;
     return L;
 }
 
@@ -458,7 +457,7 @@ __device__ inline int wave_max_i32(int v) {
 // ------------------------------------------------------------------------------------------
 // DX = exact state dimension known at compile time (0: runtime p.D <= DP): folds every D-dependent
 // offset and small loop, which is what keeps the 128-VGPR budget of a 1024-thread workgroup.
-template <int DP, int NT, bool GLOBAL, int DX>
+template <int DP, int NT, int DX>
 __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NT / kWave;
@@ -475,7 +474,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     const int wpp = (p.RC * N + 63) / 64;   // work-item slots per output pair
     const int SD2 = rnd2(D * D);
 
-    const Layout L = make_layout(N, D, A, E, G, DP, wpp, CM, p.CH, H * A, GLOBAL);
+    const Layout L = make_layout(N, D, A, E, G, DP, wpp, CM, p.CH, H * A);
     const int NR = N + p.CH;                // rows per pair in the row-record array (data + zero padding)
     double* s_mu = smem + L.mu;
     double* s_Sig2 = smem + L.Sig;
@@ -495,7 +494,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     int* s_K = s_pb + P;                    // per pair of the group: Taylor degree, 0 = direct exp
     int* s_counter = s_K + G;
 
-    double* ppbase = GLOBAL ? (p.scratch + (size_t)c * p.scratch_stride) : smem;
+    double* ppbase = smem;                  // per-point arrays live in LDS (large N: rollout_stream_kernel.h)
     double* a_nu = ppbase + L.nu;           // [d][p]
     double* a_lb = ppbase + L.lb;           // [a][p]
     double* a_rows = ppbase + L.rows;       // [gq][p][RS]
