@@ -56,22 +56,58 @@ __global__ __launch_bounds__(256) void xrange_kernel(const double* __restrict__ 
     }
 }
 
-// K[a][i][j], lanes along j (coalesced stores); x_i broadcast through the scalar path.
+// K_a = outputscale_a exp(-1/2 sum_e ((x_ie - x_je)/l_ae)^2) + noise_a I, 64 x 64 tiles of the upper block
+// triangle (tj >= ti); the mirror tile is written through an LDS transpose, so every store is a coalesced
+// 512-byte row segment and every element is computed once.  Lane = column j (its x_j / l_a in registers),
+// the 16 rows a thread visits read x_i / l_a as LDS broadcasts: per element 2E VALU + one exp and no global
+// load, which puts the kernel on the HBM-write side of its roofline (D N^2 8 bytes out).
+template <int EP>
 __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xt, const double* __restrict__ ils2,
                                                    const double* __restrict__ var, const double* __restrict__ noise,
                                                    int N, int E, double* __restrict__ K) {
+    __shared__ double xi[64][EP + 1];          // rows of the tile, pre-scaled by 1 / l_a
+    __shared__ double tile[64][65];
     const int a = blockIdx.z;
-    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (i >= N || j >= N) return;
-    double s = 0.0;
-    for (int e = 0; e < E; ++e) {
-        const double d = Xt[(size_t)e * N + i] - Xt[(size_t)e * N + j];
-        s = fma(d * d, ils2[a * E + e], s);
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj < ti) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = ti * 64, j0 = tj * 64;
+    double il[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) il[e] = (e < E) ? sqrt(ils2[a * E + e]) : 0.0;
+    for (int idx = threadIdx.x; idx < 64 * EP; idx += 256) {
+        const int r = idx / EP, e = idx - r * EP;
+        const int i = i0 + r;
+        xi[r][e] = (e < E && i < N) ? Xt[(size_t)e * N + i] * sqrt(ils2[a * E + e]) : 0.0;
     }
-    double v = var[a] * exp(-0.5 * s);
-    if (i == j) v += noise[a];
-    K[((size_t)a * N + i) * N + j] = v;
+    const int j = j0 + lane;
+    double xj[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) xj[e] = (e < E && j < N) ? Xt[(size_t)e * N + j] * il[e] : 0.0;
+    __syncthreads();
+    const double va = var[a], nz = noise[a];
+    double* Ka = K + (size_t)a * N * N;
+#pragma unroll 4
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr;
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < EP; ++e) { const double d = xi[r][e] - xj[e]; s = fma(d, d, s); }
+        double v = va * exp(-0.5 * s);
+        const int i = i0 + r;
+        if (i == j) v += nz;
+        tile[r][lane] = v;
+        if (i < N && j < N) Ka[(size_t)i * N + j] = v;
+    }
+    if (tj != ti) {                                  // mirror tile: K[j0 + r][i0 + lane] = tile[lane][r]
+        __syncthreads();
+#pragma unroll 4
+        for (int rr = 0; rr < 16; ++rr) {
+            const int r = wave * 16 + rr;
+            const int jj = j0 + r, ii = i0 + lane;
+            if (jj < N && ii < N) Ka[(size_t)jj * N + ii] = tile[lane][r];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -358,8 +394,13 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     GPMPC_HIP_CHECK(h, hipMemsetAsync(h->info, 0, kMaxD * sizeof(int), s));
     GPMPC_HIP_CHECK(h, hipMemsetAsync(h->linv.p, 0, (size_t)D * N * N * sizeof(double), s));
     GPMPC_HIP_CHECK(h, hipMemsetAsync(h->Tm.p, 0, (size_t)D * (N + kTPadRows) * N * sizeof(double), s));
-    hipLaunchKernelGGL(gram_kernel, dim3((N + 63) / 64, (N + 3) / 4, D), dim3(256), 0, s,
-                       h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
+    {
+        const dim3 grid((N + 63) / 64, (N + 63) / 64, D);
+        if (E <= 4) hipLaunchKernelGGL(gram_kernel<4>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
+        else if (E <= 8) hipLaunchKernelGGL(gram_kernel<8>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
+        else if (E <= 16) hipLaunchKernelGGL(gram_kernel<16>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
+        else hipLaunchKernelGGL(gram_kernel<24>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
+    }
     GPMPC_HIP_CHECK(h, hipGetLastError());
     for (int k0 = 0; k0 < N; k0 += NB) {
         const int nb = (N - k0 < NB) ? (N - k0) : NB;
