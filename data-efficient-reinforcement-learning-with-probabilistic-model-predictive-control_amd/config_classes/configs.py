@@ -85,8 +85,12 @@ _DEFAULT_OPTIMIZER = {"disp": None, "maxcor": 30, "ftol": 1e-99, "gtol": 1e-99, 
 
 
 class ControllerConfig:
+    """Reference keywords (controller_config.py:1-25) plus three optional ones for the batched optimiser that
+    replaces the sequential scipy restarts when `candidate_optimizer="cem"`."""
+
     def __init__(self, len_horizon=15, actions_optimizer_params=None, init_from_previous_actions=True,
-                 restarts_optim=1, optimize=True, num_repeat_actions=1):
+                 restarts_optim=1, optimize=True, num_repeat_actions=1,
+                 candidate_optimizer=None, cem_candidates=256, cem_iterations=4, cem_elite_fraction=0.1):
         self.len_horizon = len_horizon
         self.actions_optimizer_params = dict(_DEFAULT_OPTIMIZER if actions_optimizer_params is None
                                              else actions_optimizer_params)
@@ -94,6 +98,10 @@ class ControllerConfig:
         self.restarts_optim = restarts_optim      # with optimize=False: number of random candidates (one GPU launch)
         self.optimize = optimize
         self.num_repeat_actions = num_repeat_actions
+        self.candidate_optimizer = candidate_optimizer      # None: scipy L-BFGS-B (reference behaviour); "cem"
+        self.cem_candidates = cem_candidates                # candidates per iteration = one kernel launch
+        self.cem_iterations = cem_iterations
+        self.cem_elite_fraction = cem_elite_fraction
 
 
 def _broadcast(v, shape):

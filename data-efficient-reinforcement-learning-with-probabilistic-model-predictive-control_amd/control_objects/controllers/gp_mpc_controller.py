@@ -199,6 +199,8 @@ class GpMpcController(BaseControllerObject):
         H, A = cc.len_horizon, self.actions_mapper.dim_action
         if not cc.optimize:
             return self._random_shooting(state_mu, state_var)
+        if getattr(cc, "candidate_optimizer", None) == "cem":
+            return self._cross_entropy_search(state_mu, state_var)
         opt_fun, best = np.inf, None
         for idx_restart in range(cc.restarts_optim):
             if cc.init_from_previous_actions and self.actions_mpc_previous_iter is not None and idx_restart == 0:
@@ -240,6 +242,41 @@ class GpMpcController(BaseControllerObject):
         self.best_candidate_index, self.best_candidate_J = best, J
         self.actions_mpc_previous_iter = win.numpy().reshape(-1).copy()
         return self.actions_mapper.transform_action_mpc_to_action_model(self.actions_mpc_previous_iter)
+
+    def _cross_entropy_search(self, state_mu, state_var):
+        """Batched replacement of the sequential scipy restarts: every iteration is ONE
+        rollout launch over `cem_candidates` sequences drawn around the current mean (iteration 0: uniform,
+        plus the shifted previous solution when init_from_previous_actions), the elites refit mean / std of a
+        diagonal Gaussian over the optimiser vector in [0, 1]^(H*A); the best sequence ever evaluated wins."""
+        cc = self.config.controller
+        H, A = cc.len_horizon, self.actions_mapper.dim_action
+        n, B = H * A, int(cc.cem_candidates)
+        n_elite = max(2, int(round(B * cc.cem_elite_fraction)))
+        rng = np.random                                        # the reference's global generator
+        mean, std = np.full(n, 0.5), np.full(n, 0.5)
+        best_x, best_J = None, np.inf
+        for it in range(int(cc.cem_iterations)):
+            if it == 0:
+                cands = rng.uniform(0.0, 1.0, size=(B, n))
+                if cc.init_from_previous_actions and self.actions_mpc_previous_iter is not None:
+                    cands[0] = generate_mpc_action_init_frompreviousiter(self.actions_mpc_previous_iter, dim_action=A)
+            else:
+                cands = np.clip(mean + std * rng.standard_normal((B, n)), 0.0, 1.0)
+                cands[0] = best_x                              # keep the incumbent
+            out = self.evaluate_candidates(cands, state_mu, state_var, trajectories=True)
+            J = out["J"].cpu().numpy()
+            J = np.where(np.isnan(J), np.inf, J)
+            order = np.argsort(J, kind="stable")
+            if J[order[0]] < best_J:
+                best_J, best_x = float(J[order[0]]), cands[order[0]].copy()
+                self._cache_trajectory(out, int(order[0]))
+            elites = cands[order[:n_elite]]
+            mean, std = elites.mean(axis=0), elites.std(axis=0) + 1e-3
+        if best_x is None:
+            raise FloatingPointError("no finite objective among the candidates")
+        self.best_candidate_J = best_J
+        self.actions_mpc_previous_iter = best_x.copy()
+        return self.actions_mapper.transform_action_mpc_to_action_model(best_x)
 
     def _get_random_actions(self, state_mu, state_var):
         """Reference :155-163: one random sequence, evaluated only to fill the logging caches."""
