@@ -5,6 +5,7 @@
 #include <cstddef>
 #include <cstdio>
 #include <string>
+#include <unordered_set>
 
 #include "../../include/gpmpc.h"
 
@@ -49,6 +50,7 @@ struct RolloutArgs {
     int CM;                  // monomial capacity per (pair, side) in LDS
     int force_path;          // 0 auto, 1 always direct exp, 2 Taylor but never separable (tests)
     int force_sep;           // 1: separable whenever the degree allows, ignoring the cost model (tests)
+    int x_in_lds;            // 1: X^T is copied to LDS once per launch (the per-point pass reads it every step)
     // tiling
     int G;        // output pairs per group
     int CH;       // rows per chunk
@@ -94,6 +96,7 @@ struct Handle {
     int sep_kmax = 0;
     int mono_CM = 0;
     int* info = nullptr;        // (kMaxD) first non-positive pivot + 1, or 0
+    std::unordered_set<const void*> lds_configured;   // kernels whose dynamic-LDS limit was raised on this device
     // cost settings
     int cost_D = -1, cost_A = -1;
     double kappa = 1.0;
@@ -110,6 +113,9 @@ struct Handle {
     int num_cu = 256;
 };
 
+// Raise a kernel's dynamic-LDS limit to the device maximum once per handle (= per device).
+inline int allow_full_lds(Handle* h, const void* kernel);
+
 #define GPMPC_HIP_CHECK(h, expr)                                                         \
     do {                                                                                 \
         hipError_t e_ = (expr);                                                          \
@@ -118,6 +124,13 @@ struct Handle {
             return GPMPC_ERR_HIP;                                                        \
         }                                                                                \
     } while (0)
+
+inline int allow_full_lds(Handle* h, const void* kernel) {
+    if (h->lds_configured.count(kernel)) return GPMPC_OK;
+    GPMPC_HIP_CHECK(h, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit));
+    h->lds_configured.insert(kernel);
+    return GPMPC_OK;
+}
 
 // rollout.hip
 int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s);

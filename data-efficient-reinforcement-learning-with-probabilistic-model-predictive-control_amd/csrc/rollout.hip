@@ -231,11 +231,19 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         RC = (N + CH - 1) / CH;
     };
     if (!gs) {
-        for (int g = P; g >= 1; --g) {
-            chunking(g);
-            const int wpp = (RC * N + 63) / 64;
-            Layout L = make_layout(N, D, A, E, g, DP, wpp, CM, CH, a.H * A);
-            if ((size_t)L.lds_total * 8 <= (size_t)h->lds_limit) { G = g; lds_bytes = (size_t)L.lds_total * 8; break; }
+        // X^T in LDS when it is small next to the budget (<= 32 KiB) and the layout still fits
+        for (int xl = ((size_t)E * N * 8 <= 32 * 1024) ? 1 : 0; xl >= 0 && G == 0; --xl) {
+            for (int g = P; g >= 1; --g) {
+                chunking(g);
+                const int wpp = (RC * N + 63) / 64;
+                Layout L = make_layout(N, D, A, E, g, DP, wpp, CM, CH, a.H * A, xl != 0);
+                if ((size_t)L.lds_total * 8 <= (size_t)h->lds_limit) {
+                    G = g; lds_bytes = (size_t)L.lds_total * 8; a.x_in_lds = xl;
+                    break;
+                }
+            }
+            // prefer all pairs in one group over the X^T copy
+            if (G != 0 && G < P && xl == 1) { G = 0; }
         }
         if (G == 0) gs = true;
     }

@@ -14,24 +14,17 @@ static int launch_variant(Handle* h, RolloutArgs& a, bool global_scratch, size_t
     if (global_scratch) {
         // large-N variant: nothing per-point is materialised (rollout_stream_kernel.h); always 1024 threads
         auto sk = rollout_stream_kernel<DP, 1024>;
-        static thread_local bool stream_configured = false;
-        if (!stream_configured) {
-            GPMPC_HIP_CHECK(h, hipFuncSetAttribute(reinterpret_cast<const void*>(sk),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit));
-            stream_configured = true;
-        }
+        int rc = allow_full_lds(h, reinterpret_cast<const void*>(sk));
+        if (rc) return rc;
         hipLaunchKernelGGL(sk, dim3(a.B), dim3(1024), lds_bytes, s, a);
         GPMPC_HIP_CHECK(h, hipGetLastError());
         return GPMPC_OK;
     }
     const bool exact = (a.D == DP);
     auto kern = exact ? rollout_kernel<DP, NT, DP> : rollout_kernel<DP, NT, 0>;
-    static thread_local const void* configured[3] = {nullptr, nullptr, nullptr};
-    const void* kp = reinterpret_cast<const void*>(kern);
-    const int slot = global_scratch ? 2 : (exact ? 1 : 0);
-    if (configured[slot] != kp) {
-        GPMPC_HIP_CHECK(h, hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, h->lds_limit));
-        configured[slot] = kp;
+    {
+        int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+        if (rc) return rc;
     }
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(NT), lds_bytes, s, a);
     GPMPC_HIP_CHECK(h, hipGetLastError());

@@ -54,7 +54,7 @@ constexpr int kMaxMono = 256;      // most monomials of the separable (off-diago
 // LDS / scratch layout (offsets in doubles), shared by host (sizing) and device (carving).
 struct Layout {
     int mu, Sig, m, M, cc, s1, Vs, Sp, TS, v1, v2, ev, misc, rdet, aug, part, mom, ints;
-    int c_ils2, c_logvar, c_var, c_xr, c_act, c_exptab, c_monow, c_monoe;    // read-only tables copied to LDS once
+    int c_ils2, c_logvar, c_var, c_xr, c_act, c_exptab, c_monow, c_monoe, c_X;    // read-only tables copied to LDS once
     int lds_total;     // doubles of LDS
     // per-point arrays (LDS)
     int nu, lb, rows, kb;
@@ -63,7 +63,8 @@ struct Layout {
 
 __host__ __device__ inline int rnd2(int x) { return (x + 1) & ~1; }
 
-__host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G, int DP, int wpp, int CM, int CH, int HA) {
+__host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G, int DP, int wpp, int CM, int CH, int HA,
+                                              bool x_in_lds) {
     Layout L;
     const int P = D * (D + 1) / 2;
     int o = 0;
@@ -93,6 +94,7 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     L.c_exptab = o; o += 64;
     L.c_monow = o;  o += rnd2(CM);
     L.c_monoe = o;  o += rnd2((CM + 1) / 2);           // packed exponents, one int per monomial
+    L.c_X = o;      o += x_in_lds ? rnd2(E * N) : 0;   // X^T cached for the per-point pass when it fits
     int q = o;
     L.nu = q;   q += rnd2(D * N);
     L.lb = q;   q += rnd2(D * N);
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     const int wpp = (p.RC * N + 63) / 64;   // work-item slots per output pair
     const int SD2 = rnd2(D * D);
 
-    const Layout L = make_layout(N, D, A, E, G, DP, wpp, CM, p.CH, H * A);
+    const Layout L = make_layout(N, D, A, E, G, DP, wpp, CM, p.CH, H * A, p.x_in_lds != 0);
     const int NR = N + p.CH;                // rows per pair in the row-record array (data + zero padding)
     double* s_mu = smem + L.mu;
     double* s_Sig2 = smem + L.Sig;
@@ -506,6 +508,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     double* c_xr = smem + L.c_xr;
     double* c_act = smem + L.c_act;
     double* c_exptab = smem + L.c_exptab;
+    const double* Xs = p.x_in_lds ? (smem + L.c_X) : p.Xt;     // X^T (E, N): LDS copy or HBM/L2
     double* c_monow = smem + L.c_monow;
     int* c_monoe = reinterpret_cast<int*>(smem + L.c_monoe);
     const double* act = p.actions + (size_t)c * H * A;
@@ -522,6 +525,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     for (int i = tid; i < 2 * E; i += NT) c_xr[i] = p.xrange[i];
     for (int i = tid; i < H * A; i += NT) c_act[i] = act[i];
     for (int i = tid; i < 64; i += NT) c_exptab[i] = kExp2Tab[i];
+    if (p.x_in_lds)
+        for (int i = tid; i < E * N; i += NT) smem[L.c_X + i] = p.Xt[i];
     for (int i = tid; i < CM; i += NT) {
         c_monow[i] = p.mono_w[i];
         c_monoe[i] = p.mono_exp[i * 4] | (p.mono_exp[i * 4 + 1] << 8) | (p.mono_exp[i * 4 + 2] << 16) | (p.mono_exp[i * 4 + 3] << 24);
@@ -690,7 +695,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                 const int prob = it / N, pt = it - prob * N;
                 double nu[DP];
 #pragma unroll
-                for (int d = 0; d < DP; ++d) nu[d] = (d < D) ? (p.Xt[d * N + pt] - s_m[d]) : 0.0;
+                for (int d = 0; d < DP; ++d) nu[d] = (d < D) ? (Xs[d * N + pt] - s_m[d]) : 0.0;
                 if (prob < nmean) {
                     const int a = prob;
                     const double* Ai = s_aug + a * (D * LD) + D;          // A_a^-1
@@ -706,7 +711,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                         }
                     }
                     for (int e = D; e < E; ++e) {
-                        const double v = p.Xt[e * N + pt] - s_m[e];
+                        const double v = Xs[e * N + pt] - s_m[e];
                         q = fma(v * v, c_ils2[a * E + e], q);
                     }
                     a_lb[a * N + pt] = exp(-0.5 * q) * p.beta[a * N + pt];                 // lb (:148)
@@ -733,7 +738,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                         g[d] = 0.0;
                     }
                     for (int e = D; e < E; ++e) {
-                        const double v = p.Xt[e * N + pt] - s_m[e];
+                        const double v = Xs[e * N + pt] - s_m[e];
                         ksa = fma(v * v, c_ils2[a * E + e], ksa);
                         ksb = fma(v * v, c_ils2[b * E + e], ksb);
                     }
