@@ -232,6 +232,37 @@ def test_config5_full_size_step_against_oracle_fixture(engine):
     assert rel_err(out["J"].cpu().numpy(), g["J"]) < 1e-7
 
 
+def test_random_shapes_against_oracle(engine):
+    """Seeded fuzz over shapes (N not a multiple of 4 / 16 / 64, single points, padded D, time input, small and
+    large input variance): layout, padding and chunking edge cases of both kernels."""
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        N = int(rng.choice([1, 2, 3, 5, 17, 31, 63, 64, 65, 97, 130, 199, 257]))
+        D = int(rng.integers(1, 7))
+        A = int(rng.integers(1, 4))
+        H = int(rng.integers(1, 5))
+        B = int(rng.integers(1, 9))
+        tm = bool(rng.integers(0, 2))
+        s0 = float(rng.choice([1e-6, 1e-3, 5e-2]))
+        stream = bool(rng.integers(0, 2))
+        w = synth.make_workload(N, D, A, H, B, include_time=tm, seed=1000 + case, s0=s0, noise_var=1e-4,
+                                time0=float(N) if tm else 0.0)
+        f = factors_of(w)
+        ref = orc.evaluate_candidates(f, w)
+        engine.set_option("force_global_scratch", int(stream))
+        try:
+            engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+            _set_cost(engine, w)
+            out = engine.rollout(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+        finally:
+            engine.set_option("force_global_scratch", 0)
+        tag = (case, N, D, A, H, B, tm, s0, stream)
+        assert rel_err(out["mu"].cpu().numpy(), ref["mu"]) < 1e-8, tag
+        dS = np.max(np.abs(out["Sig"].cpu().numpy() - ref["Sig"]))
+        assert dS < 1e-6 * np.max(np.abs(ref["Sig"])) + 2e-11, (tag, dS)
+        assert rel_err(out["J"].cpu().numpy(), ref["J"]) < 1e-7, tag
+
+
 def test_rollout_is_bitwise_reproducible(engine):
     w = synth.make_workload(120, 3, 1, 10, 64, seed=5)
     engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
