@@ -25,7 +25,7 @@ static void free_buf(Buf& b) {
 
 extern "C" {
 
-int gpmpc_abi_version(void) { return 4; }
+int gpmpc_abi_version(void) { return 5; }
 
 int gpmpc_create(gpmpc_t** out, int device_id) {
     if (!out) return GPMPC_ERR_ARG;
@@ -52,10 +52,12 @@ int gpmpc_destroy(gpmpc_t* g) {
     Handle* h = H_(g);
     (void)hipSetDevice(h->device);
     Buf* all[] = {&h->Xt, &h->beta, &h->iK, &h->Tm, &h->ils2, &h->var, &h->logvar, &h->gram,
-                  &h->linv, &h->zvec, &h->cost, &h->best, &h->xrange, &h->mono_w, &h->traj};
+                  &h->linv, &h->zvec, &h->cost, &h->best, &h->xrange, &h->mono_w, &h->traj, &h->Xc, &h->Yc,
+                  &h->hyp, &h->kv, &h->vv, &h->sc};
     for (Buf* b : all) free_buf(*b);
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);
+    if (h->mismatch) (void)hipFree(h->mismatch);
     delete g;
     return GPMPC_OK;
 }
@@ -65,12 +67,13 @@ const char* gpmpc_last_error(const gpmpc_t* g) { return g ? g->h.err.c_str() : "
 int gpmpc_set_option(gpmpc_t* g, const char* name, long long value) {
     if (!g || !name) return GPMPC_ERR_ARG;
     Handle* h = H_(g);
-    if (!strcmp(name, "keep_gram")) h->opt_keep_gram = (int)value;
-    else if (!strcmp(name, "threads")) h->opt_threads = (int)value;
+    if (!strcmp(name, "threads")) h->opt_threads = (int)value;
     else if (!strcmp(name, "force_global_scratch")) h->opt_force_global = (int)value;
     else if (!strcmp(name, "rows_per_chunk")) h->opt_rows_per_chunk = (int)value;
     else if (!strcmp(name, "force_path")) h->opt_force_path = (int)value;
     else if (!strcmp(name, "force_separable")) h->opt_force_sep = (int)value;
+    else if (!strcmp(name, "incremental")) h->opt_incremental = (int)value;
+    else if (!strcmp(name, "refresh_every")) h->opt_refresh_every = (int)value;
     else return bad(g, "unknown option");
     return GPMPC_OK;
 }
@@ -116,12 +119,7 @@ int gpmpc_read_factors(gpmpc_t* g, double* iK_dst, double* beta_dst, void* strea
     return GPMPC_OK;
 }
 
-int gpmpc_get_gram(gpmpc_t* g, const double** K) {
-    if (!g || !K) return GPMPC_ERR_ARG;
-    if (!g->h.opt_keep_gram || !g->h.gram.p) return bad(g, "gram not kept: set option keep_gram before prepare");
-    *K = g->h.gram.p;
-    return GPMPC_OK;
-}
+int gpmpc_last_prepare_mode(gpmpc_t* g) { return g ? g->h.last_prepare_mode : GPMPC_ERR_ARG; }
 
 int gpmpc_set_cost(gpmpc_t* g, const double* target, const double* W, const double* W_T, double kappa,
                    int clip, const double* smin, const double* smax, int D, int A) {

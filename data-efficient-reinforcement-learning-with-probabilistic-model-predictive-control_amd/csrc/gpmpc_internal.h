@@ -89,6 +89,14 @@ struct Handle {
     Buf best;     // argmin result: [best_J, best_idx bits]
     Buf traj;     // (B, H+1, D) + (B, H+1, D, D) when the caller does not want the trajectory
     Buf xrange;   // (2, E) min / max of the inputs
+    // incremental factorisation: what the cached factors were computed from, and border-update scratch
+    Buf Xc, Yc;   // (N, E), (N, D) copies of the memory points of the last prepare
+    Buf hyp;      // lengthscales (D*E) | outputscales (D) | noises (D) of the last prepare
+    Buf kv, vv;   // (D, N) k(X, x_new), iK k
+    Buf sc;       // (D, 2) 1 / Schur complement, v^T y
+    int* mismatch = nullptr;     // device flag of the prefix comparison
+    int inc_updates = 0;         // border updates since the last full factorisation
+    bool have_state = false;     // Xc / Yc / hyp describe the cached factors
     Buf mono_w;   // (CM) 1 / alpha!
     int* mono_exp = nullptr;    // (CM, 4)
     int mono_D = -1;            // state dimension the monomial tables were built for
@@ -103,12 +111,14 @@ struct Handle {
     int clip = 0;
     int use_constraints = 0;
     // options
-    int opt_keep_gram = 0;
     int opt_threads = 0;
     int opt_force_global = 0;
     int opt_rows_per_chunk = 0;
     int opt_force_path = 0;
     int opt_force_sep = 0;
+    int opt_incremental = 1;         // reuse / border-update the cached factors when the memory only grew
+    int opt_refresh_every = 32;      // full refactorisation after this many border updates (bounds drift)
+    int last_prepare_mode = 0;       // 0 full, 1 border update(s), 2 unchanged (cache hit)
     int lds_limit = 160 * 1024;
     int num_cu = 256;
 };

@@ -319,6 +319,113 @@ __global__ __launch_bounds__(256) void syrk_inverse_kernel(const double* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Incremental factorisation: the reference refactorises from scratch at every control
+// step (gp_mpc_controller.py:117) although the memory grows by at most one point per step and the
+// hyper-parameters change only after a training round.  When the new (X, Y) is the cached one plus k
+// appended points and the hyper-parameters are unchanged, iK and beta are border-updated in O(k N^2):
+//   iK' = [[iK + v v^T / s, -v / s], [-v^T / s, 1 / s]],  v = iK k_new,  s = k(x,x) + noise - k_new^T v.
+__global__ void prefix_mismatch_kernel(const double* __restrict__ a, const double* __restrict__ b, size_t n,
+                                       int* __restrict__ flag) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && a[i] != b[i]) *flag = 1;
+}
+
+__global__ __launch_bounds__(256) void kvec_kernel(const double* __restrict__ X, int n, int E, const double* __restrict__ ils2,
+                                                   const double* __restrict__ var, int ldk, double* __restrict__ kv) {
+    const int a = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int e = 0; e < E; ++e) {
+        const double d = X[(size_t)i * E + e] - X[(size_t)n * E + e];
+        s = fma(d * d, ils2[a * E + e], s);
+    }
+    kv[(size_t)a * ldk + i] = var[a] * exp(-0.5 * s);
+}
+
+// Appending one point to K = L L^T keeps L and adds the row [l^T, d],  l = L^-1 k,  d^2 = k(x,x) + noise - l.l,
+// so  L'^-1 = [[L^-1, 0], [u^T]]  with  u = [-L^-T l / d ; 1 / d]  and  iK' = [[iK, 0], [0, 0]] + u u^T,
+// beta' = [beta; 0] + u (u.y').  Working from L^-1 (not from iK) keeps the update as accurate as the
+// triangular products: the error is O(eps sqrt(cond K)), not O(eps cond K).
+
+// l = L^-1 k  (wave per row, fixed order)
+__global__ __launch_bounds__(256) void border_lvec_kernel(const double* __restrict__ linv, const double* __restrict__ kv, int n,
+                                                          int ldk, double* __restrict__ lv) {
+    const int a = blockIdx.y;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const double* r = linv + ((size_t)a * n + row) * n;
+    double s = 0.0;
+    for (int j = lane; j <= row; j += 64) s = fma(r[j], kv[(size_t)a * ldk + j], s);
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) lv[(size_t)a * ldk + row] = s;
+}
+
+// u (n + 1 entries): 64 columns per workgroup, 16 row slices reduced through LDS in a fixed order
+__global__ __launch_bounds__(1024) void border_u_kernel(const double* __restrict__ linv, const double* __restrict__ lv, int n,
+                                                        int ldk, const double* __restrict__ var, const double* __restrict__ noise,
+                                                        double* __restrict__ uv, int* __restrict__ info) {
+    __shared__ double part[16][64];
+    __shared__ double ssum[16];
+    const int a = blockIdx.y;
+    const int t = threadIdx.x, lane = t & 63, slice = t >> 6;
+    const double* l = lv + (size_t)a * ldk;
+    double q = 0.0;
+    for (int i = t; i < n; i += 1024) q = fma(l[i], l[i], q);
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    if (lane == 0) ssum[slice] = q;
+    const int j = blockIdx.x * 64 + lane;
+    double acc = 0.0;
+    if (j < n) {
+        const double* c = linv + (size_t)a * n * n + j;
+        for (int i = j + slice; i < n; i += 16) acc = fma(l[i], c[(size_t)i * n], acc);
+    }
+    part[slice][lane] = acc;
+    __syncthreads();
+    if (slice == 0 && j <= n) {
+        double ll = 0.0, dot = 0.0;
+        for (int k = 0; k < 16; ++k) { ll += ssum[k]; dot += part[k][lane]; }
+        const double d2 = var[a] + noise[a] - ll;
+        if (!(d2 > 0.0) && j == 0 && info[a] == 0) info[a] = n + 1;
+        const double rd = 1.0 / sqrt(d2);
+        uv[(size_t)a * ldk + j] = (j < n) ? -rd * dot : rd;
+    }
+}
+
+// u . y'  (one workgroup per GP)
+__global__ __launch_bounds__(256) void border_dot_kernel(const double* __restrict__ uv, const double* __restrict__ Y, int n, int D,
+                                                         int ldk, double* __restrict__ sc) {
+    __shared__ double r[4];
+    const int a = blockIdx.x;
+    double q = 0.0;
+    for (int i = threadIdx.x; i <= n; i += 256) q = fma(uv[(size_t)a * ldk + i], Y[(size_t)i * D + a], q);
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) sc[a] = (r[0] + r[1]) + (r[2] + r[3]);
+}
+
+// iK', L'^-1 ((n+1) x (n+1), compact) and beta' from the n x n ones
+__global__ __launch_bounds__(256) void border_apply_kernel(const double* __restrict__ iK, const double* __restrict__ linv,
+                                                           const double* __restrict__ beta, const double* __restrict__ uv,
+                                                           const double* __restrict__ sc, int n, int ldk,
+                                                           double* __restrict__ iKn, double* __restrict__ linvn,
+                                                           double* __restrict__ betan) {
+    const int a = blockIdx.z;
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n1 = n + 1;
+    if (i > n || j > n) return;
+    const double ui = uv[(size_t)a * ldk + i], uj = uv[(size_t)a * ldk + j];
+    const bool old = (i < n && j < n);
+    const size_t src = ((size_t)a * n + i) * n + j, dst = ((size_t)a * n1 + i) * n1 + j;
+    iKn[dst] = fma(ui, uj, old ? iK[src] : 0.0);                    // exactly symmetric
+    linvn[dst] = old ? linv[src] : (i == n ? uj : 0.0);
+    if (i == 0) betan[(size_t)a * n1 + j] = fma(uj, sc[a], j < n ? beta[(size_t)a * n + j] : 0.0);
+}
+
 // T from externally supplied iK / beta (gpmpc_set_factors)
 __global__ __launch_bounds__(256) void tm_kernel(const double* __restrict__ iK, const double* __restrict__ beta, int N,
                                                  double* __restrict__ T) {
@@ -342,8 +449,16 @@ int grow(Handle* h, Buf& b, size_t need) {
     return GPMPC_OK;
 }
 
+static inline bool fits(const Buf& b, size_t need) { return b.p && need <= b.cap; }
+
 int ensure_model_buffers(Handle* h, int N, int D, int E, bool need_factor_ws) {
-    const size_t NN = (size_t)D * N * N, DN = (size_t)D * N, DE = (size_t)D * E, EN = (size_t)E * N;
+    // allocate with head-room for 64 more points: appended points then reuse the buffers (and their contents)
+    const size_t Nc = (size_t)N + 64;
+    const bool regrow = !fits(h->iK, (size_t)D * N * N) || !fits(h->Tm, (size_t)D * (N + kTPadRows) * N) ||
+                        !fits(h->beta, (size_t)D * N) || !fits(h->Xt, (size_t)E * N) ||
+                        (need_factor_ws && (!fits(h->gram, (size_t)D * N * N) || !fits(h->linv, (size_t)D * N * N)));
+    const size_t Ns = regrow ? Nc : (size_t)N;
+    const size_t NN = (size_t)D * Ns * Ns, DN = (size_t)D * Ns, DE = (size_t)D * E, EN = (size_t)E * Ns;
     int rc;
     if ((rc = grow(h, h->Xt, EN))) return rc;
     if ((rc = grow(h, h->ils2, DE))) return rc;
@@ -353,12 +468,19 @@ int ensure_model_buffers(Handle* h, int N, int D, int E, bool need_factor_ws) {
     if ((rc = grow(h, h->beta, DN))) return rc;
     if ((rc = grow(h, h->zvec, DN))) return rc;
     if ((rc = grow(h, h->iK, NN))) return rc;
-    if ((rc = grow(h, h->Tm, (size_t)D * (N + kTPadRows) * N))) return rc;      // + zero rows per GP
+    if ((rc = grow(h, h->Tm, (size_t)D * (Ns + kTPadRows) * Ns))) return rc;    // + zero rows per GP
     if (need_factor_ws) {
         if ((rc = grow(h, h->gram, NN))) return rc;
-        if ((rc = grow(h, h->linv, NN))) return rc;
+        if ((rc = grow(h, h->linv, (size_t)D * (Ns + kTPadRows) * Ns))) return rc;   // trades places with Tm in border updates
     }
+    if ((rc = grow(h, h->Xc, Ns * E))) return rc;
+    if ((rc = grow(h, h->Yc, Ns * D))) return rc;
+    if ((rc = grow(h, h->hyp, DE + 2 * (size_t)kMaxD))) return rc;
+    if ((rc = grow(h, h->kv, DN))) return rc;
+    if ((rc = grow(h, h->vv, DN))) return rc;
+    if ((rc = grow(h, h->sc, 2 * (size_t)kMaxD))) return rc;
     if (!h->info) GPMPC_HIP_CHECK(h, hipMalloc(&h->info, kMaxD * sizeof(int)));
+    if (!h->mismatch) GPMPC_HIP_CHECK(h, hipMalloc(&h->mismatch, sizeof(int)));
     return GPMPC_OK;
 }
 
@@ -382,14 +504,104 @@ int run_set_factors(Handle* h, const double* X, const double* iK, const double* 
     hipLaunchKernelGGL(tm_kernel, dim3((N + 63) / 64, (N + 3) / 4, D), dim3(256), 0, s, h->iK.p, h->beta.p, N, h->Tm.p);
     GPMPC_HIP_CHECK(h, hipGetLastError());
     h->N = N; h->D = D; h->E = E; h->ready = true;
+    h->have_state = false;                      // no (X, Y, hyper-parameters) record for these factors
     return GPMPC_OK;
+}
+
+// remember what the cached factors were computed from
+static int record_state(Handle* h, const double* X, const double* Y, const double* ls, const double* os,
+                        const double* noise, int N, int D, int E, hipStream_t s) {
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->Xc.p, X, (size_t)N * E * sizeof(double), hipMemcpyDeviceToDevice, s));
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->Yc.p, Y, (size_t)N * D * sizeof(double), hipMemcpyDeviceToDevice, s));
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->hyp.p, ls, (size_t)D * E * sizeof(double), hipMemcpyDeviceToDevice, s));
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->hyp.p + (size_t)D * E, os, D * sizeof(double), hipMemcpyDeviceToDevice, s));
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->hyp.p + (size_t)D * E + kMaxD, noise, D * sizeof(double), hipMemcpyDeviceToDevice, s));
+    h->have_state = true;
+    return GPMPC_OK;
+}
+
+static int check_info(Handle* h, int D, hipStream_t s) {
+    int info[kMaxD];
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(info, h->info, kMaxD * sizeof(int), hipMemcpyDeviceToHost, s));
+    GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
+    for (int a = 0; a < D; ++a) {
+        if (info[a] != 0) {
+            char buf[160];
+            snprintf(buf, sizeof buf, "cholesky: GP %d: leading minor of order %d of K + noise*I is not positive-definite",
+                     a, info[a]);
+            h->err = buf;
+            h->ready = false;
+            h->have_state = false;
+            return GPMPC_ERR_NOT_PD;
+        }
+    }
+    return GPMPC_OK;
+}
+
+// Border-update / reuse of the cached factors; returns 1 if it handled the call, 0 to fall through to the
+// full factorisation, < 0 on error.
+static int try_incremental(Handle* h, const double* X, const double* Y, const double* ls, const double* os,
+                           const double* noise, int N, int D, int E, hipStream_t s) {
+    if (!h->opt_incremental || !h->ready || !h->have_state || D != h->D || E != h->E) return 0;
+    const int n0 = h->N, k = N - n0;
+    if (k < 0 || k > 8 || h->inc_updates + k > h->opt_refresh_every) return 0;
+    const size_t NN = (size_t)D * N * N, DN = (size_t)D * N;
+    const size_t TN = (size_t)D * (N + kTPadRows) * N;
+    if (!fits(h->iK, NN) || !fits(h->gram, NN) || !fits(h->linv, TN) || !fits(h->beta, DN) || !fits(h->zvec, DN) ||
+        !fits(h->Tm, TN) || !fits(h->Xt, (size_t)E * N) || !fits(h->Xc, (size_t)N * E) ||
+        !fits(h->Yc, (size_t)N * D) || !fits(h->kv, DN) || !fits(h->vv, DN))
+        return 0;
+    // is the cached (X, Y, hyper-parameters) a prefix of the new one?
+    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->mismatch, 0, sizeof(int), s));
+    auto cmp = [&](const double* a, const double* b, size_t n) {
+        hipLaunchKernelGGL(prefix_mismatch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, n, h->mismatch);
+    };
+    cmp(X, h->Xc.p, (size_t)n0 * E);
+    cmp(Y, h->Yc.p, (size_t)n0 * D);
+    cmp(ls, h->hyp.p, (size_t)D * E);
+    cmp(os, h->hyp.p + (size_t)D * E, D);
+    cmp(noise, h->hyp.p + (size_t)D * E + kMaxD, D);
+    int flag = 1;
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(&flag, h->mismatch, sizeof(int), hipMemcpyDeviceToHost, s));
+    GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
+    if (flag) return 0;
+    if (k == 0) { h->last_prepare_mode = 2; return 1; }           // nothing changed: the factors are current
+    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->info, 0, kMaxD * sizeof(int), s));
+    for (int n = n0; n < N; ++n) {
+        hipLaunchKernelGGL(kvec_kernel, dim3((n + 255) / 256, D), dim3(256), 0, s, X, n, E, h->ils2.p, h->var.p, N, h->kv.p);
+        hipLaunchKernelGGL(border_lvec_kernel, dim3((n + 3) / 4, D), dim3(256), 0, s, h->linv.p, h->kv.p, n, N, h->vv.p);
+        hipLaunchKernelGGL(border_u_kernel, dim3((n + 64) / 64, D), dim3(1024), 0, s, h->linv.p, h->vv.p, n, N, h->var.p, noise,
+                           h->kv.p, h->info);                                        // u overwrites k
+        hipLaunchKernelGGL(border_dot_kernel, dim3(D), dim3(256), 0, s, h->kv.p, Y, n, D, N, h->sc.p);
+        hipLaunchKernelGGL(border_apply_kernel, dim3((n + 64) / 64, (n + 4) / 4, D), dim3(256), 0, s, h->iK.p, h->linv.p,
+                           h->beta.p, h->kv.p, h->sc.p, n, N, h->gram.p, h->Tm.p, h->zvec.p);
+        Buf t = h->iK; h->iK = h->gram; h->gram = t;
+        t = h->linv; h->linv = h->Tm; h->Tm = t;
+        t = h->beta; h->beta = h->zvec; h->zvec = t;
+    }
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    int rc = pack(h, X, ls, os, N, D, E, s);
+    if (rc) return rc;
+    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->Tm.p, 0, (size_t)D * (N + kTPadRows) * N * sizeof(double), s));
+    hipLaunchKernelGGL(tm_kernel, dim3((N + 63) / 64, (N + 3) / 4, D), dim3(256), 0, s, h->iK.p, h->beta.p, N, h->Tm.p);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    if ((rc = check_info(h, D, s))) return rc;
+    if ((rc = record_state(h, X, Y, ls, os, noise, N, D, E, s))) return rc;
+    h->N = N;
+    h->inc_updates += k;
+    h->last_prepare_mode = 1;
+    return 1;
 }
 
 int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, const double* os,
                 const double* noise, int N, int D, int E, hipStream_t s) {
-    int rc = ensure_model_buffers(h, N, D, E, true);
+    h->last_prepare_mode = 0;
+    int rc = try_incremental(h, X, Y, ls, os, noise, N, D, E, s);
+    if (rc != 0) return rc < 0 ? rc : GPMPC_OK;
+    rc = ensure_model_buffers(h, N, D, E, true);
     if (rc) return rc;
     h->ready = false;
+    h->have_state = false;
     if ((rc = pack(h, X, ls, os, N, D, E, s))) return rc;
     GPMPC_HIP_CHECK(h, hipMemsetAsync(h->info, 0, kMaxD * sizeof(int), s));
     GPMPC_HIP_CHECK(h, hipMemsetAsync(h->linv.p, 0, (size_t)D * N * N * sizeof(double), s));
@@ -421,18 +633,9 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     const int nt = (N + 31) / 32;
     hipLaunchKernelGGL(syrk_inverse_kernel, dim3(nt, nt, D), dim3(256), 0, s, h->linv.p, h->beta.p, N, h->iK.p, h->Tm.p);
     GPMPC_HIP_CHECK(h, hipGetLastError());
-    int info[kMaxD];
-    GPMPC_HIP_CHECK(h, hipMemcpyAsync(info, h->info, kMaxD * sizeof(int), hipMemcpyDeviceToHost, s));
-    GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
-    for (int a = 0; a < D; ++a) {
-        if (info[a] != 0) {
-            char buf[160];
-            snprintf(buf, sizeof buf, "cholesky: GP %d: leading minor of order %d of K + noise*I is not positive-definite",
-                     a, info[a]);
-            h->err = buf;
-            return GPMPC_ERR_NOT_PD;
-        }
-    }
+    if ((rc = check_info(h, D, s))) return rc;
+    if ((rc = record_state(h, X, Y, ls, os, noise, N, D, E, s))) return rc;
+    h->inc_updates = 0;
     h->N = N; h->D = D; h->E = E; h->ready = true;
     return GPMPC_OK;
 }

@@ -81,6 +81,11 @@ class HipEngine:
                                            nz.data_ptr(), N, D, E, self._stream()))
         self.N, self.D, self.E = N, D, E
 
+    @property
+    def last_prepare_mode(self):
+        """0 = full factorisation, 1 = border update of the cached factors, 2 = cache hit."""
+        return int(self.lib.gpmpc_last_prepare_mode(self._h))
+
     def set_factors(self, X, iK, beta, lengthscales, outputscales):
         X = self._dev(X)
         N, E = X.shape
@@ -99,11 +104,6 @@ class HipEngine:
         beta = torch.empty((self.D, self.N), dtype=torch.float64, device=self.device)
         self._check(self.lib.gpmpc_read_factors(self._h, iK.data_ptr(), beta.data_ptr(), self._stream()))
         return iK, beta
-
-    def gram(self):
-        p = C.c_void_p()
-        self._check(self.lib.gpmpc_get_gram(self._h, C.byref(p)))
-        return p.value
 
     # -- a6 ----------------------------------------------------------------------------
     def set_cost(self, target, W, W_T, kappa, clip_to_zero=False, state_min=None, state_max=None):

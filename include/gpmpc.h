@@ -64,6 +64,13 @@ int gpmpc_prepare(gpmpc_t* h, const double* X_dev, const double* Y_dev,
                   const double* lengthscales_dev, const double* outputscales_dev,
                   const double* noises_dev, int N, int D, int E, void* stream);
 
+/* How the last gpmpc_prepare obtained its factors: 0 = full factorisation, 1 = border update of the cached
+ * factors (the new memory was the cached one plus <= 8 appended points, hyper-parameters unchanged; O(k N^2)),
+ * 2 = cache hit (nothing changed).  The reference refactorises at every control step
+ * (gp_mpc_controller.py:117).  Option "incremental" (default 1) switches the reuse off, "refresh_every"
+ * (default 32) bounds the number of border updates between full factorisations. */
+int gpmpc_last_prepare_mode(gpmpc_t* h);
+
 /*
  * Same cached state as gpmpc_prepare but with iK (D,N,N) and beta (D,N) supplied by the
  * caller (test hook: lets the rollout kernel be checked in isolation from the
@@ -81,13 +88,10 @@ int gpmpc_get_factors(gpmpc_t* h, const double** iK_dev, const double** beta_dev
  * iK_dst_dev (D,N,N), beta_dst_dev (D,N).  Asynchronous on `stream`. */
 int gpmpc_read_factors(gpmpc_t* h, double* iK_dst_dev, double* beta_dst_dev, void* stream);
 
-/* Borrowed device pointer to the (D,N,N) Gram matrices K + noise*I of the last prepare
- * (diagnostics / tests).  Only valid when the handle was created with keep_gram, see
- * gpmpc_set_option. */
-int gpmpc_get_gram(gpmpc_t* h, const double** K_dev);
-
-/* Options: "keep_gram" (0/1, default 0), "threads" (rollout workgroup size: 0 = auto,
- * 256/512/1024), "force_global_scratch" (0/1, testing the large-N path at small N). */
+/* Options (measurement / test hooks): "threads" (rollout workgroup size: 0 = auto, 256/512/1024),
+ * "rows_per_chunk", "force_path" (0 auto / 1 direct exp / 2 element-wise Taylor), "force_separable",
+ * "force_global_scratch" (0/1, the large-N streaming kernel at any N), "incremental" (0/1, default 1),
+ * "refresh_every" (default 32). */
 int gpmpc_set_option(gpmpc_t* h, const char* name, long long value);
 
 /*

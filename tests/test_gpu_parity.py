@@ -99,6 +99,100 @@ def test_not_positive_definite_is_reported(engine):
         engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, np.zeros(2) - 1e-3)
 
 
+@pytest.mark.parametrize("N0,D,A,tm", [(40, 3, 1, False), (200, 3, 1, False), (130, 4, 2, True), (1, 2, 1, False)])
+def test_incremental_prepare_matches_full_factorisation(N0, D, A, tm):
+    """gp_mpc_controller.py:117 refactorises every control step although the memory only grew by a
+    point; gpmpc_prepare border-updates the cached inverse instead.  Same factors as a fresh
+    factorisation of the grown memory (fp64, 1e-8 -- the Cholesky-vs-reference tolerance)."""
+    import gp_mpc_amd
+    steps = [1, 1, 3, 1, 8, 2]
+    w = synth.make_workload(N0 + sum(steps), D, A, 4, 4, include_time=tm, seed=N0)
+    inc, full = gp_mpc_amd.HipEngine(0), gp_mpc_amd.HipEngine(0)
+    full.set_option("incremental", 0)
+    try:
+        n = N0
+        inc.prepare(w.X[:n], w.Y[:n], w.lengthscales, w.outputscales, w.noises)
+        assert inc.last_prepare_mode == 0
+        for k in steps:
+            n += k
+            inc.prepare(w.X[:n], w.Y[:n], w.lengthscales, w.outputscales, w.noises)
+            assert inc.last_prepare_mode == 1
+        full.prepare(w.X[:n], w.Y[:n], w.lengthscales, w.outputscales, w.noises)
+        assert full.last_prepare_mode == 0
+        iK, beta = inc.factors()
+        iK0, beta0 = full.factors()
+        assert rel_err(iK.cpu().numpy(), iK0.cpu().numpy()) < 1e-8
+        assert rel_err(beta.cpu().numpy(), beta0.cpu().numpy()) < 1e-8
+        iKn = iK.cpu().numpy()
+        assert np.array_equal(iKn, iKn.transpose(0, 2, 1))
+        iKo, betao = orc.factorize(w.X[:n], w.Y[:n], w.lengthscales, w.outputscales, w.noises)
+        assert rel_err(iKn, iKo) < 1e-8
+        # and the rollouts that consume them agree
+        for e in (inc, full):
+            e.set_cost(w.target, w.W, w.W_T, w.kappa)
+        a = inc.rollout(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+        b = full.rollout(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+        assert rel_err(a["mu"].cpu().numpy(), b["mu"].cpu().numpy()) < 1e-9
+        assert rel_err(a["Sig"].cpu().numpy(), b["Sig"].cpu().numpy()) < 1e-6
+        assert rel_err(a["J"].cpu().numpy(), b["J"].cpu().numpy()) < 1e-8
+    finally:
+        inc.close()
+        full.close()
+
+
+def test_prepare_reuse_rules():
+    """Cache hit only for identical inputs; any change of an old point, of Y, of a hyper-parameter, a
+    shrinking memory, more than 8 new points or the refresh interval force a full factorisation."""
+    import gp_mpc_amd
+    w = synth.make_workload(90, 3, 1, 3, 2, seed=5)
+    e = gp_mpc_amd.HipEngine(0)
+    try:
+        args = lambda n: (w.X[:n], w.Y[:n], w.lengthscales, w.outputscales, w.noises)   # noqa: E731
+        e.prepare(*args(60)); assert e.last_prepare_mode == 0
+        e.prepare(*args(60)); assert e.last_prepare_mode == 2
+        e.prepare(*args(61)); assert e.last_prepare_mode == 1
+        e.prepare(*args(60)); assert e.last_prepare_mode == 0          # shrank
+        e.prepare(*args(70)); assert e.last_prepare_mode == 0          # > 8 new points
+        X2 = w.X[:71].copy(); X2[5, 0] += 1e-9
+        e.prepare(X2, w.Y[:71], w.lengthscales, w.outputscales, w.noises); assert e.last_prepare_mode == 0
+        Y2 = w.Y[:72].copy(); Y2[0, 1] += 1e-12
+        e.prepare(X2[:71], Y2[:71], w.lengthscales, w.outputscales, w.noises); assert e.last_prepare_mode == 0
+        e.prepare(*args(72)); assert e.last_prepare_mode == 0          # old point differs from the cache
+        e.prepare(w.X[:73], w.Y[:73], w.lengthscales * 1.0000001, w.outputscales, w.noises); assert e.last_prepare_mode == 0
+        e.prepare(w.X[:74], w.Y[:74], w.lengthscales * 1.0000001, w.outputscales, w.noises); assert e.last_prepare_mode == 1
+        e.prepare(w.X[:75], w.Y[:75], w.lengthscales * 1.0000001, w.outputscales, w.noises * 2); assert e.last_prepare_mode == 0
+        e.set_option("refresh_every", 2)
+        modes = []
+        for n in range(76, 82):
+            e.prepare(w.X[:n], w.Y[:n], w.lengthscales * 1.0000001, w.outputscales, w.noises * 2)
+            modes.append(e.last_prepare_mode)
+        assert modes == [1, 1, 0, 1, 1, 0]
+        iK, beta = e.factors()
+        iKo, betao = orc.factorize(w.X[:81], w.Y[:81], w.lengthscales * 1.0000001, w.outputscales, w.noises * 2)
+        assert rel_err(iK.cpu().numpy(), iKo) < 1e-8 and rel_err(beta.cpu().numpy(), betao) < 1e-8
+        # set_factors drops the record: the next prepare factorises
+        e.set_factors(w.X[:81], iKo, betao, w.lengthscales, w.outputscales)
+        e.prepare(w.X[:81], w.Y[:81], w.lengthscales * 1.0000001, w.outputscales, w.noises * 2)
+        assert e.last_prepare_mode == 0
+    finally:
+        e.close()
+
+
+def test_incremental_update_reports_lost_positive_definiteness():
+    import gp_mpc_amd
+    w = synth.make_workload(41, 2, 1, 3, 2, seed=3)
+    w.X[:40] += 50.0 * np.arange(40)[:, None]       # far apart: K ~ outputscale * I, PD even with noise < 0
+    w.X[40] = w.X[3]                                 # the appended point duplicates an old one
+    e = gp_mpc_amd.HipEngine(0)
+    try:
+        nz = -0.1 * np.asarray(w.outputscales)
+        e.prepare(w.X[:40], w.Y[:40], w.lengthscales, w.outputscales, nz)
+        with pytest.raises(gp_mpc_amd.NotPositiveDefiniteError):
+            e.prepare(w.X, w.Y, w.lengthscales, w.outputscales, nz)
+    finally:
+        e.close()
+
+
 @pytest.mark.parametrize("threads", [256, 512, 1024])
 @pytest.mark.parametrize("force_global", [0, 1])
 def test_rollout_variants_agree(engine, threads, force_global):
