@@ -25,7 +25,7 @@ static void free_buf(Buf& b) {
 
 extern "C" {
 
-int gpmpc_abi_version(void) { return 5; }
+int gpmpc_abi_version(void) { return 6; }
 
 int gpmpc_create(gpmpc_t** out, int device_id) {
     if (!out) return GPMPC_ERR_ARG;
@@ -53,7 +53,7 @@ int gpmpc_destroy(gpmpc_t* g) {
     (void)hipSetDevice(h->device);
     Buf* all[] = {&h->Xt, &h->beta, &h->iK, &h->Tm, &h->ils2, &h->var, &h->logvar, &h->gram,
                   &h->linv, &h->zvec, &h->cost, &h->best, &h->xrange, &h->mono_w, &h->traj, &h->Xc, &h->Yc,
-                  &h->hyp, &h->kv, &h->vv, &h->sc};
+                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws};
     for (Buf* b : all) free_buf(*b);
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);
@@ -174,6 +174,20 @@ int gpmpc_rollout(gpmpc_t* g, const double* actions, const double* mu0, const do
     GPMPC_HIP_CHECK(H_(g), hipSetDevice(g->h.device));
     a.mu_out = mu_out; a.Sig_out = Sig_out; a.cm_out = cm_out; a.cv_out = cv_out; a.J_out = J_out;
     return launch_rollout(H_(g), a, (hipStream_t)stream);
+}
+
+int gpmpc_rollout_grad(gpmpc_t* g, const double* actions, const double* mu0, const double* S0, int B, int H, int A,
+                       int include_time, double time0, double* J_out, double* grad_out, double* mu_out, double* Sig_out,
+                       void* stream) {
+    if (!g) return GPMPC_ERR_ARG;
+    if (!grad_out) return bad(g, "null argument");
+    RolloutArgs a;
+    int rc = fill_args(g, a, actions, mu0, S0, B, H, A, include_time, time0);
+    if (rc) return rc;
+    if (A < 1) return bad(g, "gradient needs A >= 1");
+    GPMPC_HIP_CHECK(H_(g), hipSetDevice(g->h.device));
+    a.mu_out = mu_out; a.Sig_out = Sig_out; a.J_out = J_out;
+    return launch_rollout_grad(H_(g), a, grad_out, (hipStream_t)stream);
 }
 
 int gpmpc_rollout_timed(gpmpc_t* g, const double* actions, const double* mu0, const double* S0, int B, int H, int A,

@@ -89,6 +89,7 @@ struct Handle {
     Buf best;     // argmin result: [best_J, best_idx bits]
     Buf traj;     // (B, H+1, D) + (B, H+1, D, D) when the caller does not want the trajectory
     Buf xrange;   // (2, E) min / max of the inputs
+    Buf gradws;   // gradient workspace: pair moments | mean sums | cost variances
     // incremental factorisation: what the cached factors were computed from, and border-update scratch
     Buf Xc, Yc;   // (N, E), (N, D) copies of the memory points of the last prepare
     Buf hyp;      // lengthscales (D*E) | outputscales (D) | noises (D) of the last prepare
@@ -145,6 +146,8 @@ inline int allow_full_lds(Handle* h, const void* kernel) {
 // rollout.hip
 int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s);
 int launch_argmin(Handle* h, const double* J, int B, long long first, hipStream_t s);
+// grad.hip
+int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t s);
 int launch_argmin_to(Handle* h, const double* J, int B, long long first, const double* actions, int HA, double* out_dev,
                      hipStream_t s);
 // prepare.hip

@@ -1,0 +1,101 @@
+// grad.hip -- host-side dispatch of the analytic-gradient kernels (grad_kernels.h).
+#include "grad_kernels.h"
+#include <cstring>
+
+namespace gpmpc_hip {
+
+namespace {
+
+constexpr int kMomThreads = 512;
+constexpr int kSweepThreads = 256;
+
+template <int DP, int NXP>
+int launch_moments(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s) {
+    auto kern = pair_moments_kernel<DP, NXP, kMomThreads>;
+    int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(g.H, g.B), dim3(kMomThreads), lds_bytes, s, g);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    return GPMPC_OK;
+}
+
+template <int DP>
+int launch_moments_dp(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s) {
+    return g.NXP == 2 ? launch_moments<DP, 2>(h, g, lds_bytes, s) : launch_moments<DP, 6>(h, g, lds_bytes, s);
+}
+
+}  // namespace
+
+int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t s) {
+    const int N = a.N, D = a.D, A = a.A, E = a.E, H = a.H, B = a.B;
+    const int NX = E - D, P = D * (D + 1) / 2;
+    int DP = 0;
+    for (int v : {2, 3, 4, 6, 8}) if (D <= v) { DP = v; break; }
+    if (DP == 0 || NX > 6) { h->err = "gradient: supported for D <= 8 and A (+ time) <= 6"; return GPMPC_ERR_LIMIT; }
+    const int NXP = NX <= 2 ? 2 : 6;
+    const int RS = 2 + 2 * DP + NXP;
+    const int NSP = 1 + DP + DP * (DP + 1) / 2 + NXP;
+
+    GradArgs g;
+    memset(&g, 0, sizeof g);
+    // tiling of the pairwise pass: 64-row chunks, as many output pairs per group as the LDS holds
+    const int CH = (N >= 64) ? 64 : ((N + 3) & ~3);
+    const int RC = (N + CH - 1) / CH;
+    const int NR = RC * CH;
+    const int wpp = (RC * N + 63) / 64;
+    int G = 0;
+    size_t mom_lds = 0;
+    for (int gg = P; gg >= 1; --gg) {
+        const MomLayout L = make_mom_layout(N, D, E, gg, RS, NR, wpp, NSP);
+        if ((size_t)L.total * 8 <= (size_t)h->lds_limit) { G = gg; mom_lds = (size_t)L.total * 8; break; }
+    }
+    const int npr = 16;
+    const SweepLayout SL = make_sweep_layout(N, D, A, E, H, npr, kSweepThreads / 64);
+    if (G == 0 || (size_t)SL.total * 8 > (size_t)h->lds_limit) {
+        h->err = "gradient: N too large for the LDS-resident gradient kernels"; return GPMPC_ERR_LIMIT;
+    }
+    if ((unsigned long long)RC * N * N >= 0x100000000ULL || (unsigned long long)G * wpp * wpp >= 0x100000000ULL) {
+        h->err = "gradient: index range too large for the multiply-high division"; return GPMPC_ERR_LIMIT;
+    }
+    auto magic = [](unsigned d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + d - 1) / d); };
+
+    // workspace: moments, mean sums, cost variances (when the caller does not keep them)
+    const size_t n_mom = (size_t)B * H * P * NSP, n_ms = (size_t)B * H * D * (D + 1), n_cv = (size_t)B * (H + 1);
+    int rc = grow(h, h->gradws, n_mom + n_ms + n_cv);
+    if (rc) return rc;
+    g.mom = h->gradws.p;
+    g.msum = g.mom + n_mom;
+    if (!a.cv_out) a.cv_out = g.msum + n_ms;
+
+    rc = launch_rollout(h, a, s);            // forward: trajectory, costs, J
+    if (rc) return rc;
+
+    g.Xt = a.Xt; g.beta = a.beta; g.Tm = a.Tm; g.ils2 = a.ils2; g.var = a.var; g.logvar = a.logvar; g.cost = a.cost;
+    g.kappa = a.kappa; g.use_constraints = a.use_constraints;
+    g.actions = a.actions; g.mu = a.mu_out; g.Sig = a.Sig_out; g.cv = a.cv_out;
+    g.N = N; g.D = D; g.A = A; g.E = E; g.H = H; g.B = B; g.include_time = a.include_time; g.time0 = a.time0;
+    g.grad = grad_out;
+    g.DP = DP; g.NXP = NXP; g.NSP = NSP;
+    g.G = G; g.CH = CH; g.RC = RC; g.wpp = wpp;
+    g.magic_N = magic((unsigned)N); g.magic_wpp = magic((unsigned)wpp);
+    g.npr = npr;
+
+    switch (DP) {
+        case 2:  rc = launch_moments_dp<2>(h, g, mom_lds, s); break;
+        case 3:  rc = launch_moments_dp<3>(h, g, mom_lds, s); break;
+        case 4:  rc = launch_moments_dp<4>(h, g, mom_lds, s); break;
+        case 6:  rc = launch_moments_dp<6>(h, g, mom_lds, s); break;
+        default: rc = launch_moments_dp<8>(h, g, mom_lds, s); break;
+    }
+    if (rc) return rc;
+    {
+        auto kern = adjoint_sweep_kernel<kSweepThreads>;
+        rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(B), dim3(kSweepThreads), (size_t)SL.total * 8, s, g);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+    }
+    return GPMPC_OK;
+}
+
+}  // namespace gpmpc_hip

@@ -1,0 +1,722 @@
+// grad_kernels.h -- analytic gradient dJ/du of the mean-LCB objective (the reference obtains it by
+// torch autograd through predict_trajectory: gp_mpc_controller.py:277 `mean_cost.backward()`, :285).
+//
+// Two kernels after the forward rollout has stored the trajectory (mu_t, Sigma_t):
+//
+//  pair_moments_kernel  one workgroup per (candidate, horizon step) -- the steps are independent once the
+//      trajectory is known, so the N^2 work of the gradient is B*H-way parallel.  It re-evaluates the
+//      pairwise weights E_ij = T_ij exp(ka'_i + kb'_j + g_i . w_j) of gp_model.py:161-175 exactly as the
+//      forward kernel does and accumulates, per output pair (a, b), the moments of p_ij = u_i + w_j:
+//          W = sum E_ij, P1 = sum E_ij p_ij, P2 = sum E_ij p_ij p_ij^T, Pe = sum E_ij (nu_ie/l_ae^2 + nu_je/l_be^2)
+//      (all nu_i = x_i - m move together with the input mean, and Z = R^-1 Sigma enters the exponent as
+//      1/2 p^T Z p, so dW/dm and dW/dZ are these moments).  Lanes own columns j: column sums and the
+//      u_i-weighted column sums accumulate in registers, one wavefront reduction per work item.
+//  adjoint_sweep_kernel one workgroup per candidate, t = H-1 .. 0: D x D algebra on the stored moments plus
+//      one O(N D^2) pass over the points for the mean part (gp_model.py:140-153).
+//
+// CPU statement of the same algebra: oracle/adjoint.py (checked against torch autograd).
+#pragma once
+#include "rollout_kernel.h"
+
+namespace gpmpc_hip {
+
+struct GradArgs {
+    const double* Xt;      // (E, N)
+    const double* beta;    // (D, N)
+    const double* Tm;      // (D, N + kTPad, N)
+    const double* ils2;    // (D, E)
+    const double* var;     // (D)
+    const double* logvar;  // (D)
+    const double* cost;    // target | W | W_T | smin | smax
+    double kappa;
+    int use_constraints;
+    const double* actions;  // (B, H, A)
+    const double* mu;       // (B, H+1, D)     stored trajectory of the forward launch
+    const double* Sig;      // (B, H+1, D, D)
+    const double* cv;       // (B, H+1)        cost variances of the forward launch
+    int N, D, A, E, H, B;
+    int include_time;
+    double time0;
+    double* mom;     // (B, H, P, NSP)   [W | P1 (DP) | P2 upper triangle (DP (DP+1)/2) | Pe (NXP)]
+    double* msum;    // (B, H, D, D+1)   [sum lb | sum lb nu_d]
+    double* grad;    // (B, H, A)
+    int DP, NXP, NSP;
+    int G, CH, RC, wpp;
+    unsigned magic_N, magic_wpp;
+    int npr;         // small problems solved per round in the sweep (LDS sizing)
+};
+
+__host__ __device__ inline int tri_index(int d, int e, int DP) { return d * DP - (d * (d - 1)) / 2 + (e - d); }   // d <= e
+
+struct MomLayout {
+    int c_ils2, c_var, c_logvar, c_tab, m, Sig, aug, ints, nu, xe, lb, kb, rows, part, total;
+};
+
+__host__ __device__ inline MomLayout make_mom_layout(int N, int D, int E, int G, int RS, int NR, int wpp, int NSP) {
+    MomLayout L;
+    const int P = D * (D + 1) / 2;
+    int o = 0;
+    L.c_ils2 = o;   o += rnd2(D * E);
+    L.c_var = o;    o += rnd2(D);
+    L.c_logvar = o; o += rnd2(D);
+    L.c_tab = o;    o += 64;
+    L.m = o;        o += rnd2(E);
+    L.Sig = o;      o += rnd2(D * D);
+    L.aug = o;      o += (D + G) * 2 * D * D;
+    L.ints = o;     o += rnd2((2 * P + 2 + 1) / 2);
+    L.nu = o;       o += rnd2(D * N);
+    L.xe = o;       o += rnd2((E - D) * N);
+    L.lb = o;       o += rnd2(D * N);
+    L.kb = o;       o += rnd2(G * N);
+    L.rows = o;     o += G * NR * RS;
+    L.part = o;     o += rnd2(G * wpp * NSP);
+    L.total = o;
+    return L;
+}
+
+// ------------------------------------------------------------------------------------------
+template <int DP, int NXP, int NT>
+__global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NW = NT / kWave;
+    constexpr int RS = 2 + 2 * DP + NXP;     // row record: ka'_i, beta_ai, g_i (DP), u_i (DP), nu_ie / l_ae^2 (NXP)
+    constexpr int NH = DP * (DP + 1) / 2;
+    constexpr int NSP = 1 + DP + NH + NXP;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int t = blockIdx.x, c = blockIdx.y;
+    const int N = p.N, D = p.D, A = p.A, E = p.E, H = p.H, G = p.G;
+    const int NX = E - D;
+    const int P = D * (D + 1) / 2;
+    const int LD = 2 * D;
+    const int wpp = p.wpp;
+    const int NR = p.RC * p.CH;
+    const MomLayout L = make_mom_layout(N, D, E, G, RS, NR, wpp, NSP);
+    double* c_ils2 = smem + L.c_ils2;
+    double* c_logvar = smem + L.c_logvar;
+    double* c_tab = smem + L.c_tab;
+    double* s_m = smem + L.m;
+    double* s_Sig = smem + L.Sig;
+    double* s_aug = smem + L.aug;
+    int* s_pa = reinterpret_cast<int*>(smem + L.ints);
+    int* s_pb = s_pa + P;
+    int* s_counter = s_pb + P;
+    double* a_nu = smem + L.nu;
+    double* a_xe = smem + L.xe;
+    double* a_lb = smem + L.lb;
+    double* a_kb = smem + L.kb;
+    double* a_rows = smem + L.rows;
+    double* s_part = smem + L.part;
+
+    for (int i = tid; i < D; i += NT) c_logvar[i] = p.logvar[i];
+    for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
+    for (int i = tid; i < 64; i += NT) c_tab[i] = kExp2Tab[i];
+    for (int i = tid; i < E; i += NT) {
+        double v;
+        if (i < D) v = p.mu[((size_t)c * (H + 1) + t) * D + i];
+        else if (i < D + A) v = p.actions[((size_t)c * H + t) * A + (i - D)];
+        else v = p.time0 + (double)t;
+        s_m[i] = v;
+    }
+    for (int i = tid; i < D * D; i += NT) s_Sig[i] = p.Sig[((size_t)c * (H + 1) + t) * D * D + i];
+    for (int i = tid; i < G * (NR - N) * RS; i += NT) {
+        const int per = (NR - N) * RS;
+        const int gq = i / per, k = i - gq * per;
+        a_rows[((size_t)gq * NR + N) * RS + k] = 0.0;                      // zero padding rows
+    }
+    if (tid == 0) {
+        int q = 0;
+        for (int a = 0; a < D; ++a)
+            for (int b = a; b < D; ++b) { s_pa[q] = a; s_pb[q] = b; ++q; }
+    }
+    __syncthreads();
+
+    for (int i = tid; i < D * N; i += NT) a_nu[i] = p.Xt[i] - s_m[i / N];
+    for (int i = tid; i < NX * N; i += NT) a_xe[i] = p.Xt[(size_t)D * N + i] - s_m[D + i / N];
+    if (tid < D) {
+        const int a = tid;
+        double* aug = s_aug + a * (D * LD);
+        for (int i = 0; i < D; ++i)
+            for (int j = 0; j < D; ++j) {
+                aug[i * LD + j] = s_Sig[i * D + j] + (i == j ? 1.0 / c_ils2[a * E + i] : 0.0);
+                aug[i * LD + D + j] = (i == j ? 1.0 : 0.0);
+            }
+        (void)gauss_solve(aug, D, D, LD);
+    }
+    __syncthreads();
+
+    // mean part: lb_ai (gp_model.py:148) and its first moments
+    for (int it = tid; it < D * N; it += NT) {
+        const int a = it / N, pt = it - a * N;
+        const double* Ai = s_aug + a * (D * LD) + D;
+        double q = 0.0;
+        for (int i = 0; i < D; ++i) {
+            double r = 0.0;
+            for (int j = 0; j < D; ++j) r = fma(Ai[i * LD + j], a_nu[j * N + pt], r);
+            q = fma(a_nu[i * N + pt], r, q);
+        }
+        for (int x = 0; x < NX; ++x) {
+            const double v = a_xe[x * N + pt];
+            q = fma(v * v, c_ils2[a * E + D + x], q);
+        }
+        a_lb[it] = exp(-0.5 * q) * p.beta[it];
+    }
+    __syncthreads();
+    for (int task = wave; task < D * (D + 1); task += NW) {
+        const int a = task / (D + 1), dd = task - a * (D + 1);
+        double v = 0.0;
+        if (dd == 0) { for (int pt = lane; pt < N; pt += 64) v += a_lb[a * N + pt]; }
+        else { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt], a_nu[(dd - 1) * N + pt], v); }
+        v = wave_sum(v);
+        if (lane == 0) p.msum[(((size_t)c * H + t) * D + a) * (D + 1) + dd] = v;
+    }
+
+    for (int q0 = 0; q0 < P; q0 += G) {
+        const int Gc = (P - q0 < G) ? (P - q0) : G;
+        if (tid < Gc) {
+            const int gq = tid;
+            const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
+            double* aug = s_aug + (D + gq) * (D * LD);
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j < D; ++j) {
+                    const double dab = c_ils2[a * E + j] + c_ils2[b * E + j];
+                    aug[i * LD + j] = s_Sig[i * D + j] * dab + (i == j ? 1.0 : 0.0);      // R (:156-159)
+                    aug[i * LD + D + j] = s_Sig[i * D + j];
+                }
+            (void)gauss_solve(aug, D, D, LD);                                               // Z = R^-1 Sigma
+        }
+        if (tid == NT - 1) *s_counter = 0;
+        __syncthreads();
+
+        for (int it = tid; it < Gc * N; it += NT) {
+            const int gq = it / N, pt = it - gq * N;
+            const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
+            const double* Z = s_aug + (D + gq) * (D * LD) + D;
+            double u[DP], w[DP], g[DP];
+            double ksa = 0.0, ksb = 0.0;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                const double nu = (d < D) ? a_nu[d * N + pt] : 0.0;
+                u[d] = (d < D) ? nu * c_ils2[a * E + d] : 0.0;
+                w[d] = (d < D) ? nu * c_ils2[b * E + d] : 0.0;
+                ksa = fma(nu, u[d], ksa);
+                ksb = fma(nu, w[d], ksb);
+                g[d] = 0.0;
+            }
+            double* rec = a_rows + ((size_t)gq * NR + pt) * RS;
+#pragma unroll
+            for (int x = 0; x < NXP; ++x) {
+                const double v = (x < NX) ? a_xe[x * N + pt] : 0.0;
+                const double ia = (x < NX) ? c_ils2[a * E + D + x] : 0.0;
+                const double ib = (x < NX) ? c_ils2[b * E + D + x] : 0.0;
+                ksa = fma(v * v, ia, ksa);
+                ksb = fma(v * v, ib, ksb);
+                rec[2 + 2 * DP + x] = v * ia;
+            }
+            double qa = 0.0, qb = 0.0;
+#pragma unroll
+            for (int i = 0; i < DP; ++i) {
+                if (i < D) {
+                    double zu = 0.0, zw = 0.0;
+#pragma unroll
+                    for (int j = 0; j < DP; ++j)
+                        if (j < D) {
+                            const double z = Z[i * LD + j];
+                            zu = fma(z, u[j], zu);
+                            zw = fma(z, w[j], zw);
+                            g[j] = fma(z, u[i], g[j]);
+                        }
+                    qa = fma(u[i], zu, qa);
+                    qb = fma(w[i], zw, qb);
+                }
+            }
+            rec[0] = c_logvar[a] - 0.5 * ksa + 0.5 * qa;
+            rec[1] = p.beta[a * N + pt];
+#pragma unroll
+            for (int d = 0; d < DP; ++d) { rec[2 + d] = g[d]; rec[2 + DP + d] = u[d]; }
+            a_kb[gq * N + pt] = c_logvar[b] - 0.5 * ksb + 0.5 * qb;
+        }
+        __syncthreads();
+
+        const int total = Gc * wpp;
+        auto pull_item = [&]() -> int {
+            int pulled = 0;
+            if (lane == 0) pulled = __hip_atomic_fetch_add(s_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            return __builtin_amdgcn_readfirstlane(pulled);
+        };
+        for (int wi = pull_item(); wi < total; wi = pull_item()) {
+            const int gq = p.magic_wpp ? (int)__umulhi((unsigned)wi, p.magic_wpp) : wi;
+            const int slot = wi - gq * wpp;
+            const int a = __builtin_amdgcn_readfirstlane(s_pa[q0 + gq]);
+            const int b = __builtin_amdgcn_readfirstlane(s_pb[q0 + gq]);
+            const bool diag = (a == b);
+            const int flat = slot * 64 + lane;
+            const bool valid = flat < p.RC * N;
+            const int r = valid ? (p.magic_N ? (int)__umulhi((unsigned)flat, p.magic_N) : flat) : 0;
+            const int j = valid ? flat - r * N : 0;
+            const int i0 = r * p.CH;
+            int i1 = i0 + p.CH;
+            if (i1 > N) i1 = N;
+            if (diag && i1 > j + 1) i1 = j + 1;
+            const int len = (valid && i1 > i0) ? (i1 - i0) : 0;
+            const int nrows = (wave_max_i32(len) + 3) & ~3;
+            double cs = 0.0, h[DP + NXP], hh[NH];
+#pragma unroll
+            for (int d = 0; d < DP + NXP; ++d) h[d] = 0.0;
+#pragma unroll
+            for (int k = 0; k < NH; ++k) hh[k] = 0.0;
+            double w[DP];
+#pragma unroll
+            for (int d = 0; d < DP; ++d) w[d] = (d < D) ? a_nu[d * N + j] * c_ils2[b * E + d] : 0.0;
+            if (nrows > 0) {
+                const double kbj = a_kb[gq * N + j];
+                const double* rec = a_rows + ((size_t)gq * NR + i0) * RS;
+                const double* Tp = p.Tm + ((size_t)a * (N + kTPad) + i0) * N + j;
+                for (int it = 0; it < nrows; it += 2) {
+                    double e[2];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const double* rr = rec + q * RS;
+                        double arg = rr[0] + kbj;
+#pragma unroll
+                        for (int d = 0; d < DP; ++d) arg = fma(rr[2 + d], w[d], arg);
+                        const double wt = diag ? Tp[(size_t)q * N] : rr[1];
+                        e[q] = fast_exp(arg, c_tab) * wt;
+                    }
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const double* rr = rec + q * RS;
+                        cs += e[q];
+                        int k = 0;
+#pragma unroll
+                        for (int d = 0; d < DP; ++d) {
+                            const double td = e[q] * rr[2 + DP + d];
+                            h[d] += td;
+#pragma unroll
+                            for (int d2 = d; d2 < DP; ++d2) { hh[k] = fma(td, rr[2 + DP + d2], hh[k]); ++k; }
+                        }
+#pragma unroll
+                        for (int x = 0; x < NXP; ++x) h[DP + x] = fma(e[q], rr[2 + 2 * DP + x], h[DP + x]);
+                    }
+                    rec += 2 * RS;
+                    Tp += (size_t)2 * N;
+                }
+            }
+            // column factor; for a diagonal pair only i <= j was visited with a halved diagonal of T and every
+            // moment is symmetric under i <-> j, so the factor is 2
+            const double colf = valid ? (diag ? 2.0 : p.beta[b * N + j]) : 0.0;
+            double* out = s_part + (size_t)wi * NSP;
+            {
+                const double v = wave_sum(valid ? cs * colf : 0.0);
+                if (lane == 0) out[0] = v;
+            }
+            int k = 0;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                const double v1 = wave_sum(valid ? (h[d] + cs * w[d]) * colf : 0.0);
+                if (lane == 0) out[1 + d] = v1;
+#pragma unroll
+                for (int d2 = d; d2 < DP; ++d2) {
+                    const double v2 = hh[k] + cs * w[d] * w[d2] + h[d] * w[d2] + w[d] * h[d2];
+                    const double s2 = wave_sum(valid ? v2 * colf : 0.0);
+                    if (lane == 0) out[1 + DP + k] = s2;
+                    ++k;
+                }
+            }
+#pragma unroll
+            for (int x = 0; x < NXP; ++x) {
+                const double xb = (x < NX) ? a_xe[x * N + j] * c_ils2[b * E + D + x] : 0.0;
+                const double v = wave_sum(valid ? (h[DP + x] + cs * xb) * colf : 0.0);
+                if (lane == 0) out[1 + DP + NH + x] = v;
+            }
+        }
+        __syncthreads();
+
+        for (int task = wave; task < Gc * NSP; task += NW) {
+            const int gq = task / NSP, k = task - gq * NSP;
+            double v = 0.0;
+            for (int s = lane; s < wpp; s += 64) v += s_part[((size_t)gq * wpp + s) * NSP + k];
+            v = wave_sum(v);
+            if (lane == 0) p.mom[((((size_t)c * H + t) * P) + q0 + gq) * NSP + k] = v;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+struct SweepLayout {
+    int c_ils2, c_var, cost, gmu, gSig, gu, ctmp, mubar, Sigbar, Sacc, mbar, m, Sig, Ai, cc, s0, s1, M, y, V, Sb, Vb, Mb, cb, s0b,
+        s1b, Gs, Ab, mba, Ri, Z, rdet, Kq, mq, aug, om, total;
+};
+
+__host__ __device__ inline SweepLayout make_sweep_layout(int N, int D, int A, int E, int H, int npr, int nwaves) {
+    SweepLayout L;
+    const int P = D * (D + 1) / 2, DD = D * D, n = D + A, NX = E - D;
+    int o = 0;
+    auto take = [&](int& f, int sz) { f = o; o += rnd2(sz); };
+    take(L.c_ils2, D * E); take(L.c_var, D); take(L.cost, n + n * n + DD + 2 * D);
+    take(L.gmu, (H + 1) * D); take(L.gSig, (H + 1) * DD); take(L.gu, H * A); take(L.ctmp, nwaves * (2 * n * n + 3 * n));
+    take(L.mubar, D); take(L.Sigbar, DD); take(L.Sacc, DD); take(L.mbar, E);
+    take(L.m, E); take(L.Sig, DD); take(L.Ai, D * DD); take(L.cc, D); take(L.s0, D); take(L.s1, DD); take(L.M, D);
+    take(L.y, DD); take(L.V, DD); take(L.Sb, DD); take(L.Vb, DD); take(L.Mb, D); take(L.cb, D); take(L.s0b, D); take(L.s1b, DD);
+    take(L.Gs, D * (D + DD + NX)); take(L.Ab, D * DD); take(L.mba, D * E);
+    take(L.Ri, P * DD); take(L.Z, P * DD); take(L.rdet, P); take(L.Kq, P * DD); take(L.mq, P * E);
+    take(L.aug, npr * D * 3 * D); take(L.om, D * N);
+    L.total = o;
+    return L;
+}
+
+// Partials of the stage cost (setpoint_distance_reward_mapper.py:36-66; terminal :135-141) wrt (mu, Sigma, u),
+// already weighted by dJ/dcm = 1/(H+1), dJ/dcv = -kappa / (2 sqrt(cv) (H+1)) (gp_mpc_controller.py:270-276).
+// One wavefront per time step; `tmp` is that wave's scratch (2 n^2 + 3 n doubles).
+__device__ inline void cost_adjoint_wave(int lane, int D, int A, bool terminal, const double* mu, const double* Sg, const double* act,
+                                         const double* target, const double* Wm, const double* smin, const double* smax,
+                                         bool use_constraints, double wm, double wv, double* tmp, double* gmu, double* gSig,
+                                         double* gu) {
+    const int n = terminal ? D : D + A;
+    double* WS = tmp;            // W Sa  (n x n, Sa = state block)
+    double* Gm = WS + n * n;     // W Sa W
+    double* err = Gm + n * n;
+    double* We = err + n;
+    double* WTe = We + n;
+    for (int i = lane; i < n; i += 64) err[i] = (i < D ? mu[i] : act[i - D]) - target[i];
+    for (int idx = lane; idx < n * n; idx += 64) {
+        const int i = idx / n, j = idx - i * n;
+        double v = 0.0;
+        if (j < D)
+            for (int k = 0; k < D; ++k) v = fma(Wm[i * n + k], Sg[k * D + j], v);
+        WS[idx] = v;
+    }
+    wave_lds_sync();
+    for (int idx = lane; idx < n * n; idx += 64) {
+        const int i = idx / n, j = idx - i * n;
+        double v = 0.0;
+        for (int k = 0; k < D; ++k) v = fma(WS[i * n + k], Wm[k * n + j], v);
+        Gm[idx] = v;
+    }
+    for (int i = lane; i < n; i += 64) {
+        double a = 0.0, b = 0.0;
+        for (int k = 0; k < n; ++k) { a = fma(Wm[i * n + k], err[k], a); b = fma(Wm[k * n + i], err[k], b); }
+        We[i] = a; WTe[i] = b;
+    }
+    wave_lds_sync();
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int i = idx / D, j = idx - i * D;
+        // d cm / d Sa = W^T;  d cv / d Sa = 4 (W Sa W)^T + 4 (W^T e)(W e)^T
+        double v = wm * Wm[j * n + i] + wv * 4.0 * (Gm[j * n + i] + WTe[i] * We[j]);
+        if (use_constraints && !terminal && i == j) {
+            const double sq = Sg[i * D + i];                 // the reference passes the variance as sigma (:60-64)
+            const double zmin = (smin[i] - mu[i]) / sq, zmax = (smax[i] - mu[i]) / sq;
+            const double pmin = exp(-0.5 * zmin * zmin) * 0.3989422804014327, pmax = exp(-0.5 * zmax * zmax) * 0.3989422804014327;
+            v += wm * (-pmin * zmin + pmax * zmax) / sq;
+        }
+        gSig[idx] = v;
+    }
+    for (int i = lane; i < n; i += 64) {
+        double v = 0.0;
+        for (int k = 0; k < n; ++k) v = fma(Gm[i * n + k] + Gm[k * n + i], err[k], v);
+        v = wm * (We[i] + WTe[i]) + wv * 4.0 * v;
+        if (i < D) {
+            if (use_constraints && !terminal) {
+                const double sq = Sg[i * D + i];
+                const double zmin = (smin[i] - mu[i]) / sq, zmax = (smax[i] - mu[i]) / sq;
+                v += wm * (-exp(-0.5 * zmin * zmin) + exp(-0.5 * zmax * zmax)) * 0.3989422804014327 / sq;
+            }
+            gmu[i] = v;
+        } else {
+            gu[i - D] = v;
+        }
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NW = NT / kWave;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c = blockIdx.x;
+    const int N = p.N, D = p.D, A = p.A, E = p.E, H = p.H;
+    const int NX = E - D, P = D * (D + 1) / 2, DD = D * D, n = D + A;
+    const int DP = p.DP, NSP = p.NSP, NH = DP * (DP + 1) / 2;
+    const int NG = D + DD + NX;
+    const int LD3 = 3 * D;
+    const SweepLayout L = make_sweep_layout(N, D, A, E, H, p.npr, NW);
+    double* c_ils2 = smem + L.c_ils2; double* c_var = smem + L.c_var; double* c_cost = smem + L.cost;
+    double* gmu = smem + L.gmu; double* gSig = smem + L.gSig; double* gu = smem + L.gu; double* ctmp = smem + L.ctmp;
+    double* mubar = smem + L.mubar; double* Sigbar = smem + L.Sigbar; double* Sacc = smem + L.Sacc; double* mbar = smem + L.mbar;
+    double* s_m = smem + L.m; double* s_Sig = smem + L.Sig; double* s_Ai = smem + L.Ai; double* s_cc = smem + L.cc;
+    double* s_s0 = smem + L.s0; double* s_s1 = smem + L.s1; double* s_M = smem + L.M; double* s_y = smem + L.y; double* s_V = smem + L.V;
+    double* s_Sb = smem + L.Sb; double* s_Vb = smem + L.Vb; double* s_Mb = smem + L.Mb; double* s_cb = smem + L.cb;
+    double* s_s0b = smem + L.s0b; double* s_s1b = smem + L.s1b; double* s_Gs = smem + L.Gs; double* s_Ab = smem + L.Ab;
+    double* s_mba = smem + L.mba; double* s_Ri = smem + L.Ri; double* s_Z = smem + L.Z; double* s_rdet = smem + L.rdet;
+    double* s_Kq = smem + L.Kq; double* s_mq = smem + L.mq; double* s_aug = smem + L.aug; double* a_om = smem + L.om;
+    const double* target = c_cost;
+    const double* Wst = c_cost + n;
+    const double* WT = Wst + n * n;
+    const double* smin = WT + DD;
+    const double* smax = smin + D;
+    const double* traj_mu = p.mu + (size_t)c * (H + 1) * D;
+    const double* traj_Sig = p.Sig + (size_t)c * (H + 1) * DD;
+    const double* act = p.actions + (size_t)c * H * A;
+    const double* cvv = p.cv + (size_t)c * (H + 1);
+    const double inv_n = 1.0 / (double)(H + 1);
+
+    for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
+    for (int i = tid; i < D; i += NT) c_var[i] = p.var[i];
+    for (int i = tid; i < n + n * n + DD + 2 * D; i += NT) c_cost[i] = p.cost[i];
+    __syncthreads();
+    // cost adjoints of every time step (independent of the sweep): one wavefront per step
+    for (int t = wave; t <= H; t += NW) {
+        const bool terminal = (t == H);
+        const double wv = -p.kappa / (2.0 * sqrt(cvv[t])) * inv_n;
+        cost_adjoint_wave(lane, D, A, terminal, traj_mu + t * D, traj_Sig + t * DD, act + (terminal ? 0 : t) * A, target,
+                          terminal ? WT : Wst, smin, smax, p.use_constraints != 0, inv_n, wv, ctmp + wave * (2 * n * n + 3 * n),
+                          gmu + t * D, gSig + t * DD, terminal ? ctmp + wave * (2 * n * n + 3 * n) : gu + t * A);
+        wave_lds_sync();
+    }
+    __syncthreads();
+    for (int i = tid; i < D; i += NT) mubar[i] = gmu[H * D + i];
+    for (int i = tid; i < DD; i += NT) {
+        const int r = i / D, q = i - r * D;
+        Sigbar[i] = 0.5 * (gSig[H * DD + i] + gSig[H * DD + q * D + r]);
+    }
+    __syncthreads();
+
+    for (int t = H - 1; t >= 0; --t) {
+        const double* mom = p.mom + ((size_t)c * H + t) * P * NSP;
+        const double* ms = p.msum + ((size_t)c * H + t) * D * (D + 1);
+        // ---- reload the forward state of step t ------------------------------------------------
+        for (int i = tid; i < E; i += NT) {
+            double v;
+            if (i < D) v = traj_mu[t * D + i];
+            else if (i < D + A) v = act[t * A + (i - D)];
+            else v = p.time0 + (double)t;
+            s_m[i] = v;
+        }
+        for (int i = tid; i < DD; i += NT) s_Sig[i] = traj_Sig[t * DD + i];
+        for (int i = tid; i < D * (D + 1); i += NT) {
+            const int a = i / (D + 1), dd = i - a * (D + 1);
+            if (dd == 0) s_s0[a] = ms[i]; else s_s1[a * D + dd - 1] = ms[i];
+        }
+        __syncthreads();
+        // ---- small solves: A_a^-1, det A_a;  R_ab^-1, Z_ab, det R_ab -----------------------------
+        for (int base = 0; base < D + P; base += p.npr) {
+            const int prob = base + tid;
+            if (tid < p.npr && prob < D + P) {
+                double* aug = s_aug + tid * (D * LD3);
+                if (prob < D) {
+                    const int a = prob;
+                    double prodil = 1.0;
+                    for (int i = 0; i < D; ++i) {
+                        prodil *= c_ils2[a * E + i];
+                        for (int j = 0; j < D; ++j) {
+                            aug[i * LD3 + j] = s_Sig[i * D + j] + (i == j ? 1.0 / c_ils2[a * E + i] : 0.0);
+                            aug[i * LD3 + D + j] = (i == j ? 1.0 : 0.0);
+                        }
+                    }
+                    const double det = gauss_solve(aug, D, D, LD3);
+                    for (int i = 0; i < D; ++i)
+                        for (int j = 0; j < D; ++j) s_Ai[a * DD + i * D + j] = aug[i * LD3 + D + j];
+                    s_cc[a] = c_var[a] / sqrt(det * prodil);
+                } else {
+                    const int q = prob - D;
+                    int a = 0, rem = q;
+                    while (rem >= D - a) { rem -= D - a; ++a; }
+                    const int b = a + rem;
+                    for (int i = 0; i < D; ++i)
+                        for (int j = 0; j < D; ++j) {
+                            const double dab = c_ils2[a * E + j] + c_ils2[b * E + j];
+                            aug[i * LD3 + j] = s_Sig[i * D + j] * dab + (i == j ? 1.0 : 0.0);
+                            aug[i * LD3 + D + j] = (i == j ? 1.0 : 0.0);
+                            aug[i * LD3 + 2 * D + j] = s_Sig[i * D + j];
+                        }
+                    const double det = gauss_solve(aug, D, 2 * D, LD3);
+                    for (int i = 0; i < D; ++i)
+                        for (int j = 0; j < D; ++j) {
+                            s_Ri[q * DD + i * D + j] = aug[i * LD3 + D + j];
+                            s_Z[q * DD + i * D + j] = aug[i * LD3 + 2 * D + j];
+                        }
+                    s_rdet[q] = 1.0 / sqrt(det);
+                }
+            }
+            __syncthreads();
+        }
+        // ---- M, y = A^-1 s1, V;  symmetric Sigma_bar' ----------------------------------------------
+        for (int i = tid; i < DD; i += NT) {
+            const int a = i / D, k = i - a * D;
+            double v = 0.0;
+            for (int j = 0; j < D; ++j) v = fma(s_Ai[a * DD + k * D + j], s_s1[a * D + j], v);
+            s_y[a * D + k] = v;
+            s_V[k * D + a] = s_cc[a] * v;
+            const int r = a, q = k;
+            s_Sb[r * D + q] = 0.5 * (Sigbar[r * D + q] + Sigbar[q * D + r]);
+        }
+        for (int a = tid; a < D; a += NT) s_M[a] = s_cc[a] * s_s0[a];
+        __syncthreads();
+        // ---- Sigma' = Sigma + S + Sigma V + (Sigma V)^T,  mu' = mu + M,  S -= M M^T ------------------
+        for (int i = tid; i < DD; i += NT) {
+            const int r = i / D, q = i - r * D;
+            double acc = s_Sb[i], vb = 0.0;
+            for (int k = 0; k < D; ++k) {
+                acc = fma(2.0 * s_Sb[r * D + k], s_V[q * D + k], acc);        // (C_bar V^T)[r][q]
+                vb = fma(s_Sig[r * D + k], 2.0 * s_Sb[k * D + q], vb);        // V_bar = Sigma C_bar
+            }
+            Sacc[i] = acc;
+            s_Vb[i] = vb;
+        }
+        for (int a = tid; a < D; a += NT) {
+            double v = mubar[a];
+            for (int b = 0; b < D; ++b) v = fma(-2.0 * s_Sb[a * D + b], s_M[b], v);
+            s_Mb[a] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < DD; i += NT) {
+            const int a = i / D, k = i - a * D;
+            double v = 0.0;
+            for (int j = 0; j < D; ++j) v = fma(s_Ai[a * DD + k * D + j], s_Vb[j * D + a], v);
+            s_s1b[a * D + k] = s_cc[a] * v;                                      // s1_bar = c A^-1 v_bar
+        }
+        for (int a = tid; a < D; a += NT) {
+            double v = s_Mb[a] * s_s0[a];
+            for (int k = 0; k < D; ++k) v = fma(s_Vb[k * D + a], s_y[a * D + k], v);
+            s_cb[a] = v;                                                         // c_bar
+            s_s0b[a] = s_Mb[a] * s_cc[a];
+        }
+        __syncthreads();
+        // ---- mean part over the points: q_bar_i = -1/2 lb_i (s0_bar + s1_bar . nu_i) -----------------
+        for (int it = tid; it < D * N; it += NT) {
+            const int a = it / N, pt = it - a * N;
+            double nu[kMaxD];
+            for (int d = 0; d < D; ++d) nu[d] = p.Xt[(size_t)d * N + pt] - s_m[d];
+            double q = 0.0, lin = s_s0b[a];
+            for (int i = 0; i < D; ++i) {
+                double r = 0.0;
+                for (int j = 0; j < D; ++j) r = fma(s_Ai[a * DD + i * D + j], nu[j], r);
+                q = fma(nu[i], r, q);
+                lin = fma(s_s1b[a * D + i], nu[i], lin);
+            }
+            for (int x = 0; x < NX; ++x) {
+                const double v = p.Xt[(size_t)(D + x) * N + pt] - s_m[D + x];
+                q = fma(v * v, c_ils2[a * E + D + x], q);
+            }
+            a_om[it] = -0.5 * exp(-0.5 * q) * p.beta[it] * lin;
+        }
+        __syncthreads();
+        for (int task = wave; task < D * NG; task += NW) {
+            const int a = task / NG, k = task - a * NG;
+            double v = 0.0;
+            if (k < D) {
+                for (int pt = lane; pt < N; pt += 64) v = fma(a_om[a * N + pt], p.Xt[(size_t)k * N + pt] - s_m[k], v);
+            } else if (k < D + DD) {
+                const int d1 = (k - D) / D, d2 = (k - D) - d1 * D;
+                for (int pt = lane; pt < N; pt += 64)
+                    v = fma(a_om[a * N + pt] * (p.Xt[(size_t)d1 * N + pt] - s_m[d1]), p.Xt[(size_t)d2 * N + pt] - s_m[d2], v);
+            } else {
+                const int x = k - D - DD;
+                for (int pt = lane; pt < N; pt += 64) v = fma(a_om[a * N + pt], p.Xt[(size_t)(D + x) * N + pt] - s_m[D + x], v);
+            }
+            v = wave_sum(v);
+            if (lane == 0) s_Gs[a * NG + k] = v;
+        }
+        __syncthreads();
+        // ---- per output a: A_bar, m_bar contribution;  per pair: K_q, m_q -----------------------------
+        for (int task = tid; task < D + P; task += NT) {
+            if (task < D) {
+                const int a = task;
+                const double* Ai = s_Ai + a * DD;
+                const double* G1 = s_Gs + a * NG;
+                const double* G2 = G1 + D;
+                const double* Ge = G2 + DD;
+                double* Ab = s_Ab + a * DD;
+                // Ai_bar = sym(c v_bar s1^T) + G2;  A_bar = -Ai Ai_bar Ai - 1/2 c_bar c Ai
+                for (int i = 0; i < D; ++i)
+                    for (int j = 0; j < D; ++j) {
+                        double v = 0.0;
+                        for (int k = 0; k < D; ++k)
+                            for (int l = 0; l < D; ++l) {
+                                const double aib = 0.5 * s_cc[a] * (s_Vb[k * D + a] * s_s1[a * D + l] + s_Vb[l * D + a] * s_s1[a * D + k])
+                                                   + 0.5 * (G2[k * D + l] + G2[l * D + k]);
+                                v = fma(Ai[i * D + k] * aib, Ai[l * D + j], v);
+                            }
+                        Ab[i * D + j] = -v - 0.5 * s_cb[a] * s_cc[a] * Ai[i * D + j];
+                    }
+                for (int e = 0; e < E; ++e) {
+                    double v;
+                    if (e < D) {
+                        double r = 0.0;
+                        for (int k = 0; k < D; ++k) r = fma(Ai[e * D + k], G1[k], r);
+                        v = -(s_s0[a] * s_s1b[a * D + e] + 2.0 * r);
+                    } else {
+                        v = -2.0 * c_ils2[a * E + e] * Ge[e - D];
+                    }
+                    s_mba[a * E + e] = v;
+                }
+            } else {
+                const int q = task - D;
+                int a = 0, rem = q;
+                while (rem >= D - a) { rem -= D - a; ++a; }
+                const int b = a + rem;
+                const double* mo = mom + (size_t)q * NSP;
+                const double* Ri = s_Ri + q * DD;
+                const double* Z = s_Z + q * DD;
+                const double sb = (a == b) ? s_Sb[a * D + a] : 2.0 * s_Sb[a * D + b];
+                const double Wb = sb * s_rdet[q];
+                const double coef = -0.5 * sb * mo[0] * s_rdet[q];
+                double* Kq = s_Kq + q * DD;
+                // Zb = 1/2 Wb P2 (symmetric);  RZ = Ri^T Zb;  Rb = coef Ri^T - RZ Z^T;  K = RZ + Rb diag(dab)
+                for (int i = 0; i < D; ++i)
+                    for (int j = 0; j < D; ++j) {
+                        double rz_ij = 0.0, rzzt = 0.0;
+                        for (int k = 0; k < D; ++k) {
+                            const int lo = k < j ? k : j, hi = k < j ? j : k;
+                            rz_ij = fma(Ri[k * D + i], 0.5 * Wb * mo[1 + DP + tri_index(lo, hi, DP)], rz_ij);
+                        }
+                        for (int l = 0; l < D; ++l) {
+                            double rz_il = 0.0;
+                            for (int k = 0; k < D; ++k) {
+                                const int lo = k < l ? k : l, hi = k < l ? l : k;
+                                rz_il = fma(Ri[k * D + i], 0.5 * Wb * mo[1 + DP + tri_index(lo, hi, DP)], rz_il);
+                            }
+                            rzzt = fma(rz_il, Z[j * D + l], rzzt);
+                        }
+                        const double dab = c_ils2[a * E + j] + c_ils2[b * E + j];
+                        Kq[i * D + j] = rz_ij + (coef * Ri[j * D + i] - rzzt) * dab;
+                    }
+                for (int e = 0; e < E; ++e) {
+                    double v;
+                    if (e < D) {
+                        double zp = 0.0;
+                        for (int k = 0; k < D; ++k) zp = fma(Z[e * D + k], mo[1 + k], zp);
+                        v = Wb * (mo[1 + e] - (c_ils2[a * E + e] + c_ils2[b * E + e]) * zp);
+                    } else {
+                        v = Wb * mo[1 + DP + NH + (e - D)];
+                    }
+                    s_mq[q * E + e] = v;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- assemble (fixed order) -------------------------------------------------------------------
+        for (int i = tid; i < DD; i += NT) {
+            double v = Sacc[i];
+            for (int a = 0; a < D; ++a) v += s_Ab[a * DD + i];
+            for (int q = 0; q < P; ++q) v += s_Kq[q * DD + i];
+            Sacc[i] = v;
+        }
+        for (int e = tid; e < E; e += NT) {
+            double v = (e < D) ? mubar[e] : 0.0;
+            for (int a = 0; a < D; ++a) v += s_mba[a * E + e];
+            for (int q = 0; q < P; ++q) v += s_mq[q * E + e];
+            mbar[e] = v;
+        }
+        __syncthreads();
+        for (int i = tid; i < DD; i += NT) {
+            const int r = i / D, q = i - r * D;
+            Sigbar[i] = 0.5 * (Sacc[i] + Sacc[q * D + r]) + 0.5 * (gSig[t * DD + i] + gSig[t * DD + q * D + r]);
+        }
+        for (int i = tid; i < D; i += NT) mubar[i] = mbar[i] + gmu[t * D + i];
+        for (int i = tid; i < A; i += NT) p.grad[((size_t)c * H + t) * A + i] = mbar[D + i] + gu[t * A + i];
+        __syncthreads();
+    }
+}
+
+}  // namespace gpmpc_hip
