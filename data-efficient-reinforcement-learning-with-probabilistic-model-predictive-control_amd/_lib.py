@@ -44,7 +44,7 @@ SIGNATURES = {
     "gpmpc_set_option": (C.c_int, [_P, C.c_char_p, C.c_longlong]),
     "gpmpc_set_cost": (C.c_int, [_P, _P, _P, _P, _D, _I, _P, _P, _I, _I]),
     "gpmpc_rollout": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P]),
-    "gpmpc_rollout_grad": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P]),
+    "gpmpc_rollout_grad": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _P]),
     "gpmpc_rollout_timed": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _I, C.POINTER(C.c_float), _P]),
     "gpmpc_argmin_async": (C.c_int, [_P, _P, _I, C.c_longlong, _P, _I, _P, _P]),
     "gpmpc_argmin": (C.c_int, [_P, _P, _I, C.c_longlong, C.POINTER(_D), C.POINTER(C.c_longlong), _P]),

@@ -32,6 +32,7 @@ from ..observations_states_mappers.normalization_observation_state_mapper import
 from ..states_reward_mappers.setpoint_distance_reward_mapper import SetpointStateRewardMapper
 from .abstract_controller import BaseControllerObject
 from .iteration_info_class import IterationInformation
+from ..._lib import GPMPC_ERR_LIMIT, GpmpcError
 
 F64 = torch.float64
 FD_STEP = 1e-3           # 4th-order stencil: truncation ~ h^4, rounding ~ 1e-13 / h
@@ -61,6 +62,7 @@ class GpMpcController(BaseControllerObject):
         self.queue_train = self.ctx.Queue()
         self.info_iters = {}
         self.num_rollouts = 0          # candidate trajectories evaluated so far (throughput accounting)
+        self.analytic_gradient = True  # gradient kernels (gpmpc_rollout_grad); False: 4th-order differences of the rollout
 
     # ------------------------------------------------------------------------------ public
     def get_action(self, obs_mu, obs_var=None, random=False):
@@ -114,6 +116,20 @@ class GpMpcController(BaseControllerObject):
         H, A = self.config.controller.len_horizon, self.actions_mapper.dim_action
         base = self.actions_mapper.mpc_to_model_batch(np.asarray(actions_mpc, dtype=np.float64).reshape(1, -1))[0]
         n = H * A
+        self.transition_model.set_cost(self.config.reward)
+        if self.analytic_gradient:
+            try:
+                out = self.transition_model.objective_and_gradient_batch(base[None], obs_mu, obs_var, self.iter_ctrl,
+                                                                         trajectories=True)
+            except GpmpcError as e:
+                if e.code != GPMPC_ERR_LIMIT:
+                    raise
+                self.analytic_gradient = False         # shape outside the gradient kernels: difference the rollout
+            else:
+                self.num_rollouts += 1
+                grad = self.actions_mapper.chain_grad_model_to_mpc(out["grad"][0].cpu().numpy())
+                self._cache_trajectory(out, 0)
+                return float(out["J"][0]), grad
         cand = np.repeat(base[None], 4 * n + 1, axis=0)            # [base, +h, -h, +2h, -2h] per coordinate
         flat = cand.reshape(4 * n + 1, n)
         k = np.arange(n)

@@ -171,6 +171,15 @@ class GpStateTransitionModel(AbstractStateTransitionModel):
         return self.engine.rollout(actions, _t(obs_mu).numpy(), _t(obs_var).numpy(), self.config.include_time_model,
                                    float(current_time_idx), trajectories, stage_costs)
 
+    def objective_and_gradient_batch(self, actions, obs_mu, obs_var, current_time_idx=0, trajectories=False):
+        """actions (B,H,A) -> dict of DEVICE tensors: J (B,), grad (B,H,A) = dJ/d(actions) (analytic; what the
+        reference gets from autograd, gp_mpc_controller.py:277), optionally the trajectories and costs."""
+        if self._cost_key is None:
+            raise RuntimeError("call set_cost(reward_config) before predicting")
+        actions = torch.as_tensor(np.asarray(actions) if not isinstance(actions, torch.Tensor) else actions, dtype=F64)
+        return self.engine.rollout_grad(actions, _t(obs_mu).numpy(), _t(obs_var).numpy(), self.config.include_time_model,
+                                        float(current_time_idx), trajectories)
+
     def predict_trajectory(self, actions, obs_mu, obs_var, len_horizon, current_time_idx):
         """Same signature / return shapes as the reference (:60-110): ((H+1,D), (H+1,D,D)) CPU tensors."""
         out = self.predict_trajectory_batch(_t(actions)[None], obs_mu, obs_var, len_horizon, current_time_idx,

@@ -178,7 +178,7 @@ int gpmpc_rollout(gpmpc_t* g, const double* actions, const double* mu0, const do
 
 int gpmpc_rollout_grad(gpmpc_t* g, const double* actions, const double* mu0, const double* S0, int B, int H, int A,
                        int include_time, double time0, double* J_out, double* grad_out, double* mu_out, double* Sig_out,
-                       void* stream) {
+                       double* cm_out, double* cv_out, void* stream) {
     if (!g) return GPMPC_ERR_ARG;
     if (!grad_out) return bad(g, "null argument");
     RolloutArgs a;
@@ -186,7 +186,7 @@ int gpmpc_rollout_grad(gpmpc_t* g, const double* actions, const double* mu0, con
     if (rc) return rc;
     if (A < 1) return bad(g, "gradient needs A >= 1");
     GPMPC_HIP_CHECK(H_(g), hipSetDevice(g->h.device));
-    a.mu_out = mu_out; a.Sig_out = Sig_out; a.J_out = J_out;
+    a.mu_out = mu_out; a.Sig_out = Sig_out; a.J_out = J_out; a.cm_out = cm_out; a.cv_out = cv_out;
     return launch_rollout_grad(H_(g), a, grad_out, (hipStream_t)stream);
 }
 

@@ -14,7 +14,7 @@
 //  adjoint_sweep_kernel one workgroup per candidate, t = H-1 .. 0: D x D algebra on the stored moments plus
 //      one O(N D^2) pass over the points for the mean part (gp_model.py:140-153).
 //
-// CPU statement of the same algebra: oracle/adjoint.py (checked against torch autograd).
+// The derivation is written out in DESIGN.md (section 4.4); a numpy statement of it lives with the tests.
 #pragma once
 #include "rollout_kernel.h"
 

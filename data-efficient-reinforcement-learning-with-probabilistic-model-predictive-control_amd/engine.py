@@ -147,8 +147,9 @@ class HipEngine:
         return out
 
     def rollout_grad(self, actions, mu0, S0, include_time=False, time0=0.0, trajectories=False):
-        """Objective and analytic gradient: dict(J (B,), grad (B,H,A) = dJ/d(actions), [mu, Sig]).
-        Raises LimitError for shapes the gradient kernels do not cover (callers then difference `rollout`)."""
+        """Objective and analytic gradient: dict(J (B,), grad (B,H,A) = dJ/d(actions), [mu, Sig, cost_mu, cost_var]).
+        Raises GpmpcError(GPMPC_ERR_LIMIT) for shapes the gradient kernels do not cover (callers then
+        difference `rollout`)."""
         actions = self._dev(actions)
         B, H, A = actions.shape
         D = self.D
@@ -159,11 +160,15 @@ class HipEngine:
         if trajectories:
             out["mu"] = torch.empty((B, H + 1, D), dtype=torch.float64, device=self.device)
             out["Sig"] = torch.empty((B, H + 1, D, D), dtype=torch.float64, device=self.device)
+            out["cost_mu"] = torch.empty((B, H + 1), dtype=torch.float64, device=self.device)
+            out["cost_var"] = torch.empty((B, H + 1), dtype=torch.float64, device=self.device)
         self._check(self.lib.gpmpc_rollout_grad(self._h, actions.data_ptr(), _hp(mu0), _hp(S0), B, H, A,
                                                 int(bool(include_time)), float(time0), out["J"].data_ptr(),
                                                 out["grad"].data_ptr(),
                                                 out["mu"].data_ptr() if trajectories else None,
-                                                out["Sig"].data_ptr() if trajectories else None, self._stream()))
+                                                out["Sig"].data_ptr() if trajectories else None,
+                                                out["cost_mu"].data_ptr() if trajectories else None,
+                                                out["cost_var"].data_ptr() if trajectories else None, self._stream()))
         return out
 
     def rollout_timed(self, actions, mu0, S0, reps, include_time=False, time0=0.0):

@@ -1,0 +1,130 @@
+"""Tier 2 (GPU, through the C ABI): gpmpc_rollout_grad -- the analytic gradient dJ/d(actions) the reference obtains
+with `mean_cost.backward()` (gp_mpc_controller.py:277) -- vs the reference-generated autograd goldens, vs the numpy
+adjoint of oracle/adjoint.py on seeded inputs, and vs differences of the forward kernel at the bench shape.
+Tolerance: 1e-7 of the gradient's scale (fp64; the goldens themselves carry ~1e-9)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, workload_of, factors_of, rel_err
+from oracle import adjoint, synth
+from oracle import gpmpc_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import gp_mpc_amd
+    eng = gp_mpc_amd.HipEngine(0)
+    yield eng
+    eng.close()
+
+
+def _load_model(engine, w, g=None):
+    f = factors_of(w)
+    engine.set_factors(w.X, f.iK, f.beta, w.lengthscales, w.outputscales)
+    use_c = g is not None and "use_constraints" in g and bool(g["use_constraints"])
+    engine.set_cost(w.target, w.W, w.W_T, w.kappa, False, g["state_min"] if use_c else None, g["state_max"] if use_c else None)
+    return f
+
+
+def test_gradient_matches_reference_autograd_golden(engine):
+    g = load("lcb_grad_norm")
+    w = workload_of(g)
+    _load_model(engine, w)
+    out = engine.rollout_grad(g["actions_model"], w.mu0, w.S0, w.include_time, w.time0)
+    assert rel_err(out["J"].cpu().numpy(), g["J"]) < 1e-9
+    grad = out["grad"].cpu().numpy().reshape(g["grad"].shape)
+    for b in range(grad.shape[0]):
+        assert rel_err(grad[b], g["grad"][b]) < 1e-7
+
+
+def test_gradient_with_action_change_mapper_matches_reference_golden(engine):
+    g = load("lcb_grad_deriv")
+    w = workload_of(g)
+    _load_model(engine, w)
+    out = engine.rollout_grad(g["actions_model"], w.mu0, w.S0, w.include_time, w.time0)
+    gm = out["grad"].cpu().numpy()
+    for b in range(gm.shape[0]):
+        tail = np.cumsum(gm[b][::-1], axis=0)[::-1]                   # derivative_action_mapper.py:28-35, clamp backward = identity
+        assert rel_err((2.0 * g["max_change"] * tail).reshape(-1), g["grad"][b]) < 1e-7
+
+
+@pytest.mark.parametrize("N,D,A,H,B,tm", [(30, 3, 1, 5, 3, False), (25, 2, 2, 4, 2, True), (70, 4, 2, 3, 2, False),
+                                          (1, 2, 1, 3, 2, False), (65, 1, 1, 4, 2, False), (90, 6, 2, 4, 2, True),
+                                          (40, 8, 3, 3, 2, False), (130, 3, 5, 3, 2, True), (200, 3, 1, 25, 3, False)])
+def test_gradient_matches_numpy_adjoint(engine, N, D, A, H, B, tm):
+    w = synth.make_workload(N, D, A, H, B, include_time=tm, seed=N + D)
+    f = _load_model(engine, w)
+    out = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0, trajectories=True)
+    fwd = engine.rollout(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+    assert torch.equal(out["J"], fwd["J"]) and torch.equal(out["mu"], fwd["mu"]) and torch.equal(out["cost_var"], fwd["cost_var"])
+    grad = out["grad"].cpu().numpy()
+    for b in range(B):
+        J, gr, *_ = adjoint.lcb_and_gradient(f, w.actions[b], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
+        assert abs(float(out["J"][b]) - J) < 1e-7 * abs(J)          # same bound as the forward parity tests
+        assert rel_err(grad[b], gr) < 1e-7
+
+
+def test_gradient_with_state_constraints(engine):
+    g = load("traj_constraints")
+    w = workload_of(g)
+    f = _load_model(engine, w, g)
+    out = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+    assert rel_err(out["J"].cpu().numpy(), g["J"]) < 1e-7
+    for b in range(2):
+        J, gr, *_ = adjoint.lcb_and_gradient(f, w.actions[b], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0,
+                                             state_min=g["state_min"], state_max=g["state_max"])
+        assert rel_err(out["grad"][b].cpu().numpy(), gr) < 1e-7
+
+
+def test_clipping_changes_the_value_not_the_gradient(engine):
+    g = load("lcb_grad_norm")
+    w = workload_of(g)
+    _load_model(engine, w)
+    free = engine.rollout_grad(g["actions_model"], w.mu0, w.S0, w.include_time, w.time0)
+    engine.set_cost(w.target, w.W, w.W_T, w.kappa, True)
+    clipped = engine.rollout_grad(g["actions_model"], w.mu0, w.S0, w.include_time, w.time0)
+    assert torch.equal(free["grad"], clipped["grad"])
+    assert bool((clipped["J"] >= free["J"] - 1e-12).all())
+
+
+def test_gradient_at_bench_shape_matches_differences_of_the_forward_kernel(engine):
+    """Config 2 (N=200, D=3, H=25): 4th-order central differences of gpmpc_rollout in one launch of 4 H A + 1 candidates."""
+    w = synth.make_workload(200, 3, 1, 25, 2, seed=0)
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    engine.set_cost(w.target, w.W, w.W_T, w.kappa)
+    out = engine.rollout_grad(w.actions, w.mu0, w.S0)
+    h, n = 1e-3, 25
+    base = w.actions[0]
+    cand = np.repeat(base[None], 4 * n + 1, axis=0)
+    flat = cand.reshape(4 * n + 1, n)
+    k = np.arange(n)
+    flat[1 + k, k] += h
+    flat[1 + n + k, k] -= h
+    flat[1 + 2 * n + k, k] += 2 * h
+    flat[1 + 3 * n + k, k] -= 2 * h
+    J = engine.rollout(cand, w.mu0, w.S0)["J"].cpu().numpy()
+    fd = (8.0 * (J[1:1 + n] - J[1 + n:1 + 2 * n]) - (J[1 + 2 * n:1 + 3 * n] - J[1 + 3 * n:])) / (12.0 * h)
+    # the differences carry the fp64 noise floor of Sigma at N = 200 (~1e-8 of J / h): 1e-5-level agreement is theirs
+    assert rel_err(out["grad"][0].cpu().numpy().reshape(-1), fd) < 1e-4
+
+
+def test_gradient_is_bitwise_reproducible_and_batch_independent(engine):
+    w = synth.make_workload(120, 3, 2, 6, 5, seed=4)
+    _load_model(engine, w)
+    a = engine.rollout_grad(w.actions, w.mu0, w.S0)["grad"]
+    b = engine.rollout_grad(w.actions, w.mu0, w.S0)["grad"]
+    assert torch.equal(a, b)
+    one = engine.rollout_grad(w.actions[3:4], w.mu0, w.S0)["grad"]
+    assert torch.equal(one[0], a[3])
+
+
+def test_unsupported_shape_is_reported_not_approximated(engine):
+    import gp_mpc_amd
+    w = synth.make_workload(40, 12, 2, 2, 2, seed=2)
+    _load_model(engine, w)
+    with pytest.raises(gp_mpc_amd.GpmpcError) as e:
+        engine.rollout_grad(w.actions, w.mu0, w.S0)
+    assert e.value.code == -4

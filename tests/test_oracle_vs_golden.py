@@ -120,3 +120,70 @@ def test_unfused_torch_baseline_matches_reference(name):
         assert rel_err(Sigs.numpy(), g["Sig"][b]) < 1e-7
         J = m.lcb(mus, Sigs, tt(w.actions[b]), tt(w.target), tt(w.W), tt(w.W_T), w.kappa)
         assert abs(float(J) - g["J"][b]) < 1e-8 * max(1.0, abs(g["J"][b]))
+
+
+# ----------------------------------------------------------------------------- analytic gradient
+@pytest.mark.parametrize("name", ["lcb_grad_norm", "lcb_grad_deriv"])
+def test_numpy_adjoint_matches_reference_autograd(name):
+    """oracle/adjoint.py (the algebra of the gradient kernels) vs the gradients the reference's
+    `mean_cost.backward()` produced (gp_mpc_controller.py:277); fp64, 1e-7 of the gradient's scale."""
+    from oracle import adjoint
+    g = load(name)
+    w = workload_of(g)
+    f = factors_of(w)
+    acts = g["actions_model"]
+    for b in range(acts.shape[0]):
+        J, grad, mus, Sigs, _ = adjoint.lcb_and_gradient(f, acts[b], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa,
+                                                         w.include_time, w.time0)
+        assert abs(J - g["J"][b]) < 1e-9 * abs(g["J"][b])
+        if bool(g["limit_action_change"]):
+            # model[t] = clamp(prev + sum_{s<=t} (2 m u[s] - m)), clamp backward = identity (derivative_action_mapper.py:28-35)
+            tail = np.cumsum(grad[::-1], axis=0)[::-1]
+            grad = 2.0 * g["max_change"] * tail
+        assert rel_err(grad.reshape(-1), g["grad"][b]) < 1e-7
+
+
+@pytest.mark.parametrize("N,D,A,H,tm", [(30, 3, 1, 5, False), (25, 2, 2, 4, True), (40, 4, 2, 3, False)])
+def test_numpy_adjoint_matches_torch_autograd_of_the_reference_op_sequence(N, D, A, H, tm):
+    import torch
+    from oracle import adjoint, synth
+    from oracle.unfused_torch import UnfusedTorchModel
+    w = synth.make_workload(N, D, A, H, 2, include_time=tm, seed=1)
+    f = factors_of(w)
+    J, grad, mus, Sigs, _ = adjoint.lcb_and_gradient(f, w.actions[0], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa,
+                                                     w.include_time, w.time0)
+    m = UnfusedTorchModel(w.X, f.iK, f.beta, w.lengthscales, w.outputscales)
+    tt = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)   # noqa: E731
+    acts = tt(w.actions[0]).requires_grad_(True)
+    mu_t, Sig_t = m.predict_trajectory(acts, tt(w.mu0), tt(w.S0), w.include_time, w.time0)
+    Jt = m.lcb(mu_t, Sig_t, acts, tt(w.target), tt(w.W), tt(w.W_T), w.kappa)
+    Jt.backward()
+    assert abs(J - Jt.item()) < 1e-10 * abs(J)
+    assert rel_err(grad, acts.grad.numpy()) < 1e-8
+    assert rel_err(mus, mu_t.detach().numpy()) < 1e-10
+
+
+def test_numpy_adjoint_with_state_constraints_matches_differences_of_the_oracle():
+    """use_constraints adds the normal-cdf penalties (setpoint_distance_reward_mapper.py:58-66) to the stage cost;
+    their partials are checked against central differences of the oracle's own forward objective."""
+    from oracle import adjoint
+    g = load("traj_constraints")
+    w = workload_of(g)
+    f = factors_of(w)
+    smin, smax = g["state_min"], g["state_max"]
+    a0 = w.actions[0]
+    J, grad, *_ = adjoint.lcb_and_gradient(f, a0, w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0,
+                                           state_min=smin, state_max=smax)
+    ref = orc.evaluate_candidates(f, w, actions=a0[None], state_min=smin, state_max=smax)
+    assert abs(J - ref["J"][0]) < 1e-10 * abs(J)
+    h = 1e-3                                        # 4th-order stencil: truncation ~ h^4, rounding ~ 1e-13 / h
+    fd = np.zeros_like(a0)
+
+    def Jof(a):
+        return orc.evaluate_candidates(f, w, actions=a[None], state_min=smin, state_max=smax)["J"][0]
+    for t in range(a0.shape[0]):
+        for k in range(a0.shape[1]):
+            d = np.zeros_like(a0)
+            d[t, k] = h
+            fd[t, k] = (8.0 * (Jof(a0 + d) - Jof(a0 - d)) - (Jof(a0 + 2 * d) - Jof(a0 - 2 * d))) / (12.0 * h)
+    assert rel_err(grad, fd) < 1e-6
