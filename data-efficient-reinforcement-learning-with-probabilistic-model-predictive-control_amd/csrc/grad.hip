@@ -7,20 +7,32 @@ namespace gpmpc_hip {
 namespace {
 
 constexpr int kMomThreads = 512;
-constexpr int kSweepThreads = 256;
 
 template <int DP, int NXP>
 int launch_moments(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s) {
-    auto kern = pair_moments_kernel<DP, NXP, kMomThreads>;
+    // 16 waves per (candidate, step) where the accumulators fit the 128-VGPR budget of a 1024-thread workgroup
+    constexpr int NT = (DP <= 3) ? 1024 : kMomThreads;
+    auto kern = pair_moments_kernel<DP, NXP, NT>;
     int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
     if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(g.H, g.B), dim3(kMomThreads), lds_bytes, s, g);
+    hipLaunchKernelGGL(kern, dim3(g.H, g.B), dim3(NT), lds_bytes, s, g);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    return GPMPC_OK;
+}
+
+template <int DP, int NT>
+int launch_sweep(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s) {
+    auto kern = adjoint_sweep_kernel<DP, NT>;
+    int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(g.B), dim3(NT), lds_bytes, s, g);
     GPMPC_HIP_CHECK(h, hipGetLastError());
     return GPMPC_OK;
 }
 
 template <int DP>
 int launch_moments_dp(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s) {
+    if (g.NXP == 1) return launch_moments<DP, 1>(h, g, lds_bytes, s);
     return g.NXP == 2 ? launch_moments<DP, 2>(h, g, lds_bytes, s) : launch_moments<DP, 6>(h, g, lds_bytes, s);
 }
 
@@ -32,7 +44,7 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     int DP = 0;
     for (int v : {2, 3, 4, 6, 8}) if (D <= v) { DP = v; break; }
     if (DP == 0 || NX > 6) { h->err = "gradient: supported for D <= 8 and A (+ time) <= 6"; return GPMPC_ERR_LIMIT; }
-    const int NXP = NX <= 2 ? 2 : 6;
+    const int NXP = NX <= 1 ? 1 : (NX <= 2 ? 2 : 6);
     const int RS = 2 + 2 * DP + NXP;
     const int NSP = 1 + DP + DP * (DP + 1) / 2 + NXP;
 
@@ -49,8 +61,8 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
         const MomLayout L = make_mom_layout(N, D, E, gg, RS, NR, wpp, NSP);
         if ((size_t)L.total * 8 <= (size_t)h->lds_limit) { G = gg; mom_lds = (size_t)L.total * 8; break; }
     }
-    const int npr = 16;
-    const SweepLayout SL = make_sweep_layout(N, D, A, E, H, npr, kSweepThreads / 64);
+    const int sweep_nt = DP <= 4 ? 64 : 256;
+    const SweepLayout SL = make_sweep_layout(D, A, E, H, NSP, sweep_nt / 64, DP <= 4 ? 0 : kSweepAug);
     if (G == 0 || (size_t)SL.total * 8 > (size_t)h->lds_limit) {
         h->err = "gradient: N too large for the LDS-resident gradient kernels"; return GPMPC_ERR_LIMIT;
     }
@@ -60,7 +72,7 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     auto magic = [](unsigned d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + d - 1) / d); };
 
     // workspace: moments, mean sums, cost variances (when the caller does not keep them)
-    const size_t n_mom = (size_t)B * H * P * NSP, n_ms = (size_t)B * H * D * (D + 1), n_cv = (size_t)B * (H + 1);
+    const size_t n_mom = (size_t)B * H * P * NSP, n_ms = (size_t)B * H * D * mean_moment_count(D, NX), n_cv = (size_t)B * (H + 1);
     int rc = grow(h, h->gradws, n_mom + n_ms + n_cv);
     if (rc) return rc;
     g.mom = h->gradws.p;
@@ -78,8 +90,8 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     g.DP = DP; g.NXP = NXP; g.NSP = NSP;
     g.G = G; g.CH = CH; g.RC = RC; g.wpp = wpp;
     g.magic_N = magic((unsigned)N); g.magic_wpp = magic((unsigned)wpp);
-    g.npr = npr;
 
+    g.xrange = h->xrange.p; g.force_path = h->opt_force_path;
     switch (DP) {
         case 2:  rc = launch_moments_dp<2>(h, g, mom_lds, s); break;
         case 3:  rc = launch_moments_dp<3>(h, g, mom_lds, s); break;
@@ -88,13 +100,14 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
         default: rc = launch_moments_dp<8>(h, g, mom_lds, s); break;
     }
     if (rc) return rc;
-    {
-        auto kern = adjoint_sweep_kernel<kSweepThreads>;
-        rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
-        if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3(B), dim3(kSweepThreads), (size_t)SL.total * 8, s, g);
-        GPMPC_HIP_CHECK(h, hipGetLastError());
+    switch (DP) {
+        case 2:  rc = launch_sweep<2, 64>(h, g, (size_t)SL.total * 8, s); break;
+        case 3:  rc = launch_sweep<3, 64>(h, g, (size_t)SL.total * 8, s); break;
+        case 4:  rc = launch_sweep<4, 64>(h, g, (size_t)SL.total * 8, s); break;
+        case 6:  rc = launch_sweep<6, 256>(h, g, (size_t)SL.total * 8, s); break;
+        default: rc = launch_sweep<8, 256>(h, g, (size_t)SL.total * 8, s); break;
     }
+    if (rc) return rc;
     return GPMPC_OK;
 }
 

@@ -38,18 +38,47 @@ struct GradArgs {
     int include_time;
     double time0;
     double* mom;     // (B, H, P, NSP)   [W | P1 (DP) | P2 upper triangle (DP (DP+1)/2) | Pe (NXP)]
-    double* msum;    // (B, H, D, D+1)   [sum lb | sum lb nu_d]
+    double* msum;    // (B, H, D, NM)    moments of nu under lb_a up to third order (mean_moment_count)
     double* grad;    // (B, H, A)
+    const double* xrange;   // (2, E) min / max of the memory points per input dimension
     int DP, NXP, NSP;
+    int force_path;         // 0 auto, 1 always the direct exp form (tests)
     int G, CH, RC, wpp;
     unsigned magic_N, magic_wpp;
-    int npr;         // small problems solved per round in the sweep (LDS sizing)
 };
 
 __host__ __device__ inline int tri_index(int d, int e, int DP) { return d * DP - (d * (d - 1)) / 2 + (e - d); }   // d <= e
 
+// Mean-part moments per output a (sums over the points, weights lb_ai):
+//   [0] 1 | [1, 1+D) nu_d | tri(D) nu_d1 nu_d2 (d1 <= d2) | D x tri(D) nu_k nu_d1 nu_d2 | NX nu_x | D x NX nu_k nu_x
+__host__ __device__ inline int tri_count(int D) { return D * (D + 1) / 2; }
+__host__ __device__ inline int mean_moment_count(int D, int NX) { return 1 + D + tri_count(D) + D * tri_count(D) + NX + D * NX; }
+__host__ __device__ inline int sym_index(int i, int j, int D) { return i <= j ? tri_index(i, j, D) : tri_index(j, i, D); }
+__device__ inline void decode_tri(int k, int D, int& d1, int& d2) {
+    d1 = 0;
+    while (k >= D - d1) { k -= D - d1; ++d1; }
+    d2 = d1 + k;
+}
+// factors of component `comp`: indices < D are state dims, D + x the extra input dims; -1 = no factor
+__device__ inline void decode_mean_moment(int comp, int D, int NX, int& i1, int& i2, int& i3) {
+    const int T2 = tri_count(D);
+    i1 = i2 = i3 = -1;
+    if (comp == 0) return;
+    comp -= 1;
+    if (comp < D) { i1 = comp; return; }
+    comp -= D;
+    if (comp < T2) { decode_tri(comp, D, i1, i2); return; }
+    comp -= T2;
+    if (comp < D * T2) { i1 = comp / T2; decode_tri(comp - i1 * T2, D, i2, i3); return; }
+    comp -= D * T2;
+    if (comp < NX) { i1 = D + comp; return; }
+    comp -= NX;
+    i1 = comp / NX;
+    i2 = D + (comp - i1 * NX);
+}
+
 struct MomLayout {
-    int c_ils2, c_var, c_logvar, c_tab, m, Sig, aug, ints, nu, xe, lb, kb, rows, part, total;
+    int c_ils2, c_xr, c_logvar, c_tab, m, Sig, aug, ints, nu, xe, lb, kb, rows, part, total;
 };
 
 __host__ __device__ inline MomLayout make_mom_layout(int N, int D, int E, int G, int RS, int NR, int wpp, int NSP) {
@@ -57,13 +86,13 @@ __host__ __device__ inline MomLayout make_mom_layout(int N, int D, int E, int G,
     const int P = D * (D + 1) / 2;
     int o = 0;
     L.c_ils2 = o;   o += rnd2(D * E);
-    L.c_var = o;    o += rnd2(D);
+    L.c_xr = o;     o += rnd2(2 * E);
     L.c_logvar = o; o += rnd2(D);
     L.c_tab = o;    o += 64;
     L.m = o;        o += rnd2(E);
     L.Sig = o;      o += rnd2(D * D);
     L.aug = o;      o += (D + G) * 2 * D * D;
-    L.ints = o;     o += rnd2((2 * P + 2 + 1) / 2);
+    L.ints = o;     o += rnd2((2 * P + G + 2 + 1) / 2);      // pa[P], pb[P], K[G], counter
     L.nu = o;       o += rnd2(D * N);
     L.xe = o;       o += rnd2((E - D) * N);
     L.lb = o;       o += rnd2(D * N);
@@ -99,7 +128,9 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
     double* s_aug = smem + L.aug;
     int* s_pa = reinterpret_cast<int*>(smem + L.ints);
     int* s_pb = s_pa + P;
-    int* s_counter = s_pb + P;
+    int* s_K = s_pb + P;                 // per pair of the group: Taylor degree of exp(g.w), 0 = direct exp
+    int* s_counter = s_K + G;
+    double* c_xr = smem + L.c_xr;
     double* a_nu = smem + L.nu;
     double* a_xe = smem + L.xe;
     double* a_lb = smem + L.lb;
@@ -110,6 +141,7 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
     for (int i = tid; i < D; i += NT) c_logvar[i] = p.logvar[i];
     for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
     for (int i = tid; i < 64; i += NT) c_tab[i] = kExp2Tab[i];
+    for (int i = tid; i < 2 * E; i += NT) c_xr[i] = p.xrange[i];
     for (int i = tid; i < E; i += NT) {
         double v;
         if (i < D) v = p.mu[((size_t)c * (H + 1) + t) * D + i];
@@ -129,18 +161,44 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
             for (int b = a; b < D; ++b) { s_pa[q] = a; s_pb[q] = b; ++q; }
     }
     __syncthreads();
+#if defined(GPMPC_PROF_ON)
+    long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_last = __builtin_readcyclecounter();
+#define GPMPC_GTRACE(id) do { if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0) { long long now_ = __builtin_readcyclecounter(); \
+    prof_acc[id] += now_ - prof_last; prof_last = now_; } } while (0)
+#else
+#define GPMPC_GTRACE(id) do {} while (0)
+#endif
 
     for (int i = tid; i < D * N; i += NT) a_nu[i] = p.Xt[i] - s_m[i / N];
     for (int i = tid; i < NX * N; i += NT) a_xe[i] = p.Xt[(size_t)D * N + i] - s_m[D + i / N];
     if (tid < D) {
         const int a = tid;
         double* aug = s_aug + a * (D * LD);
-        for (int i = 0; i < D; ++i)
-            for (int j = 0; j < D; ++j) {
-                aug[i * LD + j] = s_Sig[i * D + j] + (i == j ? 1.0 / c_ils2[a * E + i] : 0.0);
-                aug[i * LD + D + j] = (i == j ? 1.0 : 0.0);
-            }
-        (void)gauss_solve(aug, D, D, LD);
+        if constexpr (DP <= 4) {
+            double m[DP][2 * DP];
+#pragma unroll
+            for (int i = 0; i < DP; ++i)
+#pragma unroll
+                for (int j = 0; j < DP; ++j) {
+                    const bool in = (i < D && j < D);
+                    m[i][j] = (in ? s_Sig[i * D + j] : 0.0) + (i == j ? (i < D ? 1.0 / c_ils2[a * E + i] : 1.0) : 0.0);
+                    m[i][DP + j] = (i == j) ? 1.0 : 0.0;
+                }
+            (void)small_solve<DP>(m);
+#pragma unroll
+            for (int i = 0; i < DP; ++i)
+#pragma unroll
+                for (int j = 0; j < DP; ++j)
+                    if (i < D && j < D) aug[i * LD + D + j] = m[i][DP + j];
+        } else {
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j < D; ++j) {
+                    aug[i * LD + j] = s_Sig[i * D + j] + (i == j ? 1.0 / c_ils2[a * E + i] : 0.0);
+                    aug[i * LD + D + j] = (i == j ? 1.0 : 0.0);
+                }
+            (void)gauss_solve(aug, D, D, LD);
+        }
     }
     __syncthreads();
 
@@ -161,13 +219,23 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
         a_lb[it] = exp(-0.5 * q) * p.beta[it];
     }
     __syncthreads();
-    for (int task = wave; task < D * (D + 1); task += NW) {
-        const int a = task / (D + 1), dd = task - a * (D + 1);
+    GPMPC_GTRACE(0);
+    // moments of nu under the weights lb_ai up to third order (what the reverse sweep needs of the mean part)
+    const int NM = mean_moment_count(D, NX);
+    for (int task = wave; task < D * NM; task += NW) {
+        const int a = task / NM, comp = task - a * NM;
+        int i1, i2, i3;
+        decode_mean_moment(comp, D, NX, i1, i2, i3);
+        const double* f1 = i1 < 0 ? nullptr : (i1 < D ? a_nu + i1 * N : a_xe + (i1 - D) * N);
+        const double* f2 = i2 < 0 ? nullptr : (i2 < D ? a_nu + i2 * N : a_xe + (i2 - D) * N);
+        const double* f3 = i3 < 0 ? nullptr : (i3 < D ? a_nu + i3 * N : a_xe + (i3 - D) * N);
         double v = 0.0;
-        if (dd == 0) { for (int pt = lane; pt < N; pt += 64) v += a_lb[a * N + pt]; }
-        else { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt], a_nu[(dd - 1) * N + pt], v); }
+        if (!f1) { for (int pt = lane; pt < N; pt += 64) v += a_lb[a * N + pt]; }
+        else if (!f2) { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt], f1[pt], v); }
+        else if (!f3) { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt] * f1[pt], f2[pt], v); }
+        else { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt] * f1[pt] * f2[pt], f3[pt], v); }
         v = wave_sum(v);
-        if (lane == 0) p.msum[(((size_t)c * H + t) * D + a) * (D + 1) + dd] = v;
+        if (lane == 0) p.msum[(((size_t)c * H + t) * D + a) * NM + comp] = v;
     }
 
     for (int q0 = 0; q0 < P; q0 += G) {
@@ -176,16 +244,51 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
             const int gq = tid;
             const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
             double* aug = s_aug + (D + gq) * (D * LD);
-            for (int i = 0; i < D; ++i)
+            if constexpr (DP <= 4) {
+                double m[DP][2 * DP];
+#pragma unroll
+                for (int i = 0; i < DP; ++i)
+#pragma unroll
+                    for (int j = 0; j < DP; ++j) {
+                        const bool in = (i < D && j < D);
+                        const double sg = in ? s_Sig[i * D + j] : 0.0;
+                        m[i][j] = sg * (in ? c_ils2[a * E + j] + c_ils2[b * E + j] : 0.0) + (i == j ? 1.0 : 0.0);     // R (:156-159)
+                        m[i][DP + j] = sg;
+                    }
+                (void)small_solve<DP>(m);                                                       // Z = R^-1 Sigma
+#pragma unroll
+                for (int i = 0; i < DP; ++i)
+#pragma unroll
+                    for (int j = 0; j < DP; ++j)
+                        if (i < D && j < D) aug[i * LD + D + j] = m[i][DP + j];
+            } else {
+                for (int i = 0; i < D; ++i)
+                    for (int j = 0; j < D; ++j) {
+                        const double dab = c_ils2[a * E + j] + c_ils2[b * E + j];
+                        aug[i * LD + j] = s_Sig[i * D + j] * dab + (i == j ? 1.0 : 0.0);
+                        aug[i * LD + D + j] = s_Sig[i * D + j];
+                    }
+                (void)gauss_solve(aug, D, D, LD);
+            }
+            // |g_i . w_j| <= cmax from the data range of the memory points -> Taylor degree (as in the forward kernel)
+            double cmax = 0.0;
+            for (int i = 0; i < D; ++i) {
+                const double ui = fmax(fabs(c_xr[i] - s_m[i]), fabs(c_xr[E + i] - s_m[i])) * c_ils2[a * E + i];
                 for (int j = 0; j < D; ++j) {
-                    const double dab = c_ils2[a * E + j] + c_ils2[b * E + j];
-                    aug[i * LD + j] = s_Sig[i * D + j] * dab + (i == j ? 1.0 : 0.0);      // R (:156-159)
-                    aug[i * LD + D + j] = s_Sig[i * D + j];
+                    const double wj = fmax(fabs(c_xr[j] - s_m[j]), fabs(c_xr[E + j] - s_m[j])) * c_ils2[b * E + j];
+                    cmax = fma(fabs(aug[i * LD + D + j]) * ui, wj, cmax);
                 }
-            (void)gauss_solve(aug, D, D, LD);                                               // Z = R^-1 Sigma
+            }
+            int K = 0;
+            if (p.force_path != 1 && cmax <= kTaylorMaxArg[kMaxTaylor]) {
+                K = 1;
+                for (int k = 1; k < kMaxTaylor; ++k) K += (cmax > kTaylorMaxArg[k]) ? 1 : 0;
+            }
+            s_K[gq] = K;
         }
         if (tid == NT - 1) *s_counter = 0;
         __syncthreads();
+        GPMPC_GTRACE(2);
 
         for (int it = tid; it < Gc * N; it += NT) {
             const int gq = it / N, pt = it - gq * N;
@@ -229,13 +332,24 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
                     qb = fma(w[i], zw, qb);
                 }
             }
-            rec[0] = c_logvar[a] - 0.5 * ksa + 0.5 * qa;
-            rec[1] = p.beta[a * N + pt];
+            const double ka = c_logvar[a] - 0.5 * ksa + 0.5 * qa;
+            const double kb = c_logvar[b] - 0.5 * ksb + 0.5 * qb;
+            const double ba = p.beta[a * N + pt];
+            if (s_K[gq] > 0) {                         // Taylor form: exp(ka'), exp(kb') are per-point factors
+                const double ea = exp(ka);
+                rec[0] = ea;
+                rec[1] = ea * ba;
+                a_kb[gq * N + pt] = (a == b) ? 2.0 * ea : exp(kb) * p.beta[b * N + pt];
+            } else {
+                rec[0] = ka;
+                rec[1] = ba;
+                a_kb[gq * N + pt] = kb;
+            }
 #pragma unroll
             for (int d = 0; d < DP; ++d) { rec[2 + d] = g[d]; rec[2 + DP + d] = u[d]; }
-            a_kb[gq * N + pt] = c_logvar[b] - 0.5 * ksb + 0.5 * qb;
         }
         __syncthreads();
+        GPMPC_GTRACE(3);
 
         const int total = Gc * wpp;
         auto pull_item = [&]() -> int {
@@ -267,43 +381,70 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
             double w[DP];
 #pragma unroll
             for (int d = 0; d < DP; ++d) w[d] = (d < D) ? a_nu[d * N + j] * c_ils2[b * E + d] : 0.0;
+            const int K = __builtin_amdgcn_readfirstlane(s_K[gq]);
+            const double kbj = a_kb[gq * N + j];
             if (nrows > 0) {
-                const double kbj = a_kb[gq * N + j];
                 const double* rec = a_rows + ((size_t)gq * NR + i0) * RS;
                 const double* Tp = p.Tm + ((size_t)a * (N + kTPad) + i0) * N + j;
-                for (int it = 0; it < nrows; it += 2) {
-                    double e[2];
+                // two rows per trip; the next trip's T values are in flight during this trip's math (reading past the
+                // last trip only touches the zero padding rows of T)
+                auto accumulate = [&](double e, const double* rr) {
+                    cs += e;
+                    int k = 0;
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const double* rr = rec + q * RS;
-                        double arg = rr[0] + kbj;
+                    for (int d = 0; d < DP; ++d) {
+                        const double td = e * rr[2 + DP + d];
+                        h[d] += td;
 #pragma unroll
-                        for (int d = 0; d < DP; ++d) arg = fma(rr[2 + d], w[d], arg);
-                        const double wt = diag ? Tp[(size_t)q * N] : rr[1];
-                        e[q] = fast_exp(arg, c_tab) * wt;
+                        for (int d2 = d; d2 < DP; ++d2) { hh[k] = fma(td, rr[2 + DP + d2], hh[k]); ++k; }
                     }
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const double* rr = rec + q * RS;
-                        cs += e[q];
-                        int k = 0;
+                    for (int x = 0; x < NXP; ++x) h[DP + x] = fma(e, rr[2 + 2 * DP + x], h[DP + x]);
+                };
+                auto run = [&](auto kc) {
+                    constexpr int KK = decltype(kc)::value;
+                    double tn[2];
 #pragma unroll
-                        for (int d = 0; d < DP; ++d) {
-                            const double td = e[q] * rr[2 + DP + d];
-                            h[d] += td;
+                    for (int q = 0; q < 2; ++q) tn[q] = diag ? Tp[(size_t)q * N] : 1.0;
+                    for (int it = 0; it < nrows; it += 2) {
+                        double e[2];
 #pragma unroll
-                            for (int d2 = d; d2 < DP; ++d2) { hh[k] = fma(td, rr[2 + DP + d2], hh[k]); ++k; }
+                        for (int q = 0; q < 2; ++q) {
+                            const double* rr = rec + q * RS;
+                            const double tv = tn[q];
+                            tn[q] = diag ? Tp[(size_t)(2 + q) * N] : 1.0;
+                            if constexpr (KK > 0) {
+                                double cc = rr[2] * w[0];
+#pragma unroll
+                                for (int d = 1; d < DP; ++d) cc = fma(rr[2 + d], w[d], cc);
+                                e[q] = taylor_exp<KK>(cc) * (diag ? rr[0] * tv : rr[1]);
+                            } else {
+                                double arg = rr[0] + kbj;
+#pragma unroll
+                                for (int d = 0; d < DP; ++d) arg = fma(rr[2 + d], w[d], arg);
+                                e[q] = fast_exp(arg, c_tab) * (diag ? tv : rr[1]);
+                            }
                         }
 #pragma unroll
-                        for (int x = 0; x < NXP; ++x) h[DP + x] = fma(e[q], rr[2 + 2 * DP + x], h[DP + x]);
+                        for (int q = 0; q < 2; ++q) accumulate(e[q], rec + q * RS);
+                        rec += 2 * RS;
+                        Tp += (size_t)2 * N;
                     }
-                    rec += 2 * RS;
-                    Tp += (size_t)2 * N;
-                }
+                };
+                if (K == 0) run(std::integral_constant<int, 0>{});
+                else if (K <= 2) run(std::integral_constant<int, 2>{});
+                else if (K == 3) run(std::integral_constant<int, 3>{});
+                else if (K == 4) run(std::integral_constant<int, 4>{});
+                else if (K == 5) run(std::integral_constant<int, 5>{});
+                else if (K == 6) run(std::integral_constant<int, 6>{});
+                else if (K <= 8) run(std::integral_constant<int, 8>{});
+                else if (K <= 10) run(std::integral_constant<int, 10>{});
+                else if (K <= 12) run(std::integral_constant<int, 12>{});
+                else run(std::integral_constant<int, 14>{});
             }
             // column factor; for a diagonal pair only i <= j was visited with a halved diagonal of T and every
             // moment is symmetric under i <-> j, so the factor is 2
-            const double colf = valid ? (diag ? 2.0 : p.beta[b * N + j]) : 0.0;
+            const double colf = valid ? (K > 0 ? kbj : (diag ? 2.0 : p.beta[b * N + j])) : 0.0;
             double* out = s_part + (size_t)wi * NSP;
             {
                 const double v = wave_sum(valid ? cs * colf : 0.0);
@@ -329,7 +470,9 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
                 if (lane == 0) out[1 + DP + NH + x] = v;
             }
         }
+        GPMPC_GTRACE(4);
         __syncthreads();
+        GPMPC_GTRACE(5);
 
         for (int task = wave; task < Gc * NSP; task += NW) {
             const int gq = task / NSP, k = task - gq * NSP;
@@ -339,16 +482,24 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
             if (lane == 0) p.mom[((((size_t)c * H + t) * P) + q0 + gq) * NSP + k] = v;
         }
         __syncthreads();
+        GPMPC_GTRACE(6);
     }
+#if defined(GPMPC_PROF_ON)
+    if (threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0)
+        printf("PROF moments cycles: nu/lb %lld | mean moments + Z %lld | records %lld | items(wave0) %lld | wait %lld | fold %lld\n",
+               prof_acc[0], prof_acc[2], prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6]);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
+constexpr int kSweepAug = 16;     // LDS augmented blocks of the sweep (D > 4)
+
 struct SweepLayout {
-    int c_ils2, c_var, cost, gmu, gSig, gu, ctmp, mubar, Sigbar, Sacc, mbar, m, Sig, Ai, cc, s0, s1, M, y, V, Sb, Vb, Mb, cb, s0b,
-        s1b, Gs, Ab, mba, Ri, Z, rdet, Kq, mq, aug, om, total;
+    int c_ils2, c_var, cost, gmu, gSig, gu, ctmp, mubar, Sigbar, Sacc, mbar, m, Sig, ms, mom, Ai, cc, M, y, V, Sb, Vb, Mb, cb, s0b,
+        s1b, Gs, Aib, Ab, mba, Ri, Z, rdet, RZ, mq, aug, total;
 };
 
-__host__ __device__ inline SweepLayout make_sweep_layout(int N, int D, int A, int E, int H, int npr, int nwaves) {
+__host__ __device__ inline SweepLayout make_sweep_layout(int D, int A, int E, int H, int NSP, int nwaves, int naug) {
     SweepLayout L;
     const int P = D * (D + 1) / 2, DD = D * D, n = D + A, NX = E - D;
     int o = 0;
@@ -356,11 +507,12 @@ __host__ __device__ inline SweepLayout make_sweep_layout(int N, int D, int A, in
     take(L.c_ils2, D * E); take(L.c_var, D); take(L.cost, n + n * n + DD + 2 * D);
     take(L.gmu, (H + 1) * D); take(L.gSig, (H + 1) * DD); take(L.gu, H * A); take(L.ctmp, nwaves * (2 * n * n + 3 * n));
     take(L.mubar, D); take(L.Sigbar, DD); take(L.Sacc, DD); take(L.mbar, E);
-    take(L.m, E); take(L.Sig, DD); take(L.Ai, D * DD); take(L.cc, D); take(L.s0, D); take(L.s1, DD); take(L.M, D);
+    take(L.m, E); take(L.Sig, DD); take(L.ms, D * mean_moment_count(D, NX)); take(L.mom, P * NSP);
+    take(L.Ai, D * DD); take(L.cc, D); take(L.M, D);
     take(L.y, DD); take(L.V, DD); take(L.Sb, DD); take(L.Vb, DD); take(L.Mb, D); take(L.cb, D); take(L.s0b, D); take(L.s1b, DD);
-    take(L.Gs, D * (D + DD + NX)); take(L.Ab, D * DD); take(L.mba, D * E);
-    take(L.Ri, P * DD); take(L.Z, P * DD); take(L.rdet, P); take(L.Kq, P * DD); take(L.mq, P * E);
-    take(L.aug, npr * D * 3 * D); take(L.om, D * N);
+    take(L.Gs, D * (D + DD + NX)); take(L.Aib, D * DD); take(L.Ab, D * DD); take(L.mba, D * E);
+    take(L.Ri, P * DD); take(L.Z, P * DD); take(L.rdet, P); take(L.RZ, P * DD); take(L.mq, P * E);
+    take(L.aug, naug * D * 2 * D);
     L.total = o;
     return L;
 }
@@ -428,27 +580,31 @@ __device__ inline void cost_adjoint_wave(int lane, int D, int A, bool terminal, 
     }
 }
 
-template <int NT>
+// One workgroup per candidate (one wavefront for D <= 4: every hand-off is then a wave-level LDS sync).
+template <int DP, int NT>
 __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NT / kWave;
+    auto sync = [] { if constexpr (NT == 64) wave_lds_sync(); else __syncthreads(); };
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x;
-    const int N = p.N, D = p.D, A = p.A, E = p.E, H = p.H;
+    const int D = p.D, A = p.A, E = p.E, H = p.H;
     const int NX = E - D, P = D * (D + 1) / 2, DD = D * D, n = D + A;
-    const int DP = p.DP, NSP = p.NSP, NH = DP * (DP + 1) / 2;
+    const int NSP = p.NSP, NH = DP * (DP + 1) / 2;
     const int NG = D + DD + NX;
-    const int LD3 = 3 * D;
-    const SweepLayout L = make_sweep_layout(N, D, A, E, H, p.npr, NW);
+    const int T2 = tri_count(D), NM = mean_moment_count(D, NX);
+    const int LD = 2 * D;
+    const SweepLayout L = make_sweep_layout(D, A, E, H, NSP, NW, DP <= 4 ? 0 : kSweepAug);
     double* c_ils2 = smem + L.c_ils2; double* c_var = smem + L.c_var; double* c_cost = smem + L.cost;
     double* gmu = smem + L.gmu; double* gSig = smem + L.gSig; double* gu = smem + L.gu; double* ctmp = smem + L.ctmp;
     double* mubar = smem + L.mubar; double* Sigbar = smem + L.Sigbar; double* Sacc = smem + L.Sacc; double* mbar = smem + L.mbar;
-    double* s_m = smem + L.m; double* s_Sig = smem + L.Sig; double* s_Ai = smem + L.Ai; double* s_cc = smem + L.cc;
-    double* s_s0 = smem + L.s0; double* s_s1 = smem + L.s1; double* s_M = smem + L.M; double* s_y = smem + L.y; double* s_V = smem + L.V;
+    double* s_m = smem + L.m; double* s_Sig = smem + L.Sig; double* s_ms = smem + L.ms; double* s_mom = smem + L.mom;
+    double* s_Ai = smem + L.Ai; double* s_cc = smem + L.cc; double* s_M = smem + L.M; double* s_y = smem + L.y; double* s_V = smem + L.V;
     double* s_Sb = smem + L.Sb; double* s_Vb = smem + L.Vb; double* s_Mb = smem + L.Mb; double* s_cb = smem + L.cb;
-    double* s_s0b = smem + L.s0b; double* s_s1b = smem + L.s1b; double* s_Gs = smem + L.Gs; double* s_Ab = smem + L.Ab;
-    double* s_mba = smem + L.mba; double* s_Ri = smem + L.Ri; double* s_Z = smem + L.Z; double* s_rdet = smem + L.rdet;
-    double* s_Kq = smem + L.Kq; double* s_mq = smem + L.mq; double* s_aug = smem + L.aug; double* a_om = smem + L.om;
+    double* s_s0b = smem + L.s0b; double* s_s1b = smem + L.s1b; double* s_Gs = smem + L.Gs; double* s_Aib = smem + L.Aib;
+    double* s_Ab = smem + L.Ab; double* s_mba = smem + L.mba; double* s_Ri = smem + L.Ri; double* s_Z = smem + L.Z;
+    double* s_rdet = smem + L.rdet; double* s_RZ = smem + L.RZ; double* s_mq = smem + L.mq;
+    [[maybe_unused]] double* s_aug = smem + L.aug;
     const double* target = c_cost;
     const double* Wst = c_cost + n;
     const double* WT = Wst + n * n;
@@ -459,11 +615,12 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
     const double* act = p.actions + (size_t)c * H * A;
     const double* cvv = p.cv + (size_t)c * (H + 1);
     const double inv_n = 1.0 / (double)(H + 1);
+    auto pair_of = [&](int q, int& a, int& b) { decode_tri(q, D, a, b); };
 
     for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
     for (int i = tid; i < D; i += NT) c_var[i] = p.var[i];
     for (int i = tid; i < n + n * n + DD + 2 * D; i += NT) c_cost[i] = p.cost[i];
-    __syncthreads();
+    sync();
     // cost adjoints of every time step (independent of the sweep): one wavefront per step
     for (int t = wave; t <= H; t += NW) {
         const bool terminal = (t == H);
@@ -473,85 +630,100 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
                           gmu + t * D, gSig + t * DD, terminal ? ctmp + wave * (2 * n * n + 3 * n) : gu + t * A);
         wave_lds_sync();
     }
-    __syncthreads();
+    sync();
     for (int i = tid; i < D; i += NT) mubar[i] = gmu[H * D + i];
     for (int i = tid; i < DD; i += NT) {
         const int r = i / D, q = i - r * D;
         Sigbar[i] = 0.5 * (gSig[H * DD + i] + gSig[H * DD + q * D + r]);
     }
-    __syncthreads();
+    sync();
 
     for (int t = H - 1; t >= 0; --t) {
-        const double* mom = p.mom + ((size_t)c * H + t) * P * NSP;
-        const double* ms = p.msum + ((size_t)c * H + t) * D * (D + 1);
-        // ---- reload the forward state of step t ------------------------------------------------
-        for (int i = tid; i < E; i += NT) {
-            double v;
-            if (i < D) v = traj_mu[t * D + i];
-            else if (i < D + A) v = act[t * A + (i - D)];
-            else v = p.time0 + (double)t;
-            s_m[i] = v;
-        }
-        for (int i = tid; i < DD; i += NT) s_Sig[i] = traj_Sig[t * DD + i];
-        for (int i = tid; i < D * (D + 1); i += NT) {
-            const int a = i / (D + 1), dd = i - a * (D + 1);
-            if (dd == 0) s_s0[a] = ms[i]; else s_s1[a * D + dd - 1] = ms[i];
-        }
-        __syncthreads();
-        // ---- small solves: A_a^-1, det A_a;  R_ab^-1, Z_ab, det R_ab -----------------------------
-        for (int base = 0; base < D + P; base += p.npr) {
-            const int prob = base + tid;
-            if (tid < p.npr && prob < D + P) {
-                double* aug = s_aug + tid * (D * LD3);
-                if (prob < D) {
-                    const int a = prob;
-                    double prodil = 1.0;
-                    for (int i = 0; i < D; ++i) {
-                        prodil *= c_ils2[a * E + i];
-                        for (int j = 0; j < D; ++j) {
-                            aug[i * LD3 + j] = s_Sig[i * D + j] + (i == j ? 1.0 / c_ils2[a * E + i] : 0.0);
-                            aug[i * LD3 + D + j] = (i == j ? 1.0 : 0.0);
-                        }
-                    }
-                    const double det = gauss_solve(aug, D, D, LD3);
-                    for (int i = 0; i < D; ++i)
-                        for (int j = 0; j < D; ++j) s_Ai[a * DD + i * D + j] = aug[i * LD3 + D + j];
-                    s_cc[a] = c_var[a] / sqrt(det * prodil);
-                } else {
-                    const int q = prob - D;
-                    int a = 0, rem = q;
-                    while (rem >= D - a) { rem -= D - a; ++a; }
-                    const int b = a + rem;
-                    for (int i = 0; i < D; ++i)
-                        for (int j = 0; j < D; ++j) {
-                            const double dab = c_ils2[a * E + j] + c_ils2[b * E + j];
-                            aug[i * LD3 + j] = s_Sig[i * D + j] * dab + (i == j ? 1.0 : 0.0);
-                            aug[i * LD3 + D + j] = (i == j ? 1.0 : 0.0);
-                            aug[i * LD3 + 2 * D + j] = s_Sig[i * D + j];
-                        }
-                    const double det = gauss_solve(aug, D, 2 * D, LD3);
-                    for (int i = 0; i < D; ++i)
-                        for (int j = 0; j < D; ++j) {
-                            s_Ri[q * DD + i * D + j] = aug[i * LD3 + D + j];
-                            s_Z[q * DD + i * D + j] = aug[i * LD3 + 2 * D + j];
-                        }
-                    s_rdet[q] = 1.0 / sqrt(det);
-                }
+        // ---- forward quantities of step t -------------------------------------------------------------
+        {
+            const double* mom = p.mom + ((size_t)c * H + t) * P * NSP;
+            const double* ms = p.msum + ((size_t)c * H + t) * D * NM;
+            for (int i = tid; i < P * NSP; i += NT) s_mom[i] = mom[i];
+            for (int i = tid; i < D * NM; i += NT) s_ms[i] = ms[i];
+            for (int i = tid; i < E; i += NT) {
+                double v;
+                if (i < D) v = traj_mu[t * D + i];
+                else if (i < D + A) v = act[t * A + (i - D)];
+                else v = p.time0 + (double)t;
+                s_m[i] = v;
             }
-            __syncthreads();
+            for (int i = tid; i < DD; i += NT) s_Sig[i] = traj_Sig[t * DD + i];
         }
-        // ---- M, y = A^-1 s1, V;  symmetric Sigma_bar' ----------------------------------------------
+        sync();
+        // ---- small solves: A_a^-1, c_a;  R_ab^-1, Z_ab, 1/sqrt det R_ab --------------------------------
+        constexpr int PSTEP = (DP <= 4) ? NT : kSweepAug;        // LDS solves: kSweepAug threads, one augmented block each
+        for (int prob = tid; prob < D + P && tid < PSTEP; prob += PSTEP) {
+            int a = prob, b = prob;
+            if (prob >= D) pair_of(prob - D, a, b);
+            double det;
+            double* dst = (prob < D) ? s_Ai + a * DD : s_Ri + (prob - D) * DD;
+            if constexpr (DP <= 4) {
+                double m[DP][2 * DP];
+#pragma unroll
+                for (int i = 0; i < DP; ++i)
+#pragma unroll
+                    for (int j = 0; j < DP; ++j) {
+                        const bool in = (i < D && j < D);
+                        const double sg = in ? s_Sig[i * D + j] : 0.0;
+                        double v;
+                        if (prob < D) v = sg + ((i == j) ? (i < D ? 1.0 / c_ils2[a * E + i] : 1.0) : 0.0);
+                        else v = sg * (in ? c_ils2[a * E + j] + c_ils2[b * E + j] : 0.0) + (i == j ? 1.0 : 0.0);
+                        m[i][j] = v;
+                        m[i][DP + j] = (i == j) ? 1.0 : 0.0;
+                    }
+                det = small_solve<DP>(m);
+#pragma unroll
+                for (int i = 0; i < DP; ++i)
+#pragma unroll
+                    for (int j = 0; j < DP; ++j)
+                        if (i < D && j < D) dst[i * D + j] = m[i][DP + j];
+            } else {
+                double* aug = s_aug + tid * (D * LD);
+                for (int i = 0; i < D; ++i)
+                    for (int j = 0; j < D; ++j) {
+                        const double sg = s_Sig[i * D + j];
+                        aug[i * LD + j] = (prob < D) ? sg + (i == j ? 1.0 / c_ils2[a * E + i] : 0.0)
+                                                     : sg * (c_ils2[a * E + j] + c_ils2[b * E + j]) + (i == j ? 1.0 : 0.0);
+                        aug[i * LD + D + j] = (i == j) ? 1.0 : 0.0;
+                    }
+                det = gauss_solve(aug, D, D, LD);
+                for (int i = 0; i < D; ++i)
+                    for (int j = 0; j < D; ++j) dst[i * D + j] = aug[i * LD + D + j];
+            }
+            if (prob < D) {
+                double prodil = 1.0;
+                for (int i = 0; i < D; ++i) prodil *= c_ils2[a * E + i];
+                s_cc[a] = c_var[a] / sqrt(det * prodil);
+            } else {
+                s_rdet[prob - D] = 1.0 / sqrt(det);
+            }
+        }
+        for (int i = tid; i < DD; i += NT) {
+            const int r = i / D, q = i - r * D;
+            s_Sb[i] = 0.5 * (Sigbar[i] + Sigbar[q * D + r]);
+        }
+        sync();
+        // ---- Z = R^-1 Sigma;  y = A^-1 s1, V, M --------------------------------------------------------
+        for (int i = tid; i < P * DD; i += NT) {
+            const int q = i / DD, r = (i - q * DD) / D, cc = i - q * DD - r * D;
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) v = fma(s_Ri[q * DD + r * D + k], s_Sig[k * D + cc], v);
+            s_Z[i] = v;
+        }
         for (int i = tid; i < DD; i += NT) {
             const int a = i / D, k = i - a * D;
             double v = 0.0;
-            for (int j = 0; j < D; ++j) v = fma(s_Ai[a * DD + k * D + j], s_s1[a * D + j], v);
+            for (int j = 0; j < D; ++j) v = fma(s_Ai[a * DD + k * D + j], s_ms[a * NM + 1 + j], v);
             s_y[a * D + k] = v;
             s_V[k * D + a] = s_cc[a] * v;
-            const int r = a, q = k;
-            s_Sb[r * D + q] = 0.5 * (Sigbar[r * D + q] + Sigbar[q * D + r]);
         }
-        for (int a = tid; a < D; a += NT) s_M[a] = s_cc[a] * s_s0[a];
-        __syncthreads();
+        for (int a = tid; a < D; a += NT) s_M[a] = s_cc[a] * s_ms[a * NM];
+        sync();
         // ---- Sigma' = Sigma + S + Sigma V + (Sigma V)^T,  mu' = mu + M,  S -= M M^T ------------------
         for (int i = tid; i < DD; i += NT) {
             const int r = i / D, q = i - r * D;
@@ -568,7 +740,18 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             for (int b = 0; b < D; ++b) v = fma(-2.0 * s_Sb[a * D + b], s_M[b], v);
             s_Mb[a] = v;
         }
-        __syncthreads();
+        // pairs: RZ = R^-T Z_bar,  Z_bar = 1/2 W_bar P2
+        for (int i = tid; i < P * DD; i += NT) {
+            const int q = i / DD, r = (i - q * DD) / D, cc = i - q * DD - r * D;
+            int a, b;
+            pair_of(q, a, b);
+            const double Wb = ((a == b) ? s_Sb[a * D + a] : 2.0 * s_Sb[a * D + b]) * s_rdet[q];
+            const double* mo = s_mom + q * NSP;
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) v = fma(s_Ri[q * DD + k * D + r], mo[1 + DP + sym_index(k, cc, DP)], v);
+            s_RZ[i] = 0.5 * Wb * v;
+        }
+        sync();
         for (int i = tid; i < DD; i += NT) {
             const int a = i / D, k = i - a * D;
             double v = 0.0;
@@ -576,130 +759,112 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             s_s1b[a * D + k] = s_cc[a] * v;                                      // s1_bar = c A^-1 v_bar
         }
         for (int a = tid; a < D; a += NT) {
-            double v = s_Mb[a] * s_s0[a];
+            double v = s_Mb[a] * s_ms[a * NM];
             for (int k = 0; k < D; ++k) v = fma(s_Vb[k * D + a], s_y[a * D + k], v);
             s_cb[a] = v;                                                         // c_bar
             s_s0b[a] = s_Mb[a] * s_cc[a];
         }
-        __syncthreads();
-        // ---- mean part over the points: q_bar_i = -1/2 lb_i (s0_bar + s1_bar . nu_i) -----------------
-        for (int it = tid; it < D * N; it += NT) {
-            const int a = it / N, pt = it - a * N;
-            double nu[kMaxD];
-            for (int d = 0; d < D; ++d) nu[d] = p.Xt[(size_t)d * N + pt] - s_m[d];
-            double q = 0.0, lin = s_s0b[a];
-            for (int i = 0; i < D; ++i) {
-                double r = 0.0;
-                for (int j = 0; j < D; ++j) r = fma(s_Ai[a * DD + i * D + j], nu[j], r);
-                q = fma(nu[i], r, q);
-                lin = fma(s_s1b[a * D + i], nu[i], lin);
+        // pairs: K_q = RZ + (coef R^-T - RZ Z^T) diag(dab), one thread per row, in place over RZ;  m_q
+        for (int i = tid; i < P * D; i += NT) {
+            const int q = i / D, r = i - q * D;
+            int a, b;
+            pair_of(q, a, b);
+            const double sb = (a == b) ? s_Sb[a * D + a] : 2.0 * s_Sb[a * D + b];
+            const double coef = -0.5 * sb * s_mom[q * NSP] * s_rdet[q];
+            double row[8];
+#pragma unroll
+            for (int l = 0; l < 8; ++l) row[l] = (l < D) ? s_RZ[q * DD + r * D + l] : 0.0;
+            for (int cc = 0; cc < D; ++cc) {
+                double rzzt = 0.0;
+#pragma unroll
+                for (int l = 0; l < 8; ++l)
+                    if (l < D) rzzt = fma(row[l], s_Z[q * DD + cc * D + l], rzzt);
+                double self = 0.0;
+#pragma unroll
+                for (int l = 0; l < 8; ++l) self = (l == cc) ? row[l] : self;
+                s_RZ[q * DD + r * D + cc] = self + (coef * s_Ri[q * DD + cc * D + r] - rzzt) * (c_ils2[a * E + cc] + c_ils2[b * E + cc]);
             }
-            for (int x = 0; x < NX; ++x) {
-                const double v = p.Xt[(size_t)(D + x) * N + pt] - s_m[D + x];
-                q = fma(v * v, c_ils2[a * E + D + x], q);
-            }
-            a_om[it] = -0.5 * exp(-0.5 * q) * p.beta[it] * lin;
         }
-        __syncthreads();
-        for (int task = wave; task < D * NG; task += NW) {
-            const int a = task / NG, k = task - a * NG;
-            double v = 0.0;
+        for (int i = tid; i < P * E; i += NT) {
+            const int q = i / E, e = i - q * E;
+            int a, b;
+            pair_of(q, a, b);
+            const double Wb = ((a == b) ? s_Sb[a * D + a] : 2.0 * s_Sb[a * D + b]) * s_rdet[q];
+            const double* mo = s_mom + q * NSP;
+            double v;
+            if (e < D) {
+                double zp = 0.0;
+                for (int k = 0; k < D; ++k) zp = fma(s_Z[q * DD + e * D + k], mo[1 + k], zp);
+                v = Wb * (mo[1 + e] - (c_ils2[a * E + e] + c_ils2[b * E + e]) * zp);
+            } else {
+                v = Wb * mo[1 + DP + NH + (e - D)];
+            }
+            s_mq[i] = v;
+        }
+        sync();
+        // ---- mean part: G1, G2, Ge from the stored moments (q_bar_i = -1/2 lb_i (s0_bar + s1_bar . nu_i)) ----
+        for (int i = tid; i < D * NG; i += NT) {
+            const int a = i / NG, k = i - a * NG;
+            const double* ms = s_ms + a * NM;
+            const double* Q2 = ms + 1 + D;
+            const double* Q3 = Q2 + T2;
+            const double* q1e = Q3 + D * T2;
+            const double* q2e = q1e + NX;
+            double v;
             if (k < D) {
-                for (int pt = lane; pt < N; pt += 64) v = fma(a_om[a * N + pt], p.Xt[(size_t)k * N + pt] - s_m[k], v);
+                v = s_s0b[a] * ms[1 + k];
+                for (int l = 0; l < D; ++l) v = fma(Q2[sym_index(k, l, D)], s_s1b[a * D + l], v);
             } else if (k < D + DD) {
                 const int d1 = (k - D) / D, d2 = (k - D) - d1 * D;
-                for (int pt = lane; pt < N; pt += 64)
-                    v = fma(a_om[a * N + pt] * (p.Xt[(size_t)d1 * N + pt] - s_m[d1]), p.Xt[(size_t)d2 * N + pt] - s_m[d2], v);
+                const int ti = sym_index(d1, d2, D);
+                v = s_s0b[a] * Q2[ti];
+                for (int r = 0; r < D; ++r) v = fma(Q3[r * T2 + ti], s_s1b[a * D + r], v);
             } else {
                 const int x = k - D - DD;
-                for (int pt = lane; pt < N; pt += 64) v = fma(a_om[a * N + pt], p.Xt[(size_t)(D + x) * N + pt] - s_m[D + x], v);
+                v = s_s0b[a] * q1e[x];
+                for (int r = 0; r < D; ++r) v = fma(q2e[r * NX + x], s_s1b[a * D + r], v);
             }
-            v = wave_sum(v);
-            if (lane == 0) s_Gs[a * NG + k] = v;
+            s_Gs[i] = -0.5 * v;
         }
-        __syncthreads();
-        // ---- per output a: A_bar, m_bar contribution;  per pair: K_q, m_q -----------------------------
-        for (int task = tid; task < D + P; task += NT) {
-            if (task < D) {
-                const int a = task;
-                const double* Ai = s_Ai + a * DD;
-                const double* G1 = s_Gs + a * NG;
-                const double* G2 = G1 + D;
-                const double* Ge = G2 + DD;
-                double* Ab = s_Ab + a * DD;
-                // Ai_bar = sym(c v_bar s1^T) + G2;  A_bar = -Ai Ai_bar Ai - 1/2 c_bar c Ai
-                for (int i = 0; i < D; ++i)
-                    for (int j = 0; j < D; ++j) {
-                        double v = 0.0;
-                        for (int k = 0; k < D; ++k)
-                            for (int l = 0; l < D; ++l) {
-                                const double aib = 0.5 * s_cc[a] * (s_Vb[k * D + a] * s_s1[a * D + l] + s_Vb[l * D + a] * s_s1[a * D + k])
-                                                   + 0.5 * (G2[k * D + l] + G2[l * D + k]);
-                                v = fma(Ai[i * D + k] * aib, Ai[l * D + j], v);
-                            }
-                        Ab[i * D + j] = -v - 0.5 * s_cb[a] * s_cc[a] * Ai[i * D + j];
-                    }
-                for (int e = 0; e < E; ++e) {
-                    double v;
-                    if (e < D) {
-                        double r = 0.0;
-                        for (int k = 0; k < D; ++k) r = fma(Ai[e * D + k], G1[k], r);
-                        v = -(s_s0[a] * s_s1b[a * D + e] + 2.0 * r);
-                    } else {
-                        v = -2.0 * c_ils2[a * E + e] * Ge[e - D];
-                    }
-                    s_mba[a * E + e] = v;
-                }
+        sync();
+        for (int i = tid; i < D * DD; i += NT) {
+            const int a = i / DD, k = (i - a * DD) / D, l = i - a * DD - k * D;
+            const double* G2 = s_Gs + a * NG + D;
+            s_Aib[i] = 0.5 * s_cc[a] * (s_Vb[k * D + a] * s_ms[a * NM + 1 + l] + s_Vb[l * D + a] * s_ms[a * NM + 1 + k])
+                     + 0.5 * (G2[k * D + l] + G2[l * D + k]);
+        }
+        for (int i = tid; i < D * E; i += NT) {
+            const int a = i / E, e = i - a * E;
+            const double* G1 = s_Gs + a * NG;
+            double v;
+            if (e < D) {
+                double r = 0.0;
+                for (int k = 0; k < D; ++k) r = fma(s_Ai[a * DD + e * D + k], G1[k], r);
+                v = -(s_ms[a * NM] * s_s1b[a * D + e] + 2.0 * r);
             } else {
-                const int q = task - D;
-                int a = 0, rem = q;
-                while (rem >= D - a) { rem -= D - a; ++a; }
-                const int b = a + rem;
-                const double* mo = mom + (size_t)q * NSP;
-                const double* Ri = s_Ri + q * DD;
-                const double* Z = s_Z + q * DD;
-                const double sb = (a == b) ? s_Sb[a * D + a] : 2.0 * s_Sb[a * D + b];
-                const double Wb = sb * s_rdet[q];
-                const double coef = -0.5 * sb * mo[0] * s_rdet[q];
-                double* Kq = s_Kq + q * DD;
-                // Zb = 1/2 Wb P2 (symmetric);  RZ = Ri^T Zb;  Rb = coef Ri^T - RZ Z^T;  K = RZ + Rb diag(dab)
-                for (int i = 0; i < D; ++i)
-                    for (int j = 0; j < D; ++j) {
-                        double rz_ij = 0.0, rzzt = 0.0;
-                        for (int k = 0; k < D; ++k) {
-                            const int lo = k < j ? k : j, hi = k < j ? j : k;
-                            rz_ij = fma(Ri[k * D + i], 0.5 * Wb * mo[1 + DP + tri_index(lo, hi, DP)], rz_ij);
-                        }
-                        for (int l = 0; l < D; ++l) {
-                            double rz_il = 0.0;
-                            for (int k = 0; k < D; ++k) {
-                                const int lo = k < l ? k : l, hi = k < l ? l : k;
-                                rz_il = fma(Ri[k * D + i], 0.5 * Wb * mo[1 + DP + tri_index(lo, hi, DP)], rz_il);
-                            }
-                            rzzt = fma(rz_il, Z[j * D + l], rzzt);
-                        }
-                        const double dab = c_ils2[a * E + j] + c_ils2[b * E + j];
-                        Kq[i * D + j] = rz_ij + (coef * Ri[j * D + i] - rzzt) * dab;
-                    }
-                for (int e = 0; e < E; ++e) {
-                    double v;
-                    if (e < D) {
-                        double zp = 0.0;
-                        for (int k = 0; k < D; ++k) zp = fma(Z[e * D + k], mo[1 + k], zp);
-                        v = Wb * (mo[1 + e] - (c_ils2[a * E + e] + c_ils2[b * E + e]) * zp);
-                    } else {
-                        v = Wb * mo[1 + DP + NH + (e - D)];
-                    }
-                    s_mq[q * E + e] = v;
-                }
+                v = -2.0 * c_ils2[a * E + e] * G1[D + DD + (e - D)];
             }
+            s_mba[i] = v;
         }
-        __syncthreads();
+        sync();
+        // A_bar = -A^-1 Ai_bar A^-1 - 1/2 c_bar c A^-1
+        for (int i = tid; i < D * DD; i += NT) {
+            const int a = i / DD, r = (i - a * DD) / D, cc = i - a * DD - r * D;
+            const double* Ai = s_Ai + a * DD;
+            double v = 0.0;
+            for (int k = 0; k < D; ++k) {
+                double w = 0.0;
+                for (int l = 0; l < D; ++l) w = fma(s_Aib[a * DD + k * D + l], Ai[l * D + cc], w);
+                v = fma(Ai[r * D + k], w, v);
+            }
+            s_Ab[i] = -v - 0.5 * s_cb[a] * s_cc[a] * Ai[r * D + cc];
+        }
+        sync();
         // ---- assemble (fixed order) -------------------------------------------------------------------
         for (int i = tid; i < DD; i += NT) {
             double v = Sacc[i];
             for (int a = 0; a < D; ++a) v += s_Ab[a * DD + i];
-            for (int q = 0; q < P; ++q) v += s_Kq[q * DD + i];
+            for (int q = 0; q < P; ++q) v += s_RZ[q * DD + i];
             Sacc[i] = v;
         }
         for (int e = tid; e < E; e += NT) {
@@ -708,14 +873,14 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             for (int q = 0; q < P; ++q) v += s_mq[q * E + e];
             mbar[e] = v;
         }
-        __syncthreads();
+        sync();
         for (int i = tid; i < DD; i += NT) {
             const int r = i / D, q = i - r * D;
             Sigbar[i] = 0.5 * (Sacc[i] + Sacc[q * D + r]) + 0.5 * (gSig[t * DD + i] + gSig[t * DD + q * D + r]);
         }
         for (int i = tid; i < D; i += NT) mubar[i] = mbar[i] + gmu[t * D + i];
         for (int i = tid; i < A; i += NT) p.grad[((size_t)c * H + t) * A + i] = mbar[D + i] + gu[t * A + i];
-        __syncthreads();
+        sync();
     }
 }
 
