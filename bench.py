@@ -135,6 +135,20 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
+    # the analytic-gradient path (gp_mpc_controller.py:277 `mean_cost.backward()`), reported beside the metric: J and
+    # dJ/d(actions) of every candidate = forward rollout + pairwise moment pass + reverse sweep
+    grad_ms = None
+    try:
+        eng.rollout_grad(actions, w.mu0, w.S0, w.include_time, w.time0)
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        for _ in range(5):
+            eng.rollout_grad(actions, w.mu0, w.S0, w.include_time, w.time0)
+        torch.cuda.synchronize()
+        grad_ms = (time.perf_counter() - tg) / 5 * 1e3
+    except gp_mpc_amd.GpmpcError:
+        pass                                       # shape outside the gradient kernels (D > 8, streaming N)
+
     # kernel-only time of the dominant kernel: HIP events on the launch stream
     kernel_ms, _ = eng.rollout_timed(actions, w.mu0, w.S0, max(3, min(args.steps, 20)), w.include_time, w.time0)
 
@@ -175,6 +189,10 @@ def main():
             "prepare_ms": prepare_ms,
             "prepare_incremental_ms": prepare_incremental_ms,
             "control_step_ms": prepare_ms + elapsed / args.steps * 1e3,
+            "gradient": None if grad_ms is None else {
+                "ms_per_launch": grad_ms, "objective_gradients_per_s": Bg / (grad_ms * 1e-3),
+                "rollouts_the_same_gradients_cost_by_differences": Bg * (4 * H * A + 1),
+                "note": "J and dJ/du (H x A) for every candidate of the batch: rollout + pair_moments + adjoint_sweep kernels"},
             "best_index": int(best_i), "best_J": float(best_J),
         }
         # parity spot check against the CPU oracle on identical inputs (not timed)
