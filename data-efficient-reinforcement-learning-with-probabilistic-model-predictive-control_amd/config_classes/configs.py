@@ -85,12 +85,16 @@ _DEFAULT_OPTIMIZER = {"disp": None, "maxcor": 30, "ftol": 1e-99, "gtol": 1e-99, 
 
 
 class ControllerConfig:
-    """Reference keywords (controller_config.py:1-25) plus three optional ones for the batched optimiser that
-    replaces the sequential scipy restarts when `candidate_optimizer="cem"`."""
+    """Reference keywords (controller_config.py:1-25) plus optional ones for the batched optimisers that replace
+    the sequential scipy restarts: `candidate_optimizer="cem"` (cross-entropy search, one
+    rollout launch per iteration) or `"lbfgs"` (the reference's scipy L-BFGS-B restarts advanced in lockstep: one
+    objective + analytic-gradient launch serves every restart's pending evaluation; same result as the sequential
+    loop, wall time of the longest restart)."""
 
     def __init__(self, len_horizon=15, actions_optimizer_params=None, init_from_previous_actions=True,
                  restarts_optim=1, optimize=True, num_repeat_actions=1,
-                 candidate_optimizer=None, cem_candidates=256, cem_iterations=4, cem_elite_fraction=0.1):
+                 candidate_optimizer=None, cem_candidates=256, cem_iterations=4, cem_elite_fraction=0.1,
+                 lbfgs_candidates=None):
         self.len_horizon = len_horizon
         self.actions_optimizer_params = dict(_DEFAULT_OPTIMIZER if actions_optimizer_params is None
                                              else actions_optimizer_params)
@@ -102,6 +106,7 @@ class ControllerConfig:
         self.cem_candidates = cem_candidates                # candidates per iteration = one kernel launch
         self.cem_iterations = cem_iterations
         self.cem_elite_fraction = cem_elite_fraction
+        self.lbfgs_candidates = lbfgs_candidates            # None: restarts_optim starting points
 
 
 def _broadcast(v, shape):

@@ -49,6 +49,10 @@ class AbstractActionMapper:
         """dJ/d(action_model) (H, A) -> dJ/d(action_mpc) (H*A,) with pass-through clamps."""
         raise NotImplementedError
 
+    def chain_grad_model_to_mpc_batch(self, grad_model):
+        """(B, H, A) -> (B, H*A)."""
+        return np.stack([self.chain_grad_model_to_mpc(g) for g in np.asarray(grad_model, dtype=np.float64)])
+
 
 class NormalizationActionMapper(AbstractActionMapper):
     """Identity reshape (reference normalization_action_mapper.py:21-23)."""

@@ -217,6 +217,8 @@ class GpMpcController(BaseControllerObject):
             return self._random_shooting(state_mu, state_var)
         if getattr(cc, "candidate_optimizer", None) == "cem":
             return self._cross_entropy_search(state_mu, state_var)
+        if getattr(cc, "candidate_optimizer", None) == "lbfgs":
+            return self._batched_lbfgs_search(state_mu, state_var)
         opt_fun, best = np.inf, None
         for idx_restart in range(cc.restarts_optim):
             if cc.init_from_previous_actions and self.actions_mpc_previous_iter is not None and idx_restart == 0:
@@ -293,6 +295,99 @@ class GpMpcController(BaseControllerObject):
         self.best_candidate_J = best_J
         self.actions_mpc_previous_iter = best_x.copy()
         return self.actions_mapper.transform_action_mpc_to_action_model(best_x)
+
+    def objective_and_gradient_batch(self, actions_mpc_batch, obs_mu, obs_var):
+        """(B, H*A) optimiser vectors -> (J (B,), dJ/d(actions_mpc) (B, H*A)) in one gpmpc_rollout_grad launch."""
+        X = np.asarray(actions_mpc_batch, dtype=np.float64)
+        acts = self.actions_mapper.mpc_to_model_batch(X)
+        self.transition_model.set_cost(self.config.reward)
+        out = self.transition_model.objective_and_gradient_batch(acts, obs_mu, obs_var, self.iter_ctrl)
+        self.num_rollouts += X.shape[0]
+        J = out["J"].cpu().numpy()
+        G = self.actions_mapper.chain_grad_model_to_mpc_batch(out["grad"].cpu().numpy())
+        return J, G
+
+    def _batched_lbfgs_search(self, state_mu, state_var):
+        """All restarts at once.  The reference runs `restarts_optim` scipy L-BFGS-B solves one after
+        the other, every function evaluation a forward + autograd backward of ONE sequence (:125-141).  Here the same
+        scipy solver runs once per restart, each in its own thread, but the threads advance in lockstep: whenever every
+        unfinished restart is waiting for an evaluation, ONE objective + analytic-gradient launch serves them all.  Each
+        restart therefore sees exactly the values the sequential loop would hand it (the kernels are bitwise independent
+        of the batch composition), ends at the same point, and the keep-the-best rule (:146-148) picks the same winner;
+        the wall time is that of the longest restart instead of their sum."""
+        import threading
+        cc = self.config.controller
+        H, A = cc.len_horizon, self.actions_mapper.dim_action
+        B = int(cc.lbfgs_candidates or cc.restarts_optim)
+        x0s = []
+        for b in range(B):
+            if cc.init_from_previous_actions and self.actions_mpc_previous_iter is not None and b == 0:
+                x0s.append(generate_mpc_action_init_frompreviousiter(self.actions_mpc_previous_iter, dim_action=A))
+            else:
+                x0s.append(generate_mpc_action_init_random(len_horizon=H, dim_action=A))
+        cond = threading.Condition()
+        pending, results, state = {}, {}, {"running": B, "launches": 0, "error": None}
+
+        def flush():                                   # called with the lock held, by the last thread to arrive
+            idx = sorted(pending)
+            try:
+                J, G = self.objective_and_gradient_batch(np.stack([pending[i] for i in idx]), state_mu, state_var)
+            except BaseException as e:                 # hand the failure to every waiting restart
+                state["error"] = e
+                J, G = np.full(len(idx), np.nan), np.zeros((len(idx), H * A))
+            state["launches"] += 1
+            for k, i in enumerate(idx):
+                results[i] = (float(J[k]), G[k].copy())
+            pending.clear()
+            cond.notify_all()
+
+        def make_fun(i):
+            def fun(x):
+                with cond:
+                    pending[i] = np.array(x, dtype=np.float64)
+                    if len(pending) == state["running"]:
+                        flush()
+                    while i not in results:
+                        cond.wait()
+                    out = results.pop(i)
+                if state["error"] is not None:
+                    raise RuntimeError("batched evaluation failed") from state["error"]
+                return out
+            return fun
+
+        solved = [None] * B
+
+        def worker(i):
+            try:
+                solved[i] = minimize(fun=make_fun(i), x0=x0s[i], jac=True, method="L-BFGS-B",
+                                     bounds=self.actions_mapper.bounds, options=cc.actions_optimizer_params)
+            except BaseException as e:
+                solved[i] = e
+            finally:
+                with cond:
+                    state["running"] -= 1
+                    if pending and len(pending) == state["running"]:
+                        flush()
+
+        threads = [threading.Thread(target=worker, args=(i,), daemon=True) for i in range(B)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        for r in solved:
+            if isinstance(r, BaseException):
+                raise r
+        self.lbfgs_evaluations = state["launches"]
+        self.candidates_final_J = np.array([r.fun for r in solved])
+        opt_fun, best, best_i = np.inf, None, -1
+        for i, res in enumerate(solved):               # the reference's keep-the-best rule, in restart order
+            if res.fun < opt_fun or (best is None and np.isnan(res.fun)):
+                opt_fun, best, best_i = res.fun, res.x, i
+        self.best_candidate_index, self.best_candidate_J = best_i, float(opt_fun)
+        out = self.evaluate_candidates(best[None], state_mu, state_var, trajectories=True)
+        self._cache_trajectory(out, 0)
+        self.actions_mpc_previous_iter = best.copy()
+        return self.actions_mapper.transform_action_mpc_to_action_model(best)
 
     def _get_random_actions(self, state_mu, state_var):
         """Reference :155-163: one random sequence, evaluated only to fill the logging caches."""

@@ -151,3 +151,25 @@ def test_closed_loop_pendulum_with_training_process(engine):
     assert len(ctrl.info_iters["cost"]) == 22
     ls = ctrl.transition_model.lengthscales
     assert ls.shape == (3, 4) and torch.isfinite(ls).all()
+
+
+def test_lockstep_lbfgs_reproduces_the_sequential_scipy_restarts(engine):
+    """candidate_optimizer="lbfgs": the restarts' scipy L-BFGS-B solves (gp_mpc_controller.py:125-141) advance in
+    lockstep, one objective + gradient launch per round.  Same starting points => the same end point and objective
+    for every restart, bit for bit, and the same winner as the sequential loop (:146-148)."""
+    g = load("lcb_grad_norm")
+    w = workload_of(g)
+    restarts = 6
+    seq = make_controller(w, optimize=True, restarts=restarts, engine=engine)
+    np.random.seed(7)
+    a_seq = seq._get_optimal_actions(torch.as_tensor(w.mu0), torch.as_tensor(w.S0))
+    bat = make_controller(w, optimize=True, restarts=restarts, engine=engine)
+    bat.config.controller.candidate_optimizer = "lbfgs"
+    np.random.seed(7)
+    a_bat = bat._get_optimal_actions(torch.as_tensor(w.mu0), torch.as_tensor(w.S0))
+    assert np.array_equal(a_bat.numpy(), a_seq.numpy())
+    assert np.array_equal(bat.actions_mpc_previous_iter, seq.actions_mpc_previous_iter)
+    assert bat.num_rollouts == seq.num_rollouts + 1             # + the winner's trajectory for the logging caches
+    assert bat.lbfgs_evaluations < seq.num_rollouts / 2         # launches: the longest restart, not the sum
+    J_check, _ = bat.compute_mean_lcb_trajectory(bat.actions_mpc_previous_iter, torch.as_tensor(w.mu0), torch.as_tensor(w.S0))
+    assert J_check == bat.best_candidate_J
