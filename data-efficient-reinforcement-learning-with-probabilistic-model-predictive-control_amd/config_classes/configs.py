@@ -71,13 +71,14 @@ class MemoryConfig:
 
 class TrainingConfig:
     def __init__(self, lr_train=7e-3, iter_train=15, training_frequency=25, clip_grad_value=1e-3, print_train=False,
-                 step_print_train=5):
+                 step_print_train=5, device="auto"):
         self.lr_train = lr_train
         self.iter_train = iter_train
         self.training_frequency = training_frequency
         self.clip_grad_value = clip_grad_value
         self.print_train = print_train
         self.step_print_train = step_print_train
+        self.device = device      # "auto": gpmpc_mll on the GPU when one is visible to the training process; "hip"; "cpu"
 
 
 _DEFAULT_OPTIMIZER = {"disp": None, "maxcor": 30, "ftol": 1e-99, "gtol": 1e-99, "eps": 1e-2, "maxfun": 30,

@@ -175,7 +175,8 @@ class GpMpcController(BaseControllerObject):
         tc = self.config.training
         self.p_train = self.ctx.Process(target=GpStateTransitionModel.train,
                                         args=(self.queue_train, saved_state, tc.lr_train, tc.iter_train,
-                                              tc.clip_grad_value, tc.print_train, tc.step_print_train))
+                                              tc.clip_grad_value, tc.print_train, tc.step_print_train,
+                                              getattr(tc, "device", "auto")))
         self.p_train.start()
 
     def check_and_close_processes(self):

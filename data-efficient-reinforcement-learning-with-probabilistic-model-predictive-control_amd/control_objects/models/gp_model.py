@@ -97,6 +97,25 @@ def create_models(gp_init_dict, num_models, num_inputs):
             for i in range(num_models)]
 
 
+class _DeviceNegMll(torch.autograd.Function):
+    """-log p(y | X, theta) / N with its gradient from gpmpc_mll (reference: gpytorch ExactMarginalLogLikelihood +
+    autograd, gp_model.py:262-275)."""
+
+    @staticmethod
+    def forward(ctx, ls, osc, nz, engine, X_dev, y_dev):
+        out = engine.mll(X_dev, y_dev, ls.detach().reshape(1, -1), osc.detach().reshape(1), nz.detach().reshape(1))
+        ctx.shapes = (ls.shape, osc.shape, nz.shape)
+        ctx.grads = (out["d_lengthscale"][0], out["d_outputscale"][0], out["d_noise"][0])
+        return torch.tensor(float(out["loss"][0]), dtype=F64)
+
+    @staticmethod
+    def backward(ctx, gout):
+        gl, go, gn = ctx.grads
+        sl, so, sn = ctx.shapes
+        return (gout * torch.as_tensor(gl, dtype=F64).reshape(sl), gout * torch.tensor(float(go), dtype=F64).reshape(so),
+                gout * torch.tensor(float(gn), dtype=F64).reshape(sn), None, None, None)
+
+
 class GpStateTransitionModel(AbstractStateTransitionModel):
     def __init__(self, config, dim_state, dim_action, engine=None, device=None):
         super().__init__(config, dim_state, dim_action)
@@ -198,15 +217,23 @@ class GpStateTransitionModel(AbstractStateTransitionModel):
         self.prepare_inference(_t(saved_state.inputs), _t(saved_state.states_change))
 
     @staticmethod
-    def train(queue, saved_state, lr_train, num_iter_train, clip_grad_value, print_train=False, step_print_train=25):
+    def train(queue, saved_state, lr_train, num_iter_train, clip_grad_value, print_train=False, step_print_train=25,
+              device="auto"):
         """Exact-MLL hyper-parameter search (reference :193-306), one GP at a time: random restart inside
         the constraint box, LBFGS(strong_wolfe), keep the best, never return something worse than the
-        incoming parameters.  Runs in the spawned training process; CPU torch, fp64."""
+        incoming parameters.  Runs in the spawned training process, fp64.  The loss and its gradient come from
+        gpmpc_mll (K build + Cholesky + inverse + gradient contraction on the GPU, an engine of this process's own)
+        when `device` is "hip", or "auto" with a GPU visible; "cpu" keeps the plain torch expression."""
         t0 = time.time()
         saved_state.to_tensors()
         X, Y = saved_state.inputs, saved_state.states_change
         cons = saved_state.constraints_hyperparams
         N, E = X.shape
+        engine = None
+        if device == "hip" or (device == "auto" and torch.cuda.is_available()):
+            from ...engine import HipEngine
+            engine = HipEngine(0)
+            X_dev = torch.as_tensor(X, dtype=F64).to(engine.device).contiguous()
         out = []
         for a, p in enumerate(saved_state.parameters):
             lo = {"ls": _t(cons["min_lengthscale"])[a], "os": _t(cons["min_outputscale"])[a],
@@ -215,7 +242,12 @@ class GpStateTransitionModel(AbstractStateTransitionModel):
                   "nz": _t(cons["max_std_noise"])[a] ** 2}
             y = Y[:, a]
 
+            if engine is not None:
+                y_dev = torch.as_tensor(y, dtype=F64).reshape(N, 1).to(engine.device).contiguous()
+
             def neg_mll(ls, osc, nz):
+                if engine is not None:
+                    return _DeviceNegMll.apply(ls, osc, nz, engine, X_dev, y_dev)
                 d = (X[:, None, :] - X[None, :, :]) / ls
                 K = osc * torch.exp(-0.5 * (d * d).sum(-1)) + nz * torch.eye(N, dtype=F64)
                 L = torch.linalg.cholesky(K)
@@ -253,6 +285,8 @@ class GpStateTransitionModel(AbstractStateTransitionModel):
             out.append({GpHyperParameters.KEYS[0]: best["ls"].reshape(1, E).numpy(),
                         GpHyperParameters.KEYS[1]: best["os"].reshape(()).numpy(),
                         GpHyperParameters.KEYS[2]: best["nz"].reshape(1).numpy()})
+        if engine is not None:
+            engine.close()
         if print_train:
             print(f"training process: {time.time() - t0:.2f} s")
         queue.put(out)

@@ -25,7 +25,7 @@ static void free_buf(Buf& b) {
 
 extern "C" {
 
-int gpmpc_abi_version(void) { return 6; }
+int gpmpc_abi_version(void) { return 7; }
 
 int gpmpc_create(gpmpc_t** out, int device_id) {
     if (!out) return GPMPC_ERR_ARG;
@@ -53,7 +53,7 @@ int gpmpc_destroy(gpmpc_t* g) {
     (void)hipSetDevice(h->device);
     Buf* all[] = {&h->Xt, &h->beta, &h->iK, &h->Tm, &h->ils2, &h->var, &h->logvar, &h->gram,
                   &h->linv, &h->zvec, &h->cost, &h->best, &h->xrange, &h->mono_w, &h->traj, &h->Xc, &h->Yc,
-                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws};
+                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws};
     for (Buf* b : all) free_buf(*b);
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);
@@ -117,6 +117,16 @@ int gpmpc_read_factors(gpmpc_t* g, double* iK_dst, double* beta_dst, void* strea
     if (iK_dst) GPMPC_HIP_CHECK(h, hipMemcpyAsync(iK_dst, h->iK.p, DN * h->N * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     if (beta_dst) GPMPC_HIP_CHECK(h, hipMemcpyAsync(beta_dst, h->beta.p, DN * sizeof(double), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return GPMPC_OK;
+}
+
+int gpmpc_mll(gpmpc_t* g, const double* X, const double* Y, const double* ls, const double* os, const double* noise,
+              int N, int D, int E, double* out_host, void* stream) {
+    if (!g) return GPMPC_ERR_ARG;
+    if (!X || !Y || !ls || !os || !noise || !out_host) return bad(g, "null argument");
+    int rc = check_dims(g, N, D, E);
+    if (rc) return rc;
+    GPMPC_HIP_CHECK(H_(g), hipSetDevice(g->h.device));
+    return run_mll(H_(g), X, Y, ls, os, noise, N, D, E, out_host, (hipStream_t)stream);
 }
 
 int gpmpc_last_prepare_mode(gpmpc_t* g) { return g ? g->h.last_prepare_mode : GPMPC_ERR_ARG; }

@@ -90,6 +90,7 @@ struct Handle {
     Buf traj;     // (B, H+1, D) + (B, H+1, D, D) when the caller does not want the trajectory
     Buf xrange;   // (2, E) min / max of the inputs
     Buf gradws;   // gradient workspace: pair moments | mean sums | cost variances
+    Buf mllws;    // marginal-likelihood workspace: tile partial sums | results
     // incremental factorisation: what the cached factors were computed from, and border-update scratch
     Buf Xc, Yc;   // (N, E), (N, D) copies of the memory points of the last prepare
     Buf hyp;      // lengthscales (D*E) | outputscales (D) | noises (D) of the last prepare
@@ -156,6 +157,8 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
 int run_set_factors(Handle* h, const double* X, const double* iK, const double* beta,
                     const double* ls, const double* os, int N, int D, int E, hipStream_t s);
 int ensure_model_buffers(Handle* h, int N, int D, int E, bool need_factor_ws);
+int run_mll(Handle* h, const double* X, const double* Y, const double* ls, const double* os, const double* noise,
+            int N, int D, int E, double* out_host, hipStream_t s);
 int grow(Handle* h, Buf& b, size_t need);
 
 }  // namespace gpmpc_hip

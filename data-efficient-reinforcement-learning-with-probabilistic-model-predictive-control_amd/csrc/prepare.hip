@@ -508,6 +508,105 @@ int run_set_factors(Handle* h, const double* X, const double* iK, const double* 
     return GPMPC_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Exact marginal log-likelihood of the D GPs and its gradient wrt (lengthscales, outputscale, noise): what
+// gpytorch's ExactMarginalLogLikelihood + autograd give the reference's training loop (gp_model.py:262-275).
+// With Q = beta beta^T - iK (T_a holds its upper triangle, diagonal halved):  d mll / d theta = 1/2 tr(Q dK/dtheta),
+//   dK/dl_e = K' (x_ie - x_je)^2 / l_e^3,   dK/dsigma^2 = K' / sigma^2,   dK/dnoise = I      (K' = K without noise).
+// Tiles of the upper block triangle as in gram_kernel; K' is recomputed, never stored.  Per-block partial sums
+// are written out and added in a fixed order by mll_finish_kernel (bitwise reproducible).
+template <int EP>
+__global__ __launch_bounds__(256) void mll_tile_kernel(const double* __restrict__ Xt, const double* __restrict__ ils2,
+                                                       const double* __restrict__ var, const double* __restrict__ Tm,
+                                                       int N, int E, int tpad, double* __restrict__ partial) {
+    __shared__ double xi[64][EP + 1];
+    __shared__ double red[4][EP + 1];
+    const int a = blockIdx.z;
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    const int nt = gridDim.x;
+    double* out = partial + ((size_t)a * nt * nt + (size_t)ti * nt + tj) * (EP + 1);
+    if (tj < ti) return;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = ti * 64, j0 = tj * 64;
+    for (int idx = threadIdx.x; idx < 64 * EP; idx += 256) {
+        const int r = idx / EP, e = idx - r * EP;
+        const int i = i0 + r;
+        xi[r][e] = (e < E && i < N) ? Xt[(size_t)e * N + i] * sqrt(ils2[a * E + e]) : 0.0;
+    }
+    const int j = j0 + lane;
+    double xj[EP], acc[EP + 1];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) {
+        xj[e] = (e < E && j < N) ? Xt[(size_t)e * N + j] * sqrt(ils2[a * E + e]) : 0.0;
+        acc[e] = 0.0;
+    }
+    acc[EP] = 0.0;
+    __syncthreads();
+    const double va = var[a];
+    const double* Ta = Tm + (size_t)a * (N + tpad) * N;
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wave * 16 + rr;
+        const int i = i0 + r;
+        double d2[EP];
+        double s = 0.0;
+#pragma unroll
+        for (int e = 0; e < EP; ++e) { const double d = xi[r][e] - xj[e]; d2[e] = d * d; s += d2[e]; }
+        const double q = (i < N && j < N) ? 2.0 * Ta[(size_t)i * N + j] : 0.0;        // zero below the diagonal
+        const double wq = q * va * exp(-0.5 * s);
+#pragma unroll
+        for (int e = 0; e < EP; ++e) acc[e] = fma(wq, d2[e], acc[e]);
+        acc[EP] += wq;
+    }
+#pragma unroll
+    for (int k = 0; k <= EP; ++k) {
+        double v = acc[k];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[wave][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x <= EP) out[threadIdx.x] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// out[a] = [nll | d nll / d l_e (E) | d nll / d outputscale | d nll / d noise],  nll = -mll / N
+__global__ __launch_bounds__(256) void mll_finish_kernel(const double* __restrict__ partial, int nt, int EP,
+                                                         const double* __restrict__ Y, const double* __restrict__ beta,
+                                                         const double* __restrict__ L, const double* __restrict__ Tm,
+                                                         const double* __restrict__ ils2, const double* __restrict__ var,
+                                                         int N, int D, int E, int tpad, double* __restrict__ out) {
+    __shared__ double red[3][4];
+    __shared__ double sums[32];
+    const int a = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double yb = 0.0, ld = 0.0, tq = 0.0;
+    for (int i = threadIdx.x; i < N; i += 256) {
+        yb = fma(Y[(size_t)i * D + a], beta[(size_t)a * N + i], yb);
+        ld += log(L[((size_t)a * N + i) * N + i]);
+        tq += 2.0 * Tm[((size_t)a * (N + tpad) + i) * N + i];
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+        yb += __shfl_xor(yb, off, 64); ld += __shfl_xor(ld, off, 64); tq += __shfl_xor(tq, off, 64);
+    }
+    if (lane == 0) { red[0][wave] = yb; red[1][wave] = ld; red[2][wave] = tq; }
+    if (threadIdx.x <= EP) {                    // block partials of the upper block triangle, fixed order
+        double v = 0.0;
+        for (int ti = 0; ti < nt; ++ti)
+            for (int tj = ti; tj < nt; ++tj) v += partial[((size_t)a * nt * nt + (size_t)ti * nt + tj) * (EP + 1) + threadIdx.x];
+        sums[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double ybs = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        const double lds = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        const double tqs = (red[2][0] + red[2][1]) + (red[2][2] + red[2][3]);
+        double* o = out + (size_t)a * (E + 3);
+        const double invn = 1.0 / (double)N;
+        o[0] = (0.5 * ybs + lds + 0.5 * N * 1.8378770664093453) * invn;           // log(2 pi)
+        for (int e = 0; e < E; ++e) o[1 + e] = -0.5 * invn * sums[e] * sqrt(ils2[a * E + e]);     // S_e / l_e
+        o[1 + E] = -0.5 * invn * sums[EP] / var[a];
+        o[2 + E] = -0.5 * invn * tqs;
+    }
+}
+
 // remember what the cached factors were computed from
 static int record_state(Handle* h, const double* X, const double* Y, const double* ls, const double* os,
                         const double* noise, int N, int D, int E, hipStream_t s) {
@@ -637,6 +736,32 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     if ((rc = record_state(h, X, Y, ls, os, noise, N, D, E, s))) return rc;
     h->inc_updates = 0;
     h->N = N; h->D = D; h->E = E; h->ready = true;
+    return GPMPC_OK;
+}
+
+int run_mll(Handle* h, const double* X, const double* Y, const double* ls, const double* os, const double* noise,
+            int N, int D, int E, double* out_host, hipStream_t s) {
+    const int keep = h->opt_incremental;
+    h->opt_incremental = 0;                       // always a fresh factorisation: the hyper-parameters are the variables
+    int rc = run_prepare(h, X, Y, ls, os, noise, N, D, E, s);
+    h->opt_incremental = keep;
+    if (rc) return rc;
+    const int nt = (N + 63) / 64;
+    const int EP = E <= 4 ? 4 : (E <= 8 ? 8 : (E <= 16 ? 16 : 24));
+    const size_t npart = (size_t)D * nt * nt * (EP + 1), nout = (size_t)D * (E + 3);
+    if ((rc = grow(h, h->mllws, npart + nout))) return rc;
+    double* partial = h->mllws.p;
+    double* out = partial + npart;
+    const dim3 grid(nt, nt, D);
+    if (EP == 4) hipLaunchKernelGGL(mll_tile_kernel<4>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, h->Tm.p, N, E, kTPadRows, partial);
+    else if (EP == 8) hipLaunchKernelGGL(mll_tile_kernel<8>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, h->Tm.p, N, E, kTPadRows, partial);
+    else if (EP == 16) hipLaunchKernelGGL(mll_tile_kernel<16>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, h->Tm.p, N, E, kTPadRows, partial);
+    else hipLaunchKernelGGL(mll_tile_kernel<24>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, h->Tm.p, N, E, kTPadRows, partial);
+    hipLaunchKernelGGL(mll_finish_kernel, dim3(D), dim3(256), 0, s, partial, nt, EP, Y, h->beta.p, h->gram.p, h->Tm.p, h->ils2.p,
+                       h->var.p, N, D, E, kTPadRows, out);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(out_host, out, nout * sizeof(double), hipMemcpyDeviceToHost, s));
+    GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
     return GPMPC_OK;
 }
 

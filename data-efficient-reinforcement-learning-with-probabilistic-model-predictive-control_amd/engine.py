@@ -81,6 +81,23 @@ class HipEngine:
                                            nz.data_ptr(), N, D, E, self._stream()))
         self.N, self.D, self.E = N, D, E
 
+    def mll(self, X, Y, lengthscales, outputscales, noises):
+        """Training loss of the D GPs and its gradient (gp_model.py:262-275): dict(loss (D,), d_lengthscale (D,E),
+        d_outputscale (D,), d_noise (D,)) as numpy arrays.  Replaces the cached factors of this engine."""
+        X = self._dev(X)
+        N, E = X.shape
+        Y = self._dev(Y)
+        D = Y.shape[1]
+        ls = self._dev(lengthscales, (D, E))
+        osc = self._dev(outputscales).reshape(D)
+        nz = self._dev(noises).reshape(D)
+        out = np.empty((D, E + 3), dtype=np.float64)
+        self._check(self.lib.gpmpc_mll(self._h, X.data_ptr(), Y.data_ptr(), ls.data_ptr(), osc.data_ptr(), nz.data_ptr(),
+                                       N, D, E, out.ctypes.data_as(C.POINTER(C.c_double)), self._stream()))
+        self.N, self.D, self.E = N, D, E
+        return {"loss": out[:, 0].copy(), "d_lengthscale": out[:, 1:1 + E].copy(), "d_outputscale": out[:, 1 + E].copy(),
+                "d_noise": out[:, 2 + E].copy()}
+
     @property
     def last_prepare_mode(self):
         """0 = full factorisation, 1 = border update of the cached factors, 2 = cache hit."""

@@ -64,6 +64,18 @@ int gpmpc_prepare(gpmpc_t* h, const double* X_dev, const double* Y_dev,
                   const double* lengthscales_dev, const double* outputscales_dev,
                   const double* noises_dev, int N, int D, int E, void* stream);
 
+/*
+ * Hyper-parameter training objective: for each of the D GPs the negative exact marginal
+ * log-likelihood per data point, -log p(y_a | X, theta_a) / N, and its gradient wrt the lengthscales, the
+ * outputscale and the noise variance -- the loss gpytorch's ExactMarginalLogLikelihood and autograd give the
+ * reference's LBFGS loop (rl_gp_mpc/control_objects/models/gp_model.py:262-275).  Arguments as gpmpc_prepare;
+ * out_host (D, E + 3) = [loss | d/d lengthscale_e (E) | d/d outputscale | d/d noise], host memory, synchronous.
+ * Always factorises from scratch and REPLACES the handle's cached factors with those of these hyper-parameters:
+ * give the training loop a handle of its own.  GPMPC_ERR_NOT_PD as gpmpc_prepare.
+ */
+int gpmpc_mll(gpmpc_t* h, const double* X_dev, const double* Y_dev, const double* lengthscales_dev,
+              const double* outputscales_dev, const double* noises_dev, int N, int D, int E, double* out_host, void* stream);
+
 /* How the last gpmpc_prepare obtained its factors: 0 = full factorisation, 1 = border update of the cached
  * factors (the new memory was the cached one plus <= 8 appended points, hyper-parameters unchanged; O(k N^2)),
  * 2 = cache hit (nothing changed).  The reference refactorises at every control step

@@ -432,3 +432,31 @@ def test_full_size_c2_against_oracle_subset(engine):
     Sig = out["Sig"].cpu().numpy()
     assert np.max(np.abs(Sig - Sig.transpose(0, 1, 3, 2))) == 0.0      # built symmetric
     assert np.isfinite(out["J"].cpu().numpy()).all()
+
+
+@pytest.mark.parametrize("N,D,A,tm", [(40, 3, 1, False), (200, 3, 1, False), (130, 4, 2, True), (65, 1, 1, False), (300, 6, 3, False)])
+def test_training_loss_and_gradient(N, D, A, tm):
+    """gpmpc_mll: -log p(y | X, theta) / N of every GP and its gradient wrt (lengthscales, outputscale, noise), the loss
+    of the reference's LBFGS training loop (gp_model.py:262-275), vs the closed form of oracle/gp_training.py.
+    fp64: 1e-9 on the loss; the gradient goes through the explicit inverse (cond K ~ 1e5..1e6): 1e-7."""
+    import gp_mpc_amd
+    from oracle import gp_training
+    w = synth.make_workload(N, D, A, 3, 2, include_time=tm, seed=N)
+    e = gp_mpc_amd.HipEngine(0)
+    try:
+        out = e.mll(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+        again = e.mll(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+        for k in out:
+            assert np.array_equal(out[k], again[k])                  # fixed-order sums: bitwise reproducible
+        for a in range(D):
+            loss, g_ls, g_os, g_nz = gp_training.neg_mll_and_grad(w.X, w.Y[:, a], w.lengthscales[a], w.outputscales[a], w.noises[a])
+            assert abs(out["loss"][a] - loss) < 1e-9 * abs(loss)
+            assert rel_err(out["d_lengthscale"][a], g_ls) < 1e-7
+            assert abs(out["d_outputscale"][a] - g_os) < 1e-7 * abs(g_os)
+            assert abs(out["d_noise"][a] - g_nz) < 1e-7 * abs(g_nz)
+        # the factors left behind are those of these hyper-parameters
+        iK, beta = e.factors()
+        iK0, beta0 = orc.factorize(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+        assert rel_err(beta.cpu().numpy(), beta0) < 1e-8
+    finally:
+        e.close()

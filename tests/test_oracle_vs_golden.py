@@ -187,3 +187,21 @@ def test_numpy_adjoint_with_state_constraints_matches_differences_of_the_oracle(
             d[t, k] = h
             fd[t, k] = (8.0 * (Jof(a0 + d) - Jof(a0 - d)) - (Jof(a0 + 2 * d) - Jof(a0 - 2 * d))) / (12.0 * h)
     assert rel_err(grad, fd) < 1e-6
+
+
+# ----------------------------------------------------------------------------- training loss
+def test_training_loss_closed_form_gradient_matches_autograd():
+    """oracle/gp_training.py: the exact-MLL loss of the training loop (gp_model.py:262-275; parity-unpinned against a
+    gpytorch run, see the file header) -- closed-form gradient vs torch autograd of the same expression."""
+    import torch
+    from oracle import gp_training, synth
+    w = synth.make_workload(40, 3, 1, 3, 2, seed=9)
+    for a in range(3):
+        loss, g_ls, g_os, g_nz = gp_training.neg_mll_and_grad(w.X, w.Y[:, a], w.lengthscales[a], w.outputscales[a], w.noises[a])
+        tt = lambda v: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True)   # noqa: E731
+        ls, osc, nz = tt(w.lengthscales[a]), tt(w.outputscales[a]), tt(w.noises[a])
+        lt = gp_training.neg_mll_torch(torch.as_tensor(w.X), torch.as_tensor(w.Y[:, a]), ls, osc, nz)
+        lt.backward()
+        assert abs(loss - lt.item()) < 1e-10 * abs(loss)
+        assert rel_err(g_ls, ls.grad.numpy()) < 1e-8
+        assert abs(g_os - osc.grad.item()) < 1e-8 * abs(g_os) and abs(g_nz - nz.grad.item()) < 1e-8 * abs(g_nz)
