@@ -51,11 +51,12 @@ struct RolloutArgs {
     int force_path;          // 0 auto, 1 always direct exp, 2 Taylor but never separable (tests)
     int force_sep;           // 1: separable whenever the degree allows, ignoring the cost model (tests)
     int x_in_lds;            // 1: X^T is copied to LDS once per launch (the per-point pass reads it every step)
+    int cols2;               // 1: two adjacent columns per lane in the pairwise pass (halves the LDS broadcast traffic)
     // tiling
     int G;        // output pairs per group
     int CH;       // rows per chunk
     int RC;       // row chunks per column
-    unsigned magic_N;        // ceil(2^32 / N):   x / N   == umulhi(x, magic_N)   for the index ranges used
+    unsigned magic_N;        // ceil(2^32 / NC):  x / NC  == umulhi(x, magic_N), NC = N (or ceil(N / 2) with cols2)
     unsigned magic_wpp;      // ceil(2^32 / wpp): x / wpp == umulhi(x, magic_wpp)
     // initial state distribution
     double mu0[kMaxD];
@@ -118,6 +119,7 @@ struct Handle {
     int opt_rows_per_chunk = 0;
     int opt_force_path = 0;
     int opt_force_sep = 0;
+    int opt_cols_per_lane = 0;       // 0 auto, 1 / 2: columns per lane in the pairwise pass of the rollout kernel
     int opt_incremental = 1;         // reuse / border-update the cached factors when the memory only grew
     int opt_refresh_every = 32;      // full refactorisation after this many border updates (bounds drift)
     int last_prepare_mode = 0;       // 0 full, 1 border update(s), 2 unchanged (cache hit)

@@ -214,11 +214,14 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     bool gs = h->opt_force_global != 0;
     int G = 0, CH = 0, RC = 0;
     size_t lds_bytes = 0;
+    // two adjacent columns per lane where the one-column loop is bound by the LDS broadcast bandwidth (small D)
+    const bool cols2 = !gs && (h->opt_cols_per_lane == 2 || (h->opt_cols_per_lane == 0 && DP <= 4));
+    const int NCu = cols2 ? (N + 1) / 2 : N;     // column units per row chunk
     auto chunking = [&](int g) {
         // row chunks of up to 64 rows (fewer, longer items amortise the per-item prologue: 0.76 vs 0.80 ms at
         // config 2), but at least ~2 items per wave so that the queue can balance
-        long long want = 2LL * nw * 64;
-        long long rc = (want + (long long)g * N - 1) / ((long long)g * N);
+        long long want = (cols2 ? 4LL : 2LL) * nw * 64;      // two-column items are twice as heavy: aim at twice as many
+        long long rc = (want + (long long)g * NCu - 1) / ((long long)g * NCu);
         const long long rc64 = (N + 63) / 64;
         if (rc < rc64) rc = rc64;
         int maxrc = (N + 15) / 16;
@@ -235,7 +238,7 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         for (int xl = ((size_t)E * N * 8 <= 32 * 1024) ? 1 : 0; xl >= 0 && G == 0; --xl) {
             for (int g = P; g >= 1; --g) {
                 chunking(g);
-                const int wpp = (RC * N + 63) / 64;
+                const int wpp = (RC * NCu + 63) / 64;
                 Layout L = make_layout(N, D, A, E, g, DP, wpp, CM, CH, a.H * A, xl != 0);
                 if ((size_t)L.lds_total * 8 <= (size_t)h->lds_limit) {
                     G = g; lds_bytes = (size_t)L.lds_total * 8; a.x_in_lds = xl;
@@ -258,14 +261,16 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         nt = 1024;
     }
     a.G = G; a.CH = CH; a.RC = RC;
+    a.cols2 = (cols2 && !gs) ? 1 : 0;
+    const int NCf = a.cols2 ? NCu : N;
     {
         // exact division by multiply-high: for d >= 2, umulhi(x, ceil(2^32 / d)) == x / d whenever x * d < 2^32
         // (magic 0 encodes d == 1: no division)
-        const unsigned wppv = (unsigned)((RC * N + 63) / 64);
+        const unsigned wppv = (unsigned)((RC * NCf + 63) / 64);
         auto magic = [](unsigned d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + d - 1) / d); };
-        a.magic_N = magic((unsigned)N);
+        a.magic_N = magic((unsigned)NCf);
         a.magic_wpp = magic(wppv);
-        if ((unsigned long long)RC * N * N >= 0x100000000ULL || (unsigned long long)G * wppv * wppv >= 0x100000000ULL) {
+        if ((unsigned long long)RC * NCf * NCf >= 0x100000000ULL || (unsigned long long)G * wppv * wppv >= 0x100000000ULL) {
             h->err = "rollout: index range too large for the multiply-high division"; return GPMPC_ERR_LIMIT;
         }
     }

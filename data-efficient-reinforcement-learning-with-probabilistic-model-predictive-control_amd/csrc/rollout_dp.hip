@@ -21,7 +21,8 @@ static int launch_variant(Handle* h, RolloutArgs& a, bool global_scratch, size_t
         return GPMPC_OK;
     }
     const bool exact = (a.D == DP);
-    auto kern = exact ? rollout_kernel<DP, NT, DP> : rollout_kernel<DP, NT, 0>;
+    auto kern = a.cols2 ? (exact ? rollout_kernel<DP, NT, DP, true> : rollout_kernel<DP, NT, 0, true>)
+                        : (exact ? rollout_kernel<DP, NT, DP, false> : rollout_kernel<DP, NT, 0, false>);
     {
         int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
         if (rc) return rc;

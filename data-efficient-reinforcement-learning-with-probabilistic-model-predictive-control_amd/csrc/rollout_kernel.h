@@ -442,6 +442,95 @@ __device__ inline double item_exp(const double* rec, int nrows, const double (&w
     return acc;
 }
 
+// Two columns per lane (j, j + 1): the row operands (ev_i, g_i) are LDS broadcasts whose return bandwidth, not the
+// VALU, bounds the one-column loop at small D (32 bytes per lane and row for 12 FMAs); serving two columns per read
+// halves that traffic.  Two rows x two columns in flight = the same four independent chains as the one-column loop.
+template <int DP, int K>
+__device__ inline void item_taylor2(const double* rec, int nrows, const double (&w0)[DP], const double (&w1)[DP], bool diag,
+                                    const double* Tp, int N, double& acc0, double& acc1) {
+    constexpr int RS = DP + 2;
+    constexpr int U = 2;
+    acc0 = 0.0;
+    acc1 = 0.0;
+    if (diag) {
+        double t0[U], t1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { t0[u] = Tp[(size_t)u * N]; t1[u] = Tp[(size_t)u * N + 1]; }
+        for (int it = 0; it < nrows; it += U) {
+            double n0[U], n1[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { n0[u] = Tp[(size_t)(U + u) * N]; n1[u] = Tp[(size_t)(U + u) * N + 1]; }
+            double c0[U], c1[U], ev[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double* r = rec + u * RS;
+                double a = r[2] * w0[0], b = r[2] * w1[0];
+#pragma unroll
+                for (int d = 1; d < DP; ++d) { a = fma(r[2 + d], w0[d], a); b = fma(r[2 + d], w1[d], b); }
+                c0[u] = a; c1[u] = b;
+                ev[u] = r[0];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc0 = fma(taylor_exp<K>(c0[u]) * ev[u], t0[u], acc0);
+                acc1 = fma(taylor_exp<K>(c1[u]) * ev[u], t1[u], acc1);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { t0[u] = n0[u]; t1[u] = n1[u]; }
+            rec += U * RS;
+            Tp += (size_t)U * N;
+        }
+    } else {
+        for (int it = 0; it < nrows; it += U) {
+            double c0[U], c1[U], rv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const double* r = rec + u * RS;
+                double a = r[2] * w0[0], b = r[2] * w1[0];
+#pragma unroll
+                for (int d = 1; d < DP; ++d) { a = fma(r[2 + d], w0[d], a); b = fma(r[2 + d], w1[d], b); }
+                c0[u] = a; c1[u] = b;
+                rv[u] = r[1];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc0 = fma(taylor_exp<K>(c0[u]), rv[u], acc0);
+                acc1 = fma(taylor_exp<K>(c1[u]), rv[u], acc1);
+            }
+            rec += U * RS;
+        }
+    }
+}
+
+template <int DP>
+__device__ inline void item_exp2(const double* rec, int nrows, const double (&w0)[DP], const double (&w1)[DP], double kb0,
+                                 double kb1, bool diag, const double* Tp, int N, const double* tab, double& acc0, double& acc1) {
+    constexpr int RS = DP + 2;
+    constexpr int U = 2;
+    acc0 = 0.0;
+    acc1 = 0.0;
+    for (int it = 0; it < nrows; it += U) {
+        double a0[U], a1[U], wt0[U], wt1[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const double* r = rec + u * RS;
+            double x = r[0] + kb0, y = r[0] + kb1;
+#pragma unroll
+            for (int d = 0; d < DP; ++d) { x = fma(r[2 + d], w0[d], x); y = fma(r[2 + d], w1[d], y); }
+            a0[u] = x; a1[u] = y;
+            wt0[u] = diag ? Tp[(size_t)u * N] : r[1];
+            wt1[u] = diag ? Tp[(size_t)u * N + 1] : r[1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            acc0 = fma(fast_exp(a0[u], tab), wt0[u], acc0);
+            acc1 = fma(fast_exp(a1[u], tab), wt1[u], acc1);
+        }
+        rec += U * RS;
+        Tp += (size_t)U * N;
+    }
+}
+
 __device__ inline int wave_max_i32(int v) {
     auto step = [&](auto ctrl, auto rmask) {
         const int o = __builtin_amdgcn_update_dpp(0, v, decltype(ctrl)::value, decltype(rmask)::value, 0xf, true);
@@ -459,7 +548,7 @@ __device__ inline int wave_max_i32(int v) {
 // ------------------------------------------------------------------------------------------
 // DX = exact state dimension known at compile time (0: runtime p.D <= DP): folds every D-dependent
 // offset and small loop, which is what keeps the 128-VGPR budget of a 1024-thread workgroup.
-template <int DP, int NT, int DX>
+template <int DP, int NT, int DX, bool C2>
 __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NT / kWave;
@@ -473,10 +562,11 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     const int P = D * (D + 1) / 2;
     const int DA = D + A;
     const int LD = 2 * D;                   // row stride of an augmented block
-    const int wpp = (p.RC * N + 63) / 64;   // work-item slots per output pair
+    const int NC = C2 ? (N + 1) / 2 : N;    // column units per row chunk: columns, or pairs of adjacent columns
+    const int wpp = (p.RC * NC + 63) / 64;  // work-item slots per output pair
     const int SD2 = rnd2(D * D);
 
-    const Layout L = make_layout(N, D, A, E, G, DP, wpp, CM, p.CH, H * A, p.x_in_lds != 0);
+    const Layout L = make_layout(N, D, A, E, G, DP, wpp, CM, p.CH, H * A, p.x_in_lds != 0);     // the host sized it with the same wpp
     const int NR = N + p.CH;                // rows per pair in the row-record array (data + zero padding)
     double* s_mu = smem + L.mu;
     double* s_Sig2 = smem + L.Sig;
@@ -845,13 +935,16 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     continue;
                 }
                 const int flat = slot * 64 + lane;
-                const bool valid = flat < p.RC * N;
-                const int r = valid ? (p.magic_N ? (int)__umulhi((unsigned)flat, p.magic_N) : flat) : 0;   // flat / N
-                const int j = valid ? flat - r * N : 0;
+                const bool valid = flat < p.RC * NC;
+                const int r = valid ? (p.magic_N ? (int)__umulhi((unsigned)flat, p.magic_N) : flat) : 0;   // flat / NC
+                const int jc = valid ? flat - r * NC : 0;
+                const int j = C2 ? 2 * jc : jc;
+                const bool valid1 = C2 && (j + 1 < N);        // second column of the lane (two-column form)
+                const int jl = valid1 ? j + 1 : j;            // last column of the lane
                 const int i0 = r * p.CH;                      // CH is a multiple of 4
                 int i1 = i0 + p.CH;
                 if (i1 > N) i1 = N;
-                if (diag && i1 > j + 1) i1 = j + 1;
+                if (diag && i1 > jl + 1) i1 = jl + 1;
                 const int len = (valid && i1 > i0) ? (i1 - i0) : 0;
                 const int nrows = (wave_max_i32(len) + 3) & ~3;    // wave-uniform, zero padding absorbs the overshoot
                 double acc = 0.0;
@@ -862,7 +955,29 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     const double kbj = a_kb[gq * N + j];
                     const double* rec = a_rows + ((size_t)gq * NR + i0) * RS;
                     const double* Tp = p.Tm + ((size_t)a * (N + kTPad) + i0) * N + j;
-                    if (K == 0) {
+                    if constexpr (C2) {
+                        double w1[DP];
+#pragma unroll
+                        for (int d = 0; d < DP; ++d) w1[d] = (d < D && valid1) ? a_nu[d * N + j + 1] * c_ils2[b * E + d] : 0.0;
+                        const double kb1 = valid1 ? a_kb[gq * N + j + 1] : 0.0;
+                        double acc0, acc1;
+                        if (K == 0) {
+                            item_exp2<DP>(rec, nrows, w, w1, kbj, kb1, diag, Tp, N, c_exptab, acc0, acc1);
+                            acc = acc0 * (diag ? 2.0 : p.beta[b * N + j]) + (valid1 ? acc1 * (diag ? 2.0 : p.beta[b * N + j + 1]) : 0.0);
+                        } else {
+                            if (K <= 2) item_taylor2<DP, 2>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K == 3) item_taylor2<DP, 3>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K == 4) item_taylor2<DP, 4>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K == 5) item_taylor2<DP, 5>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K == 6) item_taylor2<DP, 6>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K == 7) item_taylor2<DP, 7>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K == 8) item_taylor2<DP, 8>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K <= 10) item_taylor2<DP, 10>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K <= 12) item_taylor2<DP, 12>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else item_taylor2<DP, 14>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            acc = fma(acc0, kbj, acc1 * kb1) * (diag ? 2.0 : 1.0);
+                        }
+                    } else if (K == 0) {
                         acc = item_exp<DP>(rec, nrows, w, kbj, diag, Tp, N, c_exptab);
                         acc *= diag ? 2.0 : p.beta[b * N + j];
                     } else {
