@@ -22,7 +22,7 @@ int launch_moments(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s
 
 template <int DP, int NT>
 int launch_sweep(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s) {
-    auto kern = adjoint_sweep_kernel<DP, NT>;
+    auto kern = (g.D == DP) ? adjoint_sweep_kernel<DP, NT, DP> : adjoint_sweep_kernel<DP, NT, 0>;
     int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
     if (rc) return rc;
     hipLaunchKernelGGL(kern, dim3(g.B), dim3(NT), lds_bytes, s, g);

@@ -493,10 +493,14 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
 
 // ------------------------------------------------------------------------------------------
 constexpr int kSweepAug = 16;     // LDS augmented blocks of the sweep (D > 4)
+// registers per lane that hold the next step's moments: max(P * NSP, D * NM) / NT for the largest shapes of a padded D
+// (NX <= 6): DP 2: 3*14 | 2*24 -> 1 (64 lanes);  3: 6*19 | 3*54 -> 3;  4: 10*25 | 4*94 -> 6;  6: 21*40 | 6*223 -> 6 (256 lanes);  8: 36*57 | 8*423 -> 14
+template <int DP, int NT>
+constexpr int kSweepPrefetch = (DP == 2) ? 1 : (DP == 3) ? 3 : (DP == 4) ? 6 : (DP == 6) ? 6 : 14;
 
 struct SweepLayout {
     int c_ils2, c_var, cost, gmu, gSig, gu, ctmp, mubar, Sigbar, Sacc, mbar, m, Sig, ms, mom, Ai, cc, M, y, V, Sb, Vb, Mb, cb, s0b,
-        s1b, Gs, Aib, Ab, mba, Ri, Z, rdet, RZ, mq, aug, total;
+        s1b, Gs, Aib, Ab, mba, Ri, Z, rdet, RZ, Kq, mq, aug, total;
 };
 
 __host__ __device__ inline SweepLayout make_sweep_layout(int D, int A, int E, int H, int NSP, int nwaves, int naug) {
@@ -511,7 +515,7 @@ __host__ __device__ inline SweepLayout make_sweep_layout(int D, int A, int E, in
     take(L.Ai, D * DD); take(L.cc, D); take(L.M, D);
     take(L.y, DD); take(L.V, DD); take(L.Sb, DD); take(L.Vb, DD); take(L.Mb, D); take(L.cb, D); take(L.s0b, D); take(L.s1b, DD);
     take(L.Gs, D * (D + DD + NX)); take(L.Aib, D * DD); take(L.Ab, D * DD); take(L.mba, D * E);
-    take(L.Ri, P * DD); take(L.Z, P * DD); take(L.rdet, P); take(L.RZ, P * DD); take(L.mq, P * E);
+    take(L.Ri, P * DD); take(L.Z, P * DD); take(L.rdet, P); take(L.RZ, P * DD); take(L.Kq, D <= 4 ? P * DD : 0); take(L.mq, P * E);
     take(L.aug, naug * D * 2 * D);
     L.total = o;
     return L;
@@ -581,14 +585,38 @@ __device__ inline void cost_adjoint_wave(int lane, int D, int A, bool terminal, 
 }
 
 // One workgroup per candidate (one wavefront for D <= 4: every hand-off is then a wave-level LDS sync).
-template <int DP, int NT>
+// DX = exact state dimension at compile time (0: runtime p.D <= DP): the index arithmetic of this latency-bound kernel
+// (divisions by D and D*D, pair decoding) then folds into constants.
+template <int DP, int NT, int DX>
 __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NT / kWave;
-    auto sync = [] { if constexpr (NT == 64) wave_lds_sync(); else __syncthreads(); };
+    constexpr int NPF = kSweepPrefetch<DP, NT>;
+    // LDS-only hand-off: the fences name the local address space, so a sync does not wait for the global loads of the
+    // next step that are in flight
+    auto sync = [] {
+        if constexpr (NT == 64) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+    };
+#if defined(GPMPC_PROF_ON)
+    long long sprof[12] = {0};
+    long long sprof_last = __builtin_readcyclecounter();
+#define GPMPC_STRACE(id) do { if (threadIdx.x == 0 && blockIdx.x == 0) { long long now_ = __builtin_readcyclecounter(); \
+    sprof[id] += now_ - sprof_last; sprof_last = now_; } } while (0)
+#else
+#define GPMPC_STRACE(id) do {} while (0)
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x;
-    const int D = p.D, A = p.A, E = p.E, H = p.H;
+    const int D = (DX > 0) ? DX : p.D;
+    const int A = p.A, E = p.E, H = p.H;
     const int NX = E - D, P = D * (D + 1) / 2, DD = D * D, n = D + A;
     const int NSP = p.NSP, NH = DP * (DP + 1) / 2;
     const int NG = D + DD + NX;
@@ -604,6 +632,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
     double* s_s0b = smem + L.s0b; double* s_s1b = smem + L.s1b; double* s_Gs = smem + L.Gs; double* s_Aib = smem + L.Aib;
     double* s_Ab = smem + L.Ab; double* s_mba = smem + L.mba; double* s_Ri = smem + L.Ri; double* s_Z = smem + L.Z;
     double* s_rdet = smem + L.rdet; double* s_RZ = smem + L.RZ; double* s_mq = smem + L.mq;
+    double* s_Kq = (DP <= 4) ? smem + L.Kq : s_RZ;          // K_q: own buffer, or in place over RZ
     [[maybe_unused]] double* s_aug = smem + L.aug;
     const double* target = c_cost;
     const double* Wst = c_cost + n;
@@ -638,23 +667,40 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
     }
     sync();
 
+    // NPF values per lane cover P*NSP and D*NM (host checks the bound); E, D*D <= NT
+    double pf_mom[NPF], pf_ms[NPF], pf_m = 0.0, pf_Sig = 0.0;
+    auto fetch = [&](int t) {
+        const double* mom = p.mom + ((size_t)c * H + t) * P * NSP;
+        const double* ms = p.msum + ((size_t)c * H + t) * D * NM;
+#pragma unroll
+        for (int k = 0; k < NPF; ++k) {
+            const int i = tid + k * NT;
+            pf_mom[k] = (i < P * NSP) ? mom[i] : 0.0;
+            pf_ms[k] = (i < D * NM) ? ms[i] : 0.0;
+        }
+        // one load per value, no branch between the loads (a second load into a register still in flight would
+        // make the compiler wait for everything outstanding)
+        const double* msrc = (tid < D) ? traj_mu + t * D + tid : act + t * A + (tid < D + A ? tid - D : 0);
+        pf_m = *msrc;                               // lanes >= D + A read a valid dummy; selected away when consumed
+        pf_Sig = traj_Sig[t * DD + (tid < DD ? tid : 0)];
+    };
+    fetch(H - 1);
     for (int t = H - 1; t >= 0; --t) {
-        // ---- forward quantities of step t -------------------------------------------------------------
+        // ---- forward quantities of step t: already in registers (loaded one step ahead); the loads of step t-1 are
+        //      issued here and stay in flight during this step's algebra --------------------------------------
         {
-            const double* mom = p.mom + ((size_t)c * H + t) * P * NSP;
-            const double* ms = p.msum + ((size_t)c * H + t) * D * NM;
-            for (int i = tid; i < P * NSP; i += NT) s_mom[i] = mom[i];
-            for (int i = tid; i < D * NM; i += NT) s_ms[i] = ms[i];
-            for (int i = tid; i < E; i += NT) {
-                double v;
-                if (i < D) v = traj_mu[t * D + i];
-                else if (i < D + A) v = act[t * A + (i - D)];
-                else v = p.time0 + (double)t;
-                s_m[i] = v;
+#pragma unroll
+            for (int k = 0; k < NPF; ++k) {
+                const int i = tid + k * NT;
+                if (i < P * NSP) s_mom[i] = pf_mom[k];
+                if (i < D * NM) s_ms[i] = pf_ms[k];
             }
-            for (int i = tid; i < DD; i += NT) s_Sig[i] = traj_Sig[t * DD + i];
+            if (tid < E) s_m[tid] = (tid < D + A) ? pf_m : p.time0 + (double)t;
+            if (tid < DD) s_Sig[tid] = pf_Sig;
+            if (t > 0) fetch(t - 1);
         }
         sync();
+        GPMPC_STRACE(0);
         // ---- small solves: A_a^-1, c_a;  R_ab^-1, Z_ab, 1/sqrt det R_ab --------------------------------
         constexpr int PSTEP = (DP <= 4) ? NT : kSweepAug;        // LDS solves: kSweepAug threads, one augmented block each
         for (int prob = tid; prob < D + P && tid < PSTEP; prob += PSTEP) {
@@ -708,6 +754,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             s_Sb[i] = 0.5 * (Sigbar[i] + Sigbar[q * D + r]);
         }
         sync();
+        GPMPC_STRACE(1);
         // ---- Z = R^-1 Sigma;  y = A^-1 s1, V, M --------------------------------------------------------
         for (int i = tid; i < P * DD; i += NT) {
             const int q = i / DD, r = (i - q * DD) / D, cc = i - q * DD - r * D;
@@ -724,6 +771,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         }
         for (int a = tid; a < D; a += NT) s_M[a] = s_cc[a] * s_ms[a * NM];
         sync();
+        GPMPC_STRACE(2);
         // ---- Sigma' = Sigma + S + Sigma V + (Sigma V)^T,  mu' = mu + M,  S -= M M^T ------------------
         for (int i = tid; i < DD; i += NT) {
             const int r = i / D, q = i - r * D;
@@ -752,6 +800,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             s_RZ[i] = 0.5 * Wb * v;
         }
         sync();
+        GPMPC_STRACE(3);
         for (int i = tid; i < DD; i += NT) {
             const int a = i / D, k = i - a * D;
             double v = 0.0;
@@ -764,25 +813,38 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             s_cb[a] = v;                                                         // c_bar
             s_s0b[a] = s_Mb[a] * s_cc[a];
         }
-        // pairs: K_q = RZ + (coef R^-T - RZ Z^T) diag(dab), one thread per row, in place over RZ;  m_q
-        for (int i = tid; i < P * D; i += NT) {
-            const int q = i / D, r = i - q * D;
-            int a, b;
-            pair_of(q, a, b);
-            const double sb = (a == b) ? s_Sb[a * D + a] : 2.0 * s_Sb[a * D + b];
-            const double coef = -0.5 * sb * s_mom[q * NSP] * s_rdet[q];
-            double row[8];
-#pragma unroll
-            for (int l = 0; l < 8; ++l) row[l] = (l < D) ? s_RZ[q * DD + r * D + l] : 0.0;
-            for (int cc = 0; cc < D; ++cc) {
+        // pairs: K_q = RZ + (coef R^-T - RZ Z^T) diag(dab);  m_q
+        if constexpr (DP <= 4) {
+            for (int i = tid; i < P * DD; i += NT) {                 // one thread per element, own buffer
+                const int q = i / DD, r = (i - q * DD) / D, cc = i - q * DD - r * D;
+                int a, b;
+                pair_of(q, a, b);
+                const double sb = (a == b) ? s_Sb[a * D + a] : 2.0 * s_Sb[a * D + b];
+                const double coef = -0.5 * sb * s_mom[q * NSP] * s_rdet[q];
                 double rzzt = 0.0;
+                for (int l = 0; l < D; ++l) rzzt = fma(s_RZ[q * DD + r * D + l], s_Z[q * DD + cc * D + l], rzzt);
+                s_Kq[i] = s_RZ[i] + (coef * s_Ri[q * DD + cc * D + r] - rzzt) * (c_ils2[a * E + cc] + c_ils2[b * E + cc]);
+            }
+        } else {
+            for (int i = tid; i < P * D; i += NT) {                  // one thread per row, in place over RZ (LDS budget)
+                const int q = i / D, r = i - q * D;
+                int a, b;
+                pair_of(q, a, b);
+                const double sb = (a == b) ? s_Sb[a * D + a] : 2.0 * s_Sb[a * D + b];
+                const double coef = -0.5 * sb * s_mom[q * NSP] * s_rdet[q];
+                double row[8];
 #pragma unroll
-                for (int l = 0; l < 8; ++l)
-                    if (l < D) rzzt = fma(row[l], s_Z[q * DD + cc * D + l], rzzt);
-                double self = 0.0;
+                for (int l = 0; l < 8; ++l) row[l] = (l < D) ? s_RZ[q * DD + r * D + l] : 0.0;
+                for (int cc = 0; cc < D; ++cc) {
+                    double rzzt = 0.0;
 #pragma unroll
-                for (int l = 0; l < 8; ++l) self = (l == cc) ? row[l] : self;
-                s_RZ[q * DD + r * D + cc] = self + (coef * s_Ri[q * DD + cc * D + r] - rzzt) * (c_ils2[a * E + cc] + c_ils2[b * E + cc]);
+                    for (int l = 0; l < 8; ++l)
+                        if (l < D) rzzt = fma(row[l], s_Z[q * DD + cc * D + l], rzzt);
+                    double self = 0.0;
+#pragma unroll
+                    for (int l = 0; l < 8; ++l) self = (l == cc) ? row[l] : self;
+                    s_RZ[q * DD + r * D + cc] = self + (coef * s_Ri[q * DD + cc * D + r] - rzzt) * (c_ils2[a * E + cc] + c_ils2[b * E + cc]);
+                }
             }
         }
         for (int i = tid; i < P * E; i += NT) {
@@ -802,6 +864,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             s_mq[i] = v;
         }
         sync();
+        GPMPC_STRACE(4);
         // ---- mean part: G1, G2, Ge from the stored moments (q_bar_i = -1/2 lb_i (s0_bar + s1_bar . nu_i)) ----
         for (int i = tid; i < D * NG; i += NT) {
             const int a = i / NG, k = i - a * NG;
@@ -827,6 +890,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             s_Gs[i] = -0.5 * v;
         }
         sync();
+        GPMPC_STRACE(5);
         for (int i = tid; i < D * DD; i += NT) {
             const int a = i / DD, k = (i - a * DD) / D, l = i - a * DD - k * D;
             const double* G2 = s_Gs + a * NG + D;
@@ -847,6 +911,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             s_mba[i] = v;
         }
         sync();
+        GPMPC_STRACE(6);
         // A_bar = -A^-1 Ai_bar A^-1 - 1/2 c_bar c A^-1
         for (int i = tid; i < D * DD; i += NT) {
             const int a = i / DD, r = (i - a * DD) / D, cc = i - a * DD - r * D;
@@ -860,11 +925,12 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             s_Ab[i] = -v - 0.5 * s_cb[a] * s_cc[a] * Ai[r * D + cc];
         }
         sync();
+        GPMPC_STRACE(7);
         // ---- assemble (fixed order) -------------------------------------------------------------------
         for (int i = tid; i < DD; i += NT) {
             double v = Sacc[i];
             for (int a = 0; a < D; ++a) v += s_Ab[a * DD + i];
-            for (int q = 0; q < P; ++q) v += s_RZ[q * DD + i];
+            for (int q = 0; q < P; ++q) v += s_Kq[q * DD + i];
             Sacc[i] = v;
         }
         for (int e = tid; e < E; e += NT) {
@@ -874,6 +940,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             mbar[e] = v;
         }
         sync();
+        GPMPC_STRACE(8);
         for (int i = tid; i < DD; i += NT) {
             const int r = i / D, q = i - r * D;
             Sigbar[i] = 0.5 * (Sacc[i] + Sacc[q * D + r]) + 0.5 * (gSig[t * DD + i] + gSig[t * DD + q * D + r]);
@@ -881,7 +948,13 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         for (int i = tid; i < D; i += NT) mubar[i] = mbar[i] + gmu[t * D + i];
         for (int i = tid; i < A; i += NT) p.grad[((size_t)c * H + t) * A + i] = mbar[D + i] + gu[t * A + i];
         sync();
+        GPMPC_STRACE(9);
     }
+#if defined(GPMPC_PROF_ON)
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        printf("PROF sweep cycles: load %lld | solves %lld | Z,y,V %lld | Sacc,Vb,RZ %lld | s1b,K,mq %lld | G %lld | Aib,mba %lld | Ab %lld | assemble %lld | finish %lld\n",
+               sprof[0], sprof[1], sprof[2], sprof[3], sprof[4], sprof[5], sprof[6], sprof[7], sprof[8], sprof[9]);
+#endif
 }
 
 }  // namespace gpmpc_hip
