@@ -119,6 +119,7 @@ struct Handle {
     int opt_rows_per_chunk = 0;
     int opt_force_path = 0;
     int opt_force_sep = 0;
+    int opt_grad_cols = 0;           // 2: two columns per lane in the gradient's moment pass (A/B)
     int opt_cols_per_lane = 0;       // 0 auto, 1 / 2: columns per lane in the pairwise pass of the rollout kernel
     int opt_incremental = 1;         // reuse / border-update the cached factors when the memory only grew
     int opt_refresh_every = 32;      // full refactorisation after this many border updates (bounds drift)

@@ -10,12 +10,20 @@ constexpr int kMomThreads = 512;
 
 template <int DP, int NXP>
 int launch_moments(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s) {
-    // 16 waves per (candidate, step) where the accumulators fit the 128-VGPR budget of a 1024-thread workgroup
-    constexpr int NT = (DP <= 3) ? 1024 : kMomThreads;
-    auto kern = pair_moments_kernel<DP, NXP, NT>;
-    int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
-    if (rc) return rc;
-    hipLaunchKernelGGL(kern, dim3(g.H, g.B), dim3(NT), lds_bytes, s, g);
+    if (g.cols == 2) {
+        // two columns per lane: twice the accumulators, 8 waves per (candidate, step)
+        auto kern = pair_moments_kernel<DP, NXP, kMomThreads, 2>;
+        int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(g.H, g.B), dim3(kMomThreads), lds_bytes, s, g);
+    } else {
+        // 16 waves per (candidate, step) where the accumulators fit the 128-VGPR budget of a 1024-thread workgroup
+        constexpr int NT = (DP <= 3) ? 1024 : kMomThreads;
+        auto kern = pair_moments_kernel<DP, NXP, NT, 1>;
+        int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+        if (rc) return rc;
+        hipLaunchKernelGGL(kern, dim3(g.H, g.B), dim3(NT), lds_bytes, s, g);
+    }
     GPMPC_HIP_CHECK(h, hipGetLastError());
     return GPMPC_OK;
 }
@@ -54,7 +62,11 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     const int CH = (N >= 64) ? 64 : ((N + 3) & ~3);
     const int RC = (N + CH - 1) / CH;
     const int NR = RC * CH;
-    const int wpp = (RC * N + 63) / 64;
+    // two columns per lane need > 128 VGPRs, i.e. 8 waves instead of 16 per workgroup: measured slower at config 2
+    // (2.86 vs 2.10 ms), so one column unless asked (option "grad_cols_per_lane")
+    const int cols = (h->opt_grad_cols == 2) ? 2 : 1;
+    const int NCU = (N + cols - 1) / cols;
+    const int wpp = (RC * NCU + 63) / 64;
     int G = 0;
     size_t mom_lds = 0;
     for (int gg = P; gg >= 1; --gg) {
@@ -66,7 +78,7 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     if (G == 0 || (size_t)SL.total * 8 > (size_t)h->lds_limit) {
         h->err = "gradient: N too large for the LDS-resident gradient kernels"; return GPMPC_ERR_LIMIT;
     }
-    if ((unsigned long long)RC * N * N >= 0x100000000ULL || (unsigned long long)G * wpp * wpp >= 0x100000000ULL) {
+    if ((unsigned long long)RC * NCU * NCU >= 0x100000000ULL || (unsigned long long)G * wpp * wpp >= 0x100000000ULL) {
         h->err = "gradient: index range too large for the multiply-high division"; return GPMPC_ERR_LIMIT;
     }
     auto magic = [](unsigned d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + d - 1) / d); };
@@ -89,7 +101,8 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     g.grad = grad_out;
     g.DP = DP; g.NXP = NXP; g.NSP = NSP;
     g.G = G; g.CH = CH; g.RC = RC; g.wpp = wpp;
-    g.magic_N = magic((unsigned)N); g.magic_wpp = magic((unsigned)wpp);
+    g.cols = cols;
+    g.magic_N = magic((unsigned)NCU); g.magic_wpp = magic((unsigned)wpp);
 
     g.xrange = h->xrange.p; g.force_path = h->opt_force_path;
     switch (DP) {

@@ -43,6 +43,7 @@ struct GradArgs {
     const double* xrange;   // (2, E) min / max of the memory points per input dimension
     int DP, NXP, NSP;
     int force_path;         // 0 auto, 1 always the direct exp form (tests)
+    int cols;               // columns per lane in the pairwise pass (1 or 2)
     int G, CH, RC, wpp;
     unsigned magic_N, magic_wpp;
 };
@@ -104,7 +105,7 @@ __host__ __device__ inline MomLayout make_mom_layout(int N, int D, int E, int G,
 }
 
 // ------------------------------------------------------------------------------------------
-template <int DP, int NXP, int NT>
+template <int DP, int NXP, int NT, int NC>
 __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NT / kWave;
@@ -118,6 +119,7 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
     const int P = D * (D + 1) / 2;
     const int LD = 2 * D;
     const int wpp = p.wpp;
+    const int NCU = (N + NC - 1) / NC;      // column units per row chunk (NC adjacent columns per lane)
     const int NR = p.RC * p.CH;
     const MomLayout L = make_mom_layout(N, D, E, G, RS, NR, wpp, NSP);
     double* c_ils2 = smem + L.c_ils2;
@@ -364,69 +366,86 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
             const int b = __builtin_amdgcn_readfirstlane(s_pb[q0 + gq]);
             const bool diag = (a == b);
             const int flat = slot * 64 + lane;
-            const bool valid = flat < p.RC * N;
-            const int r = valid ? (p.magic_N ? (int)__umulhi((unsigned)flat, p.magic_N) : flat) : 0;
-            const int j = valid ? flat - r * N : 0;
+            const bool valid = flat < p.RC * NCU;
+            const int r = valid ? (p.magic_N ? (int)__umulhi((unsigned)flat, p.magic_N) : flat) : 0;       // flat / NCU
+            const int jc = valid ? flat - r * NCU : 0;
+            // the lane's NC adjacent columns j .. j + NC - 1 (two columns per lane halve the LDS broadcast traffic per
+            // element, which bounds the one-column loop: 72 bytes of row record per lane and row)
+            const int j = NC * jc;
+            bool vcol[NC];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) vcol[q] = valid && (j + q < N);
+            const int jl = (NC == 2 && vcol[NC - 1]) ? j + 1 : j;          // last column of the lane
             const int i0 = r * p.CH;
             int i1 = i0 + p.CH;
             if (i1 > N) i1 = N;
-            if (diag && i1 > j + 1) i1 = j + 1;
+            if (diag && i1 > jl + 1) i1 = jl + 1;
             const int len = (valid && i1 > i0) ? (i1 - i0) : 0;
             const int nrows = (wave_max_i32(len) + 3) & ~3;
-            double cs = 0.0, h[DP + NXP], hh[NH];
+            double cs[NC], h[NC][DP + NXP], hh[NC][NH], w[NC][DP], kbj[NC];
 #pragma unroll
-            for (int d = 0; d < DP + NXP; ++d) h[d] = 0.0;
+            for (int q = 0; q < NC; ++q) {
+                cs[q] = 0.0;
 #pragma unroll
-            for (int k = 0; k < NH; ++k) hh[k] = 0.0;
-            double w[DP];
+                for (int d = 0; d < DP + NXP; ++d) h[q][d] = 0.0;
 #pragma unroll
-            for (int d = 0; d < DP; ++d) w[d] = (d < D) ? a_nu[d * N + j] * c_ils2[b * E + d] : 0.0;
+                for (int k = 0; k < NH; ++k) hh[q][k] = 0.0;
+#pragma unroll
+                for (int d = 0; d < DP; ++d) w[q][d] = (d < D && vcol[q]) ? a_nu[d * N + j + q] * c_ils2[b * E + d] : 0.0;
+                kbj[q] = vcol[q] ? a_kb[gq * N + j + q] : 0.0;
+            }
             const int K = __builtin_amdgcn_readfirstlane(s_K[gq]);
-            const double kbj = a_kb[gq * N + j];
             if (nrows > 0) {
                 const double* rec = a_rows + ((size_t)gq * NR + i0) * RS;
                 const double* Tp = p.Tm + ((size_t)a * (N + kTPad) + i0) * N + j;
-                // two rows per trip; the next trip's T values are in flight during this trip's math (reading past the
-                // last trip only touches the zero padding rows of T)
-                auto accumulate = [&](double e, const double* rr) {
-                    cs += e;
+                auto accumulate = [&](int q, double e, const double* rr) {
+                    cs[q] += e;
                     int k = 0;
 #pragma unroll
                     for (int d = 0; d < DP; ++d) {
                         const double td = e * rr[2 + DP + d];
-                        h[d] += td;
+                        h[q][d] += td;
 #pragma unroll
-                        for (int d2 = d; d2 < DP; ++d2) { hh[k] = fma(td, rr[2 + DP + d2], hh[k]); ++k; }
+                        for (int d2 = d; d2 < DP; ++d2) { hh[q][k] = fma(td, rr[2 + DP + d2], hh[q][k]); ++k; }
                     }
 #pragma unroll
-                    for (int x = 0; x < NXP; ++x) h[DP + x] = fma(e, rr[2 + 2 * DP + x], h[DP + x]);
+                    for (int x = 0; x < NXP; ++x) h[q][DP + x] = fma(e, rr[2 + 2 * DP + x], h[q][DP + x]);
                 };
+                // two rows per trip; the next trip's T values are in flight during this trip's math (reading past the
+                // last trip only touches the zero padding rows of T)
                 auto run = [&](auto kc) {
                     constexpr int KK = decltype(kc)::value;
-                    double tn[2];
+                    double tn[2][NC];
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) tn[q] = diag ? Tp[(size_t)q * N] : 1.0;
+                    for (int u = 0; u < 2; ++u)
+#pragma unroll
+                        for (int q = 0; q < NC; ++q) tn[u][q] = diag ? Tp[(size_t)u * N + q] : 1.0;
                     for (int it = 0; it < nrows; it += 2) {
-                        double e[2];
+                        double e[2][NC];
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            const double* rr = rec + q * RS;
-                            const double tv = tn[q];
-                            tn[q] = diag ? Tp[(size_t)(2 + q) * N] : 1.0;
-                            if constexpr (KK > 0) {
-                                double cc = rr[2] * w[0];
+                        for (int u = 0; u < 2; ++u) {
+                            const double* rr = rec + u * RS;
 #pragma unroll
-                                for (int d = 1; d < DP; ++d) cc = fma(rr[2 + d], w[d], cc);
-                                e[q] = taylor_exp<KK>(cc) * (diag ? rr[0] * tv : rr[1]);
-                            } else {
-                                double arg = rr[0] + kbj;
+                            for (int q = 0; q < NC; ++q) {
+                                const double tv = tn[u][q];
+                                tn[u][q] = diag ? Tp[(size_t)(2 + u) * N + q] : 1.0;
+                                if constexpr (KK > 0) {
+                                    double cc = rr[2] * w[q][0];
 #pragma unroll
-                                for (int d = 0; d < DP; ++d) arg = fma(rr[2 + d], w[d], arg);
-                                e[q] = fast_exp(arg, c_tab) * (diag ? tv : rr[1]);
+                                    for (int d = 1; d < DP; ++d) cc = fma(rr[2 + d], w[q][d], cc);
+                                    e[u][q] = taylor_exp<KK>(cc) * (diag ? rr[0] * tv : rr[1]);
+                                } else {
+                                    double arg = rr[0] + kbj[q];
+#pragma unroll
+                                    for (int d = 0; d < DP; ++d) arg = fma(rr[2 + d], w[q][d], arg);
+                                    e[u][q] = fast_exp(arg, c_tab) * (diag ? tv : rr[1]);
+                                }
                             }
                         }
 #pragma unroll
-                        for (int q = 0; q < 2; ++q) accumulate(e[q], rec + q * RS);
+                        for (int u = 0; u < 2; ++u)
+#pragma unroll
+                            for (int q = 0; q < NC; ++q) accumulate(q, e[u][q], rec + u * RS);
                         rec += 2 * RS;
                         Tp += (size_t)2 * N;
                     }
@@ -443,30 +462,40 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
                 else run(std::integral_constant<int, 14>{});
             }
             // column factor; for a diagonal pair only i <= j was visited with a halved diagonal of T and every
-            // moment is symmetric under i <-> j, so the factor is 2
-            const double colf = valid ? (K > 0 ? kbj : (diag ? 2.0 : p.beta[b * N + j])) : 0.0;
+            // moment is symmetric under i <-> j, so the factor is 2 (Taylor form: already in kbj)
+            double colf[NC], xb[NC][NXP];
+#pragma unroll
+            for (int q = 0; q < NC; ++q) {
+                colf[q] = vcol[q] ? (K > 0 ? kbj[q] : (diag ? 2.0 : p.beta[b * N + j + q])) : 0.0;
+#pragma unroll
+                for (int x = 0; x < NXP; ++x) xb[q][x] = (x < NX && vcol[q]) ? a_xe[x * N + j + q] * c_ils2[b * E + D + x] : 0.0;
+            }
+            auto fold = [&](auto f) {             // sum of f(column) * colf over the lane's columns, then over the wave
+                double v = 0.0;
+#pragma unroll
+                for (int q = 0; q < NC; ++q) v = fma(f(q), colf[q], v);
+                return wave_sum(v);
+            };
             double* out = s_part + (size_t)wi * NSP;
             {
-                const double v = wave_sum(valid ? cs * colf : 0.0);
+                const double v = fold([&](int q) { return cs[q]; });
                 if (lane == 0) out[0] = v;
             }
             int k = 0;
 #pragma unroll
             for (int d = 0; d < DP; ++d) {
-                const double v1 = wave_sum(valid ? (h[d] + cs * w[d]) * colf : 0.0);
+                const double v1 = fold([&](int q) { return h[q][d] + cs[q] * w[q][d]; });
                 if (lane == 0) out[1 + d] = v1;
 #pragma unroll
                 for (int d2 = d; d2 < DP; ++d2) {
-                    const double v2 = hh[k] + cs * w[d] * w[d2] + h[d] * w[d2] + w[d] * h[d2];
-                    const double s2 = wave_sum(valid ? v2 * colf : 0.0);
+                    const double s2 = fold([&](int q) { return hh[q][k] + cs[q] * w[q][d] * w[q][d2] + h[q][d] * w[q][d2] + w[q][d] * h[q][d2]; });
                     if (lane == 0) out[1 + DP + k] = s2;
                     ++k;
                 }
             }
 #pragma unroll
             for (int x = 0; x < NXP; ++x) {
-                const double xb = (x < NX) ? a_xe[x * N + j] * c_ils2[b * E + D + x] : 0.0;
-                const double v = wave_sum(valid ? (h[DP + x] + cs * xb) * colf : 0.0);
+                const double v = fold([&](int q) { return h[q][DP + x] + cs[q] * xb[q][x]; });
                 if (lane == 0) out[1 + DP + NH + x] = v;
             }
         }

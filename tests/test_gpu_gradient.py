@@ -121,6 +121,19 @@ def test_gradient_is_bitwise_reproducible_and_batch_independent(engine):
     assert torch.equal(one[0], a[3])
 
 
+def test_two_columns_per_lane_variant_agrees(engine):
+    """Option grad_cols_per_lane = 2 (A/B variant of the moment pass): same gradient to fp64 rounding of the sums."""
+    w = synth.make_workload(131, 3, 2, 5, 3, seed=8)
+    _load_model(engine, w)
+    one = engine.rollout_grad(w.actions, w.mu0, w.S0)["grad"]
+    engine.set_option("grad_cols_per_lane", 2)
+    try:
+        two = engine.rollout_grad(w.actions, w.mu0, w.S0)["grad"]
+    finally:
+        engine.set_option("grad_cols_per_lane", 0)
+    assert rel_err(two.cpu().numpy(), one.cpu().numpy()) < 1e-9
+
+
 def test_unsupported_shape_is_reported_not_approximated(engine):
     import gp_mpc_amd
     w = synth.make_workload(40, 12, 2, 2, 2, seed=2)
