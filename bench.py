@@ -6,8 +6,9 @@
 
 A "step" is one pass of the hot path over one batch of candidate action sequences: one
 gpmpc_rollout launch (H-step moment-matched propagation + stage/terminal costs + LCB objective
-for every candidate, trajectories written to HBM) + the argmin (and, for N > 1, the 16-byte
-RCCL gather and the winner broadcast).  Workload = BASELINE.json configs[1] (Pendulum scale:
+for every candidate, trajectories written to HBM) + the keep-the-best kernel (and, for N > 1, the RCCL
+gather of the per-rank records) + the winner's record copied to the host.  The host reads the winner of
+step k after enqueuing step k + 1, so launches overlap the previous step's kernels.  Workload = BASELINE.json configs[1] (Pendulum scale:
 N=200 memory points, D=3, A=1, H=25, B=256 candidates, fp64) per GPU; candidates shard across
 ranks with no data-path collective, so scaling is weak (B = 256 per GPU).  Inputs are resident
 in HBM before the timed region.  `prepare` (K build + Cholesky + inverse, once per control step)
@@ -111,21 +112,35 @@ def main():
         assert eng.last_prepare_mode == 1
         prepare_incremental_ms = float(np.median(tp[1:]) * 1e3)
 
-    bufs = {"out": None}
+    # One step = rollout launch + cost/objective kernel + keep-the-best kernel (+ RCCL gather) + the winner's record
+    # copied to the host.  The host reads the winner of step k after it has enqueued step k + 1 (two pinned buffers,
+    # one event per step), so the GPU does not idle while Python prepares the next launches; every step's winner is
+    # still delivered to the host inside the timed region.
+    bufs = {"out": None, "rec": None}
+    pinned = [None, None]
 
-    def step():
+    def launch(k):
         out = bufs["out"] = eng.rollout(actions, w.mu0, w.S0, w.include_time, w.time0, out=bufs["out"])
-        return sharding.select_best_on_device(eng, out["J"], actions, lo, B_total), out
+        pend = sharding.select_best_async(eng, out["J"], actions, lo, B_total, host_buffer=pinned[k & 1], record=bufs["rec"])
+        pinned[k & 1] = pend.host
+        bufs["rec"] = pend.record
+        return pend, out
 
-    for _ in range(args.warmup):
-        step()
+    for k in range(args.warmup):
+        pend, out = launch(k)
+        pend.result()
     use_dist = dist.is_initialized()
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        (best_J, best_i, best_act), out = step()
+    prev = None
+    for k in range(args.steps):
+        pend, out = launch(k)
+        if prev is not None:
+            best_J, best_i, best_act = prev.result()
+        prev = pend
+    best_J, best_i, best_act = prev.result()
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()

@@ -83,6 +83,48 @@ def sharded_argmin(evaluate_slice, actions_local, lo, num_candidates, device, gr
     return J, i, win
 
 
+class PendingBest:
+    """Winner selection in flight: the packed per-rank records are on their way to a pinned host buffer; `result()`
+    waits for THAT copy only (an event), so the host can enqueue the next batch's launches before it looks at this
+    batch's winner."""
+
+    def __init__(self, host, event, world, H, A, record=None):
+        self.host, self.event, self.world, self.H, self.A = host, event, world, H, A
+        self.record = record            # the device record buffer, reusable by the next call
+
+    def result(self):
+        if self.event is not None:
+            self.event.synchronize()
+        host = self.host.view(self.world, -1)
+        bJ, bi = combine_best([(float(host[r, 0]), int(host[r, 1])) for r in range(self.world)])
+        if bi < 0:
+            raise FloatingPointError("no selectable candidate (all objectives NaN)")
+        owner = [r for r in range(self.world) if int(host[r, 1]) == bi][0]
+        return bJ, bi, host[owner, 2:].view(self.H, self.A).clone()
+
+
+def select_best_async(engine, J, actions_local, lo, num_candidates, group=None, host_buffer=None, record=None):
+    """select_best_on_device without the host synchronisation: local keep-the-best kernel, (N > 1) one RCCL all_gather
+    of the packed records, an asynchronous copy into pinned host memory and an event.  `host_buffer` / `record`:
+    reusable pinned / device buffers of a previous call with the same shapes.  Returns a PendingBest."""
+    n, H, A = actions_local.shape
+    rec = engine.argmin_async(J, first_global_index=lo, actions=actions_local, out=record)
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        flat = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)
+        dist.all_gather_into_tensor(flat, rec, group=group)
+    else:
+        world, flat = 1, rec
+    if rec.device.type != "cuda":
+        return PendingBest(flat.clone(), None, world, H, A, rec)
+    if host_buffer is None or host_buffer.numel() != flat.numel():
+        host_buffer = torch.empty(flat.numel(), dtype=torch.float64, pin_memory=True)
+    host_buffer.copy_(flat, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(rec.device))
+    return PendingBest(host_buffer, ev, world, H, A, rec)
+
+
 def select_best_on_device(engine, J, actions_local, lo, num_candidates, group=None):
     """Device-resident variant of sharded_argmin for the HIP engine: local keep-the-best on the GPU
     (gpmpc_argmin_async), the record [J, global index, winning (H*A) sequence] packed on the device, ONE

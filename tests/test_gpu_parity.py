@@ -405,6 +405,25 @@ def test_device_side_winner_selection(engine):
     assert sharding.select_best_on_device(engine, torch.as_tensor(Jn, device=engine.device), acts, 7, 300)[1] == 48
 
 
+def test_asynchronous_winner_selection_matches_the_blocking_one(engine):
+    """sharding.select_best_async (pinned buffer + event, what bench.py pipelines) vs select_best_on_device."""
+    from gp_mpc_amd import sharding
+    import torch
+    w = synth.make_workload(60, 3, 1, 6, 40, seed=12)
+    f = factors_of(w)
+    engine.set_factors(w.X, f.iK, f.beta, w.lengthscales, w.outputscales)
+    _set_cost(engine, w)
+    acts = torch.as_tensor(w.actions, device=engine.device)
+    out = engine.rollout(acts, w.mu0, w.S0)
+    J0, i0, a0 = sharding.select_best_on_device(engine, out["J"], acts, 0, 40)
+    pend = sharding.select_best_async(engine, out["J"], acts, 0, 40)
+    again = sharding.select_best_async(engine, out["J"], acts, 0, 40, host_buffer=None, record=pend.record)
+    J1, i1, a1 = pend.result()
+    J2, i2, a2 = again.result()
+    assert (J0, i0) == (J1, i1) == (J2, i2) and torch.equal(a0, a1) and torch.equal(a0, a2)
+    assert i0 == int(np.argmin(out["J"].cpu().numpy()))
+
+
 def test_argmin_rule(engine):
     import torch
     cases = [([3.0, 1.0, 1.0, 2.0], 1), ([float("nan"), 1.0], 0), ([2.0, float("nan"), 1.0], 2),
