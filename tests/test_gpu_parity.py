@@ -212,6 +212,27 @@ def test_rollout_variants_agree(engine, threads, force_global):
         engine.set_option("force_global_scratch", 0)
 
 
+@pytest.mark.parametrize("cols", [1, 2])
+@pytest.mark.parametrize("force_path", [1, 2])
+@pytest.mark.parametrize("name", ["traj_c1", "traj_c2", "traj_c4_time", "traj_n1_dummy", "traj_c5class"])
+def test_one_and_two_columns_per_lane_agree_with_reference(engine, name, force_path, cols):
+    """The pairwise pass with one column per lane and with two adjacent columns per lane (default for D <= 4), in the
+    direct-exp and the element-wise Taylor form, against the reference goldens (odd N, N = 1, D = 6 included)."""
+    g = load(name)
+    w = workload_of(g)
+    f = factors_of(w)
+    engine.set_option("cols_per_lane", cols)
+    engine.set_option("force_path", force_path)
+    try:
+        engine.set_factors(w.X, f.iK, f.beta, w.lengthscales, w.outputscales)
+        _set_cost(engine, w, g)
+        out = engine.rollout(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+        _check_traj(out, g, name)
+    finally:
+        engine.set_option("cols_per_lane", 0)
+        engine.set_option("force_path", 0)
+
+
 @pytest.mark.parametrize("force_path", [0, 1, 2, 3])
 @pytest.mark.parametrize("name", ["traj_c1", "traj_c2", "traj_c4", "traj_c4_time", "traj_c5class", "traj_bigvar", "traj_n1_dummy"])
 def test_exp_taylor_and_separable_paths_agree_with_reference(engine, name, force_path):
