@@ -85,7 +85,7 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     L.aug = o;  o += (D + G) * 2 * D * D;       // D mean problems + G pair problems, [A | RHS]
     L.part = o; o += rnd2(G * wpp);
     L.mom = o;  o += G * 2 * rnd2(CM);
-    L.ints = o; o += rnd2((2 * P + G + 4 + 1) / 2);   // pa[P], pb[P], K[G], counter (ints)
+    L.ints = o; o += rnd2((2 * P + 2 * G + 6 + 1) / 2);   // pa[P], pb[P], K[G], counter, noff, off[G] (ints)
     L.c_ils2 = o;   o += rnd2(D * E);
     L.c_logvar = o; o += rnd2(D);
     L.c_var = o;    o += rnd2(D);
@@ -585,6 +585,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     int* s_pb = s_pa + P;
     int* s_K = s_pb + P;                    // per pair of the group: Taylor degree, 0 = direct exp
     int* s_counter = s_K + G;
+    int* s_noff = s_counter + 1;            // off-diagonal pairs of the current group: count and their slots
+    int* s_off = s_noff + 1;
 
     double* ppbase = smem;                  // per-point arrays live in LDS (large N: rollout_stream_kernel.h)
     double* a_nu = ppbase + L.nu;           // [d][p]
@@ -776,12 +778,22 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
 #if defined(GPMPC_PROF_ON)
             if (threadIdx.x == 0 && blockIdx.x == 0) { long long now_ = __builtin_readcyclecounter(); prof_acc[7] += now_ - prof_last; }
 #endif
-            if (tid == NT - 1) *s_counter = 0;
+            if (tid == NT - 1) {
+                *s_counter = 0;
+                int no = 0;
+                for (int gq = 0; gq < Gc; ++gq)
+                    if (s_pa[q0 + gq] != s_pb[q0 + gq]) s_off[no++] = gq;
+                *s_noff = no;
+            }
             __syncthreads();
             GPMPC_TRACE(2);
 
             // ---- P2: per-point quantities ------------------------------------------------------
-            for (int it = tid; it < (nmean + Gc) * N; it += NT) {
+            // Three kinds of items of about one exp each, so that the passes over the 1024 threads stay balanced:
+            // mean part (output a), row side of a pair (u, g = Z^T u, ka'), column side of an off-diagonal pair (w, kb');
+            // for a diagonal pair the column factor is the row factor.
+            const int n_off = *s_noff;
+            for (int it = tid; it < (nmean + Gc + n_off) * N; it += NT) {
                 const int prob = it / N, pt = it - prob * N;
                 double nu[DP];
 #pragma unroll
@@ -804,66 +816,64 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                         const double v = Xs[e * N + pt] - s_m[e];
                         q = fma(v * v, c_ils2[a * E + e], q);
                     }
-                    a_lb[a * N + pt] = exp(-0.5 * q) * p.beta[a * N + pt];                 // lb (:148)
+                    a_lb[a * N + pt] = fast_exp(-0.5 * q, c_exptab) * p.beta[a * N + pt];   // lb (:148)
                     if (a == 0) {
 #pragma unroll
                         for (int d = 0; d < DP; ++d)
                             if (d < D) a_nu[d * N + pt] = nu[d];
                     }
                 } else {
-                    const int gq = prob - nmean;
+                    const bool rowside = prob < nmean + Gc;
+                    const int gq = rowside ? prob - nmean : s_off[prob - nmean - Gc];
                     const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
+                    const int c = rowside ? a : b;                         // the output whose lengthscales scale nu
                     const int K = s_K[gq] & 63;
                     const double* Z = s_aug + (D + gq) * (D * LD) + D;
-                    double u[DP], w[DP], g[DP];
-                    double ksa = 0.0, ksb = 0.0;                                          // sum_e nu_e^2 / l_e^2
+                    double u[DP], g[DP];
+                    double ks = 0.0;                                       // sum_e nu_e^2 / l_e^2
 #pragma unroll
                     for (int d = 0; d < DP; ++d) {
-                        const double ia = (d < D) ? c_ils2[a * E + d] : 0.0;
-                        const double ib = (d < D) ? c_ils2[b * E + d] : 0.0;
-                        u[d] = nu[d] * ia;
-                        w[d] = nu[d] * ib;
-                        ksa = fma(nu[d], u[d], ksa);
-                        ksb = fma(nu[d], w[d], ksb);
+                        u[d] = nu[d] * ((d < D) ? c_ils2[c * E + d] : 0.0);
+                        ks = fma(nu[d], u[d], ks);
                         g[d] = 0.0;
                     }
                     for (int e = D; e < E; ++e) {
                         const double v = Xs[e * N + pt] - s_m[e];
-                        ksa = fma(v * v, c_ils2[a * E + e], ksa);
-                        ksb = fma(v * v, c_ils2[b * E + e], ksb);
+                        ks = fma(v * v, c_ils2[c * E + e], ks);
                     }
-                    double qa = 0.0, qb = 0.0;
+                    double qq = 0.0;
 #pragma unroll
                     for (int i = 0; i < DP; ++i) {
                         if (i < D) {
-                            double zu = 0.0, zw = 0.0;
+                            double zu = 0.0;
 #pragma unroll
                             for (int j = 0; j < DP; ++j)
                                 if (j < D) {
                                     const double z = Z[i * LD + j];
                                     zu = fma(z, u[j], zu);
-                                    zw = fma(z, w[j], zw);
                                     g[j] = fma(z, u[i], g[j]);      // g = Z^T u: cross term u^T Z w = g . w
                                 }
-                            qa = fma(u[i], zu, qa);
-                            qb = fma(w[i], zw, qb);
+                            qq = fma(u[i], zu, qq);
                         }
                     }
-                    const double ka = c_logvar[a] - 0.5 * ksa + 0.5 * qa;                 // k_a (:168) + u^T Q u
-                    const double kb = c_logvar[b] - 0.5 * ksb + 0.5 * qb;
-                    const double ba = p.beta[a * N + pt];
-                    double* rec = a_rows + ((size_t)gq * NR + pt) * RS;
+                    const double kk = c_logvar[c] - 0.5 * ks + 0.5 * qq;                  // k (:168) + u^T Q u
+                    const double bc = p.beta[c * N + pt];
+                    if (rowside) {
+                        double* rec = a_rows + ((size_t)gq * NR + pt) * RS;
 #pragma unroll
-                    for (int d = 0; d < DP; ++d) rec[2 + d] = g[d];
-                    if (K > 0) {
-                        const double ea = exp(ka);
-                        rec[0] = ea;
-                        rec[1] = ea * ba;
-                        a_kb[gq * N + pt] = (a == b) ? ea : exp(kb) * p.beta[b * N + pt];
+                        for (int d = 0; d < DP; ++d) rec[2 + d] = g[d];
+                        if (K > 0) {
+                            const double ea = fast_exp(kk, c_exptab);
+                            rec[0] = ea;
+                            rec[1] = ea * bc;
+                            if (a == b) a_kb[gq * N + pt] = ea;
+                        } else {
+                            rec[0] = kk;
+                            rec[1] = bc;
+                            if (a == b) a_kb[gq * N + pt] = kk;
+                        }
                     } else {
-                        rec[0] = ka;
-                        rec[1] = ba;
-                        a_kb[gq * N + pt] = kb;
+                        a_kb[gq * N + pt] = (K > 0) ? fast_exp(kk, c_exptab) * bc : kk;
                     }
                 }
             }
