@@ -121,6 +121,35 @@ def test_gradient_is_bitwise_reproducible_and_batch_independent(engine):
     assert torch.equal(one[0], a[3])
 
 
+@pytest.mark.parametrize("N,D,A", [(90, 3, 1), (70, 4, 2), (45, 6, 2)])
+def test_direct_exp_form_of_the_moment_pass_agrees(engine, N, D, A):
+    """force_path = 1: exp(ka' + kb' + g.w) evaluated directly instead of the Taylor form (what a large input variance
+    selects automatically); same gradient."""
+    w = synth.make_workload(N, D, A, 4, 2, seed=21)
+    f = _load_model(engine, w)
+    taylor = engine.rollout_grad(w.actions, w.mu0, w.S0)["grad"].cpu().numpy()
+    engine.set_option("force_path", 1)
+    try:
+        direct = engine.rollout_grad(w.actions, w.mu0, w.S0)["grad"].cpu().numpy()
+    finally:
+        engine.set_option("force_path", 0)
+    assert rel_err(direct, taylor) < 1e-7          # two fp64 evaluation orders of sums with cancellation
+    J, gr, *_ = adjoint.lcb_and_gradient(f, w.actions[1], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa)
+    assert rel_err(direct[1], gr) < 1e-7
+
+
+def test_large_input_variance_gradient(engine):
+    """A wide initial state distribution: the bound on |g.w| exceeds the Taylor range and the kernels take the direct
+    form on their own (the forward golden traj_bigvar covers the value; here the gradient vs the numpy adjoint)."""
+    g = load("traj_bigvar")
+    w = workload_of(g)
+    f = _load_model(engine, w, g)
+    out = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+    assert rel_err(out["J"].cpu().numpy(), g["J"]) < 1e-7
+    J, gr, *_ = adjoint.lcb_and_gradient(f, w.actions[0], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
+    assert rel_err(out["grad"][0].cpu().numpy(), gr) < 1e-7
+
+
 def test_two_columns_per_lane_variant_agrees(engine):
     """Option grad_cols_per_lane = 2 (A/B variant of the moment pass): same gradient to fp64 rounding of the sums."""
     w = synth.make_workload(131, 3, 2, 5, 3, seed=8)
