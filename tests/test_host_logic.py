@@ -165,3 +165,67 @@ def test_training_improves_marginal_likelihood_cpu():
     (out,) = q.get()
     assert out["covar_module.base_kernel.lengthscale"].shape == (1, 2) and out["likelihood.noise"].shape == (1,)
     assert 4e-3 <= out["covar_module.base_kernel.lengthscale"].min() and out["likelihood.noise"][0] <= 0.09 + 1e-12
+
+
+def test_lockstep_restarts_drive_scipy_exactly_like_the_sequential_loop():
+    """candidate_optimizer="lbfgs" host logic on a stand-in objective (no GPU): every restart's scipy L-BFGS-B solve gets,
+    from the batched evaluation rounds, exactly the values a sequential loop would hand it, so end points and winner are
+    identical; a restart that finishes early drops out of the rounds; an evaluation error reaches the caller."""
+    from scipy.optimize import minimize
+    import gp_mpc_amd  # noqa: F401
+    from gp_mpc_amd.config_classes import (Config, ControllerConfig, ActionsConfig, RewardConfig, ObservationConfig,
+                                           MemoryConfig, ModelConfig, TrainingConfig)
+    from gp_mpc_amd import GpMpcController
+    D, A, H, restarts = 3, 1, 6, 5                  # ModelConfig defaults are sized for 3 states + 1 action
+    cfg = Config(observation_config=ObservationConfig(obs_var_norm=[1e-6] * D),
+                 reward_config=RewardConfig(target_state_norm=[0.5] * D, weight_state=[1.0] * D, weight_state_terminal=[1.0] * D,
+                                            target_action_norm=[0.5] * A, weight_action=[0.1] * A),
+                 actions_config=ActionsConfig(limit_action_change=False, max_change_action_norm=[0.3] * A),
+                 model_config=ModelConfig(), memory_config=MemoryConfig(points_batch_memory=16),
+                 training_config=TrainingConfig(training_frequency=10 ** 9),
+                 controller_config=ControllerConfig(len_horizon=H, restarts_optim=restarts, candidate_optimizer="lbfgs",
+                                                    init_from_previous_actions=False))
+
+    class Stub(GpMpcController):                      # the objective lives on the host; nothing touches the engine
+        rounds = []
+
+        def objective_and_gradient_batch(self, X, obs_mu, obs_var):
+            X = np.asarray(X)
+            self.rounds.append(X.shape[0])
+            c = np.linspace(0.2, 0.9, X.shape[1])
+            J = ((X - c) ** 2).sum(1) + 0.1 * np.sin(5 * X).sum(1)
+            return J, 2 * (X - c) + 0.5 * np.cos(5 * X)
+
+        def evaluate_candidates(self, actions_mpc_batch, obs_mu, obs_var, trajectories=False):
+            return None
+
+        def _cache_trajectory(self, out, idx):
+            pass
+
+        def _prepare(self):
+            pass
+
+    c = Stub(np.zeros(D), np.ones(D), np.zeros(A), np.ones(A), cfg, engine=object())
+    np.random.seed(3)
+    best = c._get_optimal_actions(None, None)
+    np.random.seed(3)
+    x0s = [np.random.uniform(0, 1, H * A) for _ in range(restarts)]
+
+    def f(x):
+        J, G = Stub.objective_and_gradient_batch(c, x[None], None, None)
+        return float(J[0]), G[0]
+    seq = [minimize(fun=f, x0=x0, jac=True, method="L-BFGS-B", bounds=c.actions_mapper.bounds,
+                    options=cfg.controller.actions_optimizer_params) for x0 in x0s]
+    assert np.array_equal(c.candidates_final_J, np.array([r.fun for r in seq]))
+    win = int(np.argmin([r.fun for r in seq]))
+    assert c.best_candidate_index == win and np.array_equal(c.actions_mpc_previous_iter, seq[win].x)
+    assert best.shape == (H, A)
+    assert c.lbfgs_evaluations == max(r.nfev for r in seq)               # rounds = the longest restart
+    assert Stub.rounds[0] == restarts and min(Stub.rounds[:c.lbfgs_evaluations]) < restarts   # early finishers drop out
+
+    class Broken(Stub):
+        def objective_and_gradient_batch(self, X, obs_mu, obs_var):
+            raise ValueError("device lost")
+    b = Broken(np.zeros(D), np.ones(D), np.zeros(A), np.ones(A), cfg, engine=object())
+    with pytest.raises(RuntimeError, match="batched evaluation failed"):
+        b._get_optimal_actions(None, None)
