@@ -229,3 +229,26 @@ def test_lockstep_restarts_drive_scipy_exactly_like_the_sequential_loop():
     b = Broken(np.zeros(D), np.ones(D), np.zeros(A), np.ones(A), cfg, engine=object())
     with pytest.raises(RuntimeError, match="batched evaluation failed"):
         b._get_optimal_actions(None, None)
+
+
+def test_pending_best_combines_rank_records_like_the_reference_loop():
+    """sharding.PendingBest.result on fabricated per-rank records [J, global index, winning actions]: lowest J wins, ties go
+    to the lowest global index, a rank with nothing selectable (-1) is skipped, NaN in global slot 0 is adopted
+    (gp_mpc_controller.py:146-148 applied across ranks)."""
+    import gp_mpc_amd  # noqa: F401
+    from gp_mpc_amd.sharding import PendingBest
+    H, A = 2, 1
+
+    def rec(J, idx, a):
+        return [J, float(idx), a, a + 0.5]
+    host = torch.tensor([rec(0.7, 3, 1.0), rec(0.4, 9, 2.0), rec(0.4, 6, 3.0)], dtype=torch.float64).reshape(-1)
+    J, i, act = PendingBest(host, None, 3, H, A).result()
+    assert (J, i) == (0.4, 6) and act.reshape(-1).tolist() == [3.0, 3.5]
+    host = torch.tensor([rec(float("inf"), -1, 0.0), rec(0.9, 5, 2.0)], dtype=torch.float64).reshape(-1)
+    assert PendingBest(host, None, 2, H, A).result()[:2] == (0.9, 5)
+    host = torch.tensor([rec(float("nan"), 0, 7.0), rec(0.1, 5, 2.0)], dtype=torch.float64).reshape(-1)
+    J, i, act = PendingBest(host, None, 2, H, A).result()
+    assert J != J and i == 0 and act.reshape(-1).tolist() == [7.0, 7.5]
+    host = torch.tensor([rec(float("inf"), -1, 0.0)], dtype=torch.float64).reshape(-1)
+    with pytest.raises(FloatingPointError):
+        PendingBest(host, None, 1, H, A).result()
