@@ -51,6 +51,7 @@ struct RolloutArgs {
     int force_path;          // 0 auto, 1 always direct exp, 2 Taylor but never separable (tests)
     int force_sep;           // 1: separable whenever the degree allows, ignoring the cost model (tests)
     int x_in_lds;            // 1: X^T is copied to LDS once per launch (the per-point pass reads it every step)
+    int exact_dim;           // 2: never use the compile-time-D instantiation (A/B); otherwise whenever D == DP
     int cols2;               // 1: two adjacent columns per lane in the pairwise pass (halves the LDS broadcast traffic)
     // tiling
     int G;        // output pairs per group
@@ -120,6 +121,7 @@ struct Handle {
     int opt_force_path = 0;
     int opt_force_sep = 0;
     int opt_grad_cols = 0;           // 2: two columns per lane in the gradient's moment pass (A/B)
+    int opt_exact_dim = 0;           // 2: forbid the compile-time-D kernel instantiation (A/B)
     int opt_cols_per_lane = 0;       // 0 auto, 1 / 2: columns per lane in the pairwise pass of the rollout kernel
     int opt_incremental = 1;         // reuse / border-update the cached factors when the memory only grew
     int opt_refresh_every = 32;      // full refactorisation after this many border updates (bounds drift)

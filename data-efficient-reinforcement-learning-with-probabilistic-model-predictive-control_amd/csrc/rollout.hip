@@ -209,6 +209,7 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     a.CM = CM;
     a.force_path = h->opt_force_path;
     a.force_sep = h->opt_force_sep;
+    a.exact_dim = h->opt_exact_dim;
 
     // choose pairs-per-group G and row chunking for the LDS-resident variant
     bool gs = h->opt_force_global != 0;

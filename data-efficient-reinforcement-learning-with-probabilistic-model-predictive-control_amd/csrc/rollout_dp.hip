@@ -20,7 +20,11 @@ static int launch_variant(Handle* h, RolloutArgs& a, bool global_scratch, size_t
         GPMPC_HIP_CHECK(h, hipGetLastError());
         return GPMPC_OK;
     }
-    const bool exact = (a.D == DP);
+    // The compile-time-D instantiation folds the index arithmetic.  For D >= 4 it spills (8 / 22 / 247 / 1000 VGPRs at
+    // D = 4 / 6 / 8 / 16 against none with the runtime D) but only in the small algebra outside the pairwise loop, and it
+    // still measured faster or equal at every D (tools/gpu_exact_ab.py: 19.1 vs 19.8 ms at config 4, 5.1 vs 6.0 ms at
+    // D = 6, 14.2 vs 15.6 ms at D = 8, equal at D = 16), so it is used whenever D == DP; option "exact_dim" = 2 forbids it.
+    const bool exact = (a.D == DP) && a.exact_dim != 2;
     auto kern = a.cols2 ? (exact ? rollout_kernel<DP, NT, DP, true> : rollout_kernel<DP, NT, 0, true>)
                         : (exact ? rollout_kernel<DP, NT, DP, false> : rollout_kernel<DP, NT, 0, false>);
     {
