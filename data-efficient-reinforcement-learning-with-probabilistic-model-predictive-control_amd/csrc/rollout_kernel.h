@@ -53,7 +53,7 @@ constexpr int kMaxMono = 256;      // most monomials of the separable (off-diago
 // ------------------------------------------------------------------------------------------
 // LDS / scratch layout (offsets in doubles), shared by host (sizing) and device (carving).
 struct Layout {
-    int mu, Sig, m, M, cc, s1, Vs, Sp, TS, v1, v2, ev, misc, rdet, aug, part, mom, ints;
+    int mu, Sig, m, M, cc, s1, Vs, Sp, misc, rdet, aug, part, mom, ints;
     int c_ils2, c_logvar, c_var, c_xr, c_act, c_exptab, c_monow, c_monoe, c_X;    // read-only tables copied to LDS once
     int lds_total;     // doubles of LDS
     // per-point arrays (LDS)
@@ -76,10 +76,6 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     L.s1 = o;   o += rnd2(D * (D + 1));
     L.Vs = o;   o += rnd2(D * D);
     L.Sp = o;   o += rnd2(P);
-    L.TS = o;   o += rnd2(D * D);
-    L.v1 = o;   o += rnd2(D);
-    L.v2 = o;   o += rnd2(D);
-    L.ev = o;   o += rnd2(D + A);
     L.misc = o; o += 8;
     L.rdet = o; o += rnd2(G);
     L.aug = o;  o += (D + G) * 2 * D * D;       // D mean problems + G pair problems, [A | RHS]
@@ -554,8 +550,6 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     constexpr int NW = NT / kWave;
     constexpr int RS = DP + 2;              // row record: [0] ea_i | ka'_i, [1] ra_i | beta_ai, [2..] g_i
     const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
     const int c = blockIdx.x;
     const int D = (DX > 0) ? DX : p.D;
     const int N = p.N, A = p.A, E = p.E, H = p.H, G = p.G, CM = p.CM;
@@ -576,7 +570,6 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     double* s_s1 = smem + L.s1;             // [a][0] = sum lb, [a][1+d] = sum lb * nu_d
     double* s_Vs = smem + L.Vs;             // [k][a]
     double* s_Sp = smem + L.Sp;
-    double* s_TS = smem + L.TS;
     double* s_rdet = smem + L.rdet;
     double* s_aug = smem + L.aug;           // problems [0, D): mean part, [D, D+G): pairs of the group
     double* s_part = smem + L.part;
@@ -1013,7 +1006,6 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
 
             // ---- P4: per-pair totals (one wave per pair, fixed order), M and V -------------------
             for (int gq = wave; gq < Gc; gq += NW) {
-                const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
                 const int Kraw = s_K[gq];
                 double v = 0.0;
                 if (Kraw & 64) {

@@ -60,7 +60,6 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
     const int tid0 = threadIdx.x;
     const int c = blockIdx.x;
     const int D = p.D, N = p.N, A = p.A, E = p.E, H = p.H, CH = p.CH;
-    const int P = D * (D + 1) / 2;
     const int DA = D + A;
     const int LD = 2 * D;
     const int SD2 = rnd2(D * D);
