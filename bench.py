@@ -126,6 +126,12 @@ def main():
         bufs["rec"] = pend.record
         return pend, out
 
+    # Untimed pre-conditioning: the GPU needs a few tens of milliseconds of sustained load to reach its steady clocks
+    # (the first launches after the tiny prepare kernels run ~10 % slow); a running controller is in that state.
+    tc = time.perf_counter()
+    while time.perf_counter() - tc < 0.25:
+        pend, out = launch(0)
+        pend.result()
     for k in range(args.warmup):
         pend, out = launch(k)
         pend.result()
