@@ -552,6 +552,107 @@ __device__ inline double wave_sum8(const double (&v)[8], int lane) {
     return r;
 }
 
+// ------------------------------------------------------------------------------------------
+// Separable moments for three state dimensions with the monomial structure known at compile time.
+// Seven bands (x0 exponent i, and for i <= 1 two ranges of the x1 exponent j) of at most 16 monomials for KS <= 6:
+//   B0: i = 0, j <= 1 | B1: i = 0, j >= 2 | B2: i = 1, j <= 1 | B3: i = 1, j >= 2 | B4: i = 2 | B5: i = 3 | B6: i >= 4.
+// Inside a band the local order is i, j, k ascending; the canonical (graded, i then j descending) index the host tables
+// use is  cum(deg - 1) + T(deg - i) + (deg - i - j),  deg = i + j + k,  cum(n) = (n+1)(n+2)(n+3)/6,  T(n) = n(n+1)/2.
+constexpr int kSep3Bands = 7;
+constexpr int sep3_i0(int B) { return B < 2 ? 0 : (B < 4 ? 1 : B - 2); }
+constexpr int sep3_i1(int B, int KS) { return B < 6 ? sep3_i0(B) : KS; }
+constexpr int sep3_j0(int B) { return (B == 1 || B == 3) ? 2 : 0; }
+constexpr int sep3_j1(int B, int KS) { return (B == 0 || B == 2) ? 1 : KS; }
+constexpr int sep3_count(int B, int KS) {
+    int n = 0;
+    for (int i = sep3_i0(B); i <= sep3_i1(B, KS) && i <= KS; ++i)
+        for (int j = sep3_j0(B); j <= sep3_j1(B, KS) && j <= KS - i; ++j) n += KS - i - j + 1;
+    return n;
+}
+template <int KS, int B>
+struct Sep3Canon {
+    int v[sep3_count(B, KS) > 0 ? sep3_count(B, KS) : 1];
+    constexpr Sep3Canon() : v{} {
+        int n = 0;
+        for (int i = sep3_i0(B); i <= sep3_i1(B, KS) && i <= KS; ++i)
+            for (int j = sep3_j0(B); j <= sep3_j1(B, KS) && j <= KS - i; ++j)
+                for (int kk = 0; kk <= KS - i - j; ++kk) {
+                    const int deg = i + j + kk;
+                    const int cum = deg * (deg + 1) * (deg + 2) / 6;                 // monomials of degree < deg
+                    v[n++] = cum + (deg - i) * (deg - i + 1) / 2 + (deg - i - j);
+                }
+    }
+};
+
+// One (side, band) item: lanes own points; every monomial of the band costs one FMA per point (x1^j, x2^k tabulated per
+// point, wt x0^i x1^j formed once per (i, j)); the lane partials are reduced 8 at a time and scattered to the
+// canonical positions of this (pair, side) in `mom`.
+// (side 0: rows, x = g_i from the row records, weight rec[1]; side 1: columns, x = nu_j / l_b^2, weight kb)
+template <int KS, int B>
+__device__ inline void sep3_band(int lane, int N, int side, const double* rec0, int RS, const double* kb, const double* nu,
+                                 const double* il, double* mom) {
+    constexpr int NBm = sep3_count(B, KS);
+    if constexpr (NBm > 0) {
+        constexpr int NP = (NBm + 7) & ~7;
+        constexpr int I0 = sep3_i0(B), I1 = sep3_i1(B, KS) < KS ? sep3_i1(B, KS) : KS;
+        constexpr int J0 = sep3_j0(B), J1 = sep3_j1(B, KS);
+        double acc[NP];
+#pragma unroll
+        for (int m = 0; m < NP; ++m) acc[m] = 0.0;
+        for (int pt = lane; pt < N; pt += 64) {
+            double x0, x1, x2, wt;
+            if (side == 0) {
+                const double* rec = rec0 + (size_t)pt * RS;
+                wt = rec[1]; x0 = rec[2]; x1 = rec[3]; x2 = rec[4];
+            } else {
+                wt = kb[pt];
+                x0 = nu[pt] * il[0]; x1 = nu[N + pt] * il[1]; x2 = nu[2 * N + pt] * il[2];
+            }
+            double py[KS + 1], pz[KS + 1];
+            py[0] = 1.0; pz[0] = 1.0;
+#pragma unroll
+            for (int e = 1; e <= KS; ++e) { py[e] = py[e - 1] * x1; pz[e] = pz[e - 1] * x2; }
+            double wx = wt;
+#pragma unroll
+            for (int e = 0; e < I0; ++e) wx *= x0;
+            int n = 0;
+#pragma unroll
+            for (int i = I0; i <= I1; ++i) {
+#pragma unroll
+                for (int j = J0; j <= (J1 < KS - i ? J1 : KS - i); ++j) {
+                    const double aij = wx * py[j];
+#pragma unroll
+                    for (int kk = 0; kk <= KS - i - j; ++kk) { acc[n] = fma(aij, pz[kk], acc[n]); ++n; }
+                }
+                wx *= x0;
+            }
+        }
+        static constexpr Sep3Canon<KS, B> canon{};
+        const int mm = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
+#pragma unroll
+        for (int g8 = 0; g8 < NP; g8 += 8) {
+            const double(&grp)[8] = *reinterpret_cast<const double(*)[8]>(&acc[g8]);
+            const double tot = wave_sum8(grp, lane);
+            if (lane < 8 && g8 + mm < NBm) mom[canon.v[g8 + mm]] = tot;
+        }
+    }
+}
+
+// Not inlined: the band code wants ~90 VGPRs of its own, next to the ~60 the work-queue loop keeps live.
+template <int KS>
+__device__ __attribute__((noinline)) void sep3_item(int band, int lane, int N, int side, const double* rec0, int RS,
+                                                     const double* kb, const double* nu, const double* il, double* mom) {
+    switch (band) {
+        case 0: sep3_band<KS, 0>(lane, N, side, rec0, RS, kb, nu, il, mom); break;
+        case 1: sep3_band<KS, 1>(lane, N, side, rec0, RS, kb, nu, il, mom); break;
+        case 2: sep3_band<KS, 2>(lane, N, side, rec0, RS, kb, nu, il, mom); break;
+        case 3: sep3_band<KS, 3>(lane, N, side, rec0, RS, kb, nu, il, mom); break;
+        case 4: sep3_band<KS, 4>(lane, N, side, rec0, RS, kb, nu, il, mom); break;
+        case 5: sep3_band<KS, 5>(lane, N, side, rec0, RS, kb, nu, il, mom); break;
+        default: sep3_band<KS, 6>(lane, N, side, rec0, RS, kb, nu, il, mom); break;
+    }
+}
+
 __device__ inline int wave_max_i32(int v) {
     auto step = [&](auto ctrl, auto rmask) {
         const int o = __builtin_amdgcn_update_dpp(0, v, decltype(ctrl)::value, decltype(rmask)::value, 0xf, true);
@@ -785,11 +886,14 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     for (int k = 1; k < kMaxTaylor; ++k) K += (cmax > kTaylorMaxArg[k]) ? 1 : 0;
                 }
                 // separable (moment) evaluation of an off-diagonal pair when it is the cheaper one
-                if (a != b && K > 0 && K <= p.sep_kmax && p.force_path == 0) {
-                    // wavefront instructions: per block of 8 monomials and side ~(6 + 8 (avg degree + 1)) per 64 points + the
-                    // 8-value reduction, against ~(D + K + 3) per element of the pairwise loop
+                if (a != b && K > 0 && K <= p.sep_kmax && (DX != 3 || K <= 6) && p.force_path == 0) {
+                    // wavefront instructions against ~(D + K + 3) per element of the pairwise loop.  D = 3 (compile-time
+                    // monomial structure): ~2 per monomial and 64 points + the 8-value reductions; otherwise per block of 8
+                    // monomials and side ~(6 + 8 (avg degree + 1)) per 64 points + one 8-value reduction
+                    const long long C_ = p.mono_cum[K < 3 ? 3 : K];
                     const long long NBk = (p.mono_cum[K] + 7) / 8;
-                    const long long cost_sep = 2 * NBk * (((N + 63) / 64) * (6 + 8 * K) + 80);
+                    const long long cost_sep = (DX == 3) ? 2 * (((N + 63) / 64) * (2 * C_ + 40) + (C_ / 8 + 4) * 70)
+                                                         : 2 * NBk * (((N + 63) / 64) * (6 + 8 * K) + 80);
                     const long long cost_el = (long long)N * N * (D + K + 3) / 64;
                     if (p.force_sep || cost_sep < cost_el) K |= 64;
                 }
@@ -934,6 +1038,21 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     // separable evaluation: moments  G_alpha = sum_i ra_i g_i^alpha,  W_alpha = sum_j rb_j w_j^alpha.
                     // Item = (side, block of 8 consecutive monomials): lanes own points, the point's x and weight are loaded
                     // once for the 8 monomials, whose exponents are wave-uniform (scalar loop counts).
+                    if constexpr (DX == 3) {
+                        // three state dimensions: compile-time monomial structure, items = (side, band of the x0 exponent)
+                        for (int itm = slot; itm < 2 * kSep3Bands; itm += wpp) {
+                            const int side = itm >= kSep3Bands, band = itm - side * kSep3Bands;
+                            const double* rec0 = a_rows + (size_t)gq * NR * RS;
+                            const double* kbp = a_kb + gq * N;
+                            const double* il = c_ils2 + b * E;
+                            double* mom = s_mom + (gq * 2 + side) * rnd2(CM);
+                            if (K <= 3) sep3_item<3>(band, lane, N, side, rec0, RS, kbp, a_nu, il, mom);
+                            else if (K == 4) sep3_item<4>(band, lane, N, side, rec0, RS, kbp, a_nu, il, mom);
+                            else if (K == 5) sep3_item<5>(band, lane, N, side, rec0, RS, kbp, a_nu, il, mom);
+                            else sep3_item<6>(band, lane, N, side, rec0, RS, kbp, a_nu, il, mom);      // K <= 6 on this path (P1)
+                        }
+                        continue;
+                    }
                     const int C = p.mono_cum[K];
                     const int NBk = (C + 7) >> 3;
                     for (int blk = slot; blk < 2 * NBk; blk += wpp) {
