@@ -554,19 +554,35 @@ __device__ inline double wave_sum8(const double (&v)[8], int lane) {
 
 // ------------------------------------------------------------------------------------------
 // Separable moments for three state dimensions with the monomial structure known at compile time.
-// Seven bands (x0 exponent i, and for i <= 1 two ranges of the x1 exponent j) of at most 16 monomials for KS <= 6:
-//   B0: i = 0, j <= 1 | B1: i = 0, j >= 2 | B2: i = 1, j <= 1 | B3: i = 1, j >= 2 | B4: i = 2 | B5: i = 3 | B6: i >= 4.
+// Bands of at most 16 monomials (ranges of the x0 exponent i and, where needed, of the x1 exponent j); fewer, larger
+// bands for the low degrees so that their items are not all set-up and reduction:
+//   KS <= 3: {i = 0}, {i >= 1}                      KS = 4: {i = 0}, {i = 1}, {i >= 2}
+//   KS = 5: {i = 0, j <= 1}, {i = 0, j >= 2}, {i = 1}, {i = 2}, {i >= 3}
+//   KS = 6: {i = 0, j <= 1}, {i = 0, j >= 2}, {i = 1, j <= 1}, {i = 1, j >= 2}, {i = 2}, {i = 3}, {i >= 4}
 // Inside a band the local order is i, j, k ascending; the canonical (graded, i then j descending) index the host tables
 // use is  cum(deg - 1) + T(deg - i) + (deg - i - j),  deg = i + j + k,  cum(n) = (n+1)(n+2)(n+3)/6,  T(n) = n(n+1)/2.
-constexpr int kSep3Bands = 7;
-constexpr int sep3_i0(int B) { return B < 2 ? 0 : (B < 4 ? 1 : B - 2); }
-constexpr int sep3_i1(int B, int KS) { return B < 6 ? sep3_i0(B) : KS; }
-constexpr int sep3_j0(int B) { return (B == 1 || B == 3) ? 2 : 0; }
-constexpr int sep3_j1(int B, int KS) { return (B == 0 || B == 2) ? 1 : KS; }
+constexpr int sep3_bands(int KS) { return KS <= 3 ? 2 : (KS == 4 ? 3 : (KS == 5 ? 5 : 7)); }
+constexpr int sep3_i0(int B, int KS) {
+    if (KS <= 4) return B;
+    if (KS == 5) return B < 2 ? 0 : B - 1;
+    return B < 2 ? 0 : (B < 4 ? 1 : B - 2);
+}
+constexpr int sep3_i1(int B, int KS) { return B == sep3_bands(KS) - 1 ? KS : sep3_i0(B, KS); }
+constexpr int sep3_j0(int B, int KS) {
+    if (KS == 5) return B == 1 ? 2 : 0;
+    if (KS >= 6) return (B == 1 || B == 3) ? 2 : 0;
+    return 0;
+}
+constexpr int sep3_j1(int B, int KS) {
+    if (KS == 5) return B == 0 ? 1 : KS;
+    if (KS >= 6) return (B == 0 || B == 2) ? 1 : KS;
+    return KS;
+}
 constexpr int sep3_count(int B, int KS) {
     int n = 0;
-    for (int i = sep3_i0(B); i <= sep3_i1(B, KS) && i <= KS; ++i)
-        for (int j = sep3_j0(B); j <= sep3_j1(B, KS) && j <= KS - i; ++j) n += KS - i - j + 1;
+    if (B >= sep3_bands(KS)) return 0;
+    for (int i = sep3_i0(B, KS); i <= sep3_i1(B, KS) && i <= KS; ++i)
+        for (int j = sep3_j0(B, KS); j <= sep3_j1(B, KS) && j <= KS - i; ++j) n += KS - i - j + 1;
     return n;
 }
 template <int KS, int B>
@@ -574,8 +590,8 @@ struct Sep3Canon {
     int v[sep3_count(B, KS) > 0 ? sep3_count(B, KS) : 1];
     constexpr Sep3Canon() : v{} {
         int n = 0;
-        for (int i = sep3_i0(B); i <= sep3_i1(B, KS) && i <= KS; ++i)
-            for (int j = sep3_j0(B); j <= sep3_j1(B, KS) && j <= KS - i; ++j)
+        for (int i = sep3_i0(B, KS); i <= sep3_i1(B, KS) && i <= KS && B < sep3_bands(KS); ++i)
+            for (int j = sep3_j0(B, KS); j <= sep3_j1(B, KS) && j <= KS - i; ++j)
                 for (int kk = 0; kk <= KS - i - j; ++kk) {
                     const int deg = i + j + kk;
                     const int cum = deg * (deg + 1) * (deg + 2) / 6;                 // monomials of degree < deg
@@ -594,8 +610,8 @@ __device__ inline void sep3_band(int lane, int N, int side, const double* rec0, 
     constexpr int NBm = sep3_count(B, KS);
     if constexpr (NBm > 0) {
         constexpr int NP = (NBm + 7) & ~7;
-        constexpr int I0 = sep3_i0(B), I1 = sep3_i1(B, KS) < KS ? sep3_i1(B, KS) : KS;
-        constexpr int J0 = sep3_j0(B), J1 = sep3_j1(B, KS);
+        constexpr int I0 = sep3_i0(B, KS), I1 = sep3_i1(B, KS) < KS ? sep3_i1(B, KS) : KS;
+        constexpr int J0 = sep3_j0(B, KS), J1 = sep3_j1(B, KS);
         double acc[NP];
 #pragma unroll
         for (int m = 0; m < NP; ++m) acc[m] = 0.0;
@@ -1040,8 +1056,10 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     // once for the 8 monomials, whose exponents are wave-uniform (scalar loop counts).
                     if constexpr (DX == 3) {
                         // three state dimensions: compile-time monomial structure, items = (side, band of the x0 exponent)
-                        for (int itm = slot; itm < 2 * kSep3Bands; itm += wpp) {
-                            const int side = itm >= kSep3Bands, band = itm - side * kSep3Bands;
+                        const int KS = K <= 3 ? 3 : K;                                   // K <= 6 on this path (P1)
+                        const int nbands = sep3_bands(KS);
+                        for (int itm = slot; itm < 2 * nbands; itm += wpp) {
+                            const int side = itm >= nbands, band = itm - side * nbands;
                             const double* rec0 = a_rows + (size_t)gq * NR * RS;
                             const double* kbp = a_kb + gq * N;
                             const double* il = c_ils2 + b * E;
