@@ -81,7 +81,7 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     L.aug = o;  o += (D + G) * 2 * D * D;       // D mean problems + G pair problems, [A | RHS]
     L.part = o; o += rnd2(G * wpp);
     L.mom = o;  o += G * 2 * rnd2(CM);
-    L.ints = o; o += rnd2((2 * P + 2 * G + 6 + 1) / 2);   // pa[P], pb[P], K[G], counter, noff, off[G] (ints)
+    L.ints = o; o += rnd2((2 * P + 2 * G + 6 + ((N + 15) / 16 + 2) + 1) / 2);   // pa[P], pb[P], K[G], counter, noff, off[G], tri[RC+1] (ints)
     L.c_ils2 = o;   o += rnd2(D * E);
     L.c_logvar = o; o += rnd2(D);
     L.c_var = o;    o += rnd2(D);
@@ -722,6 +722,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     int* s_counter = s_K + G;
     int* s_noff = s_counter + 1;            // off-diagonal pairs of the current group: count and their slots
     int* s_off = s_noff + 1;
+    int* s_tri = s_off + G;                 // diagonal pairs: column units of row chunks < r that can hold an element i <= j
 
     double* ppbase = smem;                  // per-point arrays live in LDS (large N: rollout_stream_kernel.h)
     double* a_nu = ppbase + L.nu;           // [d][p]
@@ -766,6 +767,13 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
         int q = 0;
         for (int a = 0; a < D; ++a)
             for (int b = a; b < D; ++b) { s_pa[q] = a; s_pb[q] = b; ++q; }
+        // a column unit (one column, or the pair (2 jc, 2 jc + 1)) is useful for row chunk r if its last column >= r CH
+        int run = 0;
+        for (int r = 0; r <= p.RC; ++r) {
+            s_tri[r] = run;
+            const int first = C2 ? (r * p.CH) / 2 : r * p.CH;          // first useful unit of chunk r
+            run += (first < NC) ? NC - first : 0;
+        }
     }
     __syncthreads();
     GPMPC_TRACE(1);
@@ -1113,9 +1121,25 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     continue;
                 }
                 const int flat = slot * 64 + lane;
-                const bool valid = flat < p.RC * NC;
-                const int r = valid ? (p.magic_N ? (int)__umulhi((unsigned)flat, p.magic_N) : flat) : 0;   // flat / NC
-                const int jc = valid ? flat - r * NC : 0;
+                bool valid;
+                int r, jc;
+                if (diag) {
+                    // only the (row chunk, column unit) combinations that contain an element i <= j are enumerated:
+                    // s_tri[r] = number of such combinations in chunks < r (lanes binary-search their chunk)
+                    valid = flat < s_tri[p.RC];
+                    int lo = 0, hi = p.RC;                         // invariant: s_tri[lo] <= flat < s_tri[hi]
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_tri[mid] <= flat) lo = mid; else hi = mid;
+                    }
+                    r = valid ? lo : 0;
+                    const int first = C2 ? (r * p.CH) / 2 : r * p.CH;
+                    jc = valid ? first + (flat - s_tri[r]) : 0;
+                } else {
+                    valid = flat < p.RC * NC;
+                    r = valid ? (p.magic_N ? (int)__umulhi((unsigned)flat, p.magic_N) : flat) : 0;   // flat / NC
+                    jc = valid ? flat - r * NC : 0;
+                }
                 const int j = C2 ? 2 * jc : jc;
                 const bool valid1 = C2 && (j + 1 < N);        // second column of the lane (two-column form)
                 const int jl = valid1 ? j + 1 : j;            // last column of the lane
