@@ -93,7 +93,7 @@ __host__ __device__ inline MomLayout make_mom_layout(int N, int D, int E, int G,
     L.m = o;        o += rnd2(E);
     L.Sig = o;      o += rnd2(D * D);
     L.aug = o;      o += (D + G) * 2 * D * D;
-    L.ints = o;     o += rnd2((2 * P + G + 2 + 1) / 2);      // pa[P], pb[P], K[G], counter
+    L.ints = o;     o += rnd2((2 * P + G + 2 + ((N + 3) / 4 + 2) + 1) / 2);      // pa[P], pb[P], K[G], counter, tri[RC + 1]
     L.nu = o;       o += rnd2(D * N);
     L.xe = o;       o += rnd2((E - D) * N);
     L.lb = o;       o += rnd2(D * N);
@@ -132,6 +132,7 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
     int* s_pb = s_pa + P;
     int* s_K = s_pb + P;                 // per pair of the group: Taylor degree of exp(g.w), 0 = direct exp
     int* s_counter = s_K + G;
+    int* s_tri = s_counter + 1;          // diagonal pairs: column units of row chunks < r that can hold an element i <= j
     double* c_xr = smem + L.c_xr;
     double* a_nu = smem + L.nu;
     double* a_xe = smem + L.xe;
@@ -161,6 +162,13 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
         int q = 0;
         for (int a = 0; a < D; ++a)
             for (int b = a; b < D; ++b) { s_pa[q] = a; s_pb[q] = b; ++q; }
+        // a column unit (NC adjacent columns) is useful for row chunk r of a diagonal pair if its last column >= r CH
+        int run = 0;
+        for (int r = 0; r <= p.RC; ++r) {
+            s_tri[r] = run;
+            const int first = (r * p.CH) / NC;
+            run += (first < NCU) ? NCU - first : 0;
+        }
     }
     __syncthreads();
 #if defined(GPMPC_PROF_ON)
@@ -366,9 +374,23 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
             const int b = __builtin_amdgcn_readfirstlane(s_pb[q0 + gq]);
             const bool diag = (a == b);
             const int flat = slot * 64 + lane;
-            const bool valid = flat < p.RC * NCU;
-            const int r = valid ? (p.magic_N ? (int)__umulhi((unsigned)flat, p.magic_N) : flat) : 0;       // flat / NCU
-            const int jc = valid ? flat - r * NCU : 0;
+            bool valid;
+            int r, jc;
+            if (diag) {
+                // only the (row chunk, column unit) tiles that contain an element i <= j (as in the forward kernel)
+                valid = flat < s_tri[p.RC];
+                int lo = 0, hi = p.RC;
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_tri[mid] <= flat) lo = mid; else hi = mid;
+                }
+                r = valid ? lo : 0;
+                jc = valid ? (r * p.CH) / NC + (flat - s_tri[r]) : 0;
+            } else {
+                valid = flat < p.RC * NCU;
+                r = valid ? (p.magic_N ? (int)__umulhi((unsigned)flat, p.magic_N) : flat) : 0;       // flat / NCU
+                jc = valid ? flat - r * NCU : 0;
+            }
             // the lane's NC adjacent columns j .. j + NC - 1 (two columns per lane halve the LDS broadcast traffic per
             // element, which bounds the one-column loop: 72 bytes of row record per lane and row)
             const int j = NC * jc;
