@@ -127,9 +127,10 @@ class GpMpcController(BaseControllerObject):
                 self.analytic_gradient = False         # shape outside the gradient kernels: difference the rollout
             else:
                 self.num_rollouts += 1
-                grad = self.actions_mapper.chain_grad_model_to_mpc(out["grad"][0].cpu().numpy())
-                self._cache_trajectory(out, 0)
-                return float(out["J"][0]), grad
+                host = self.transition_model.engine.host_views(out)          # one device-to-host copy for everything
+                grad = self.actions_mapper.chain_grad_model_to_mpc(host["grad"][0].numpy())
+                self._cache_trajectory(host, 0)
+                return float(host["J"][0]), grad
         cand = np.repeat(base[None], 4 * n + 1, axis=0)            # [base, +h, -h, +2h, -2h] per coordinate
         flat = cand.reshape(4 * n + 1, n)
         k = np.arange(n)
@@ -304,8 +305,9 @@ class GpMpcController(BaseControllerObject):
         self.transition_model.set_cost(self.config.reward)
         out = self.transition_model.objective_and_gradient_batch(acts, obs_mu, obs_var, self.iter_ctrl)
         self.num_rollouts += X.shape[0]
-        J = out["J"].cpu().numpy()
-        G = self.actions_mapper.chain_grad_model_to_mpc_batch(out["grad"].cpu().numpy())
+        host = self.transition_model.engine.host_views(out)
+        J = host["J"].numpy()
+        G = self.actions_mapper.chain_grad_model_to_mpc_batch(host["grad"].numpy())
         return J, G
 
     def _batched_lbfgs_search(self, state_mu, state_var):

@@ -172,13 +172,17 @@ class HipEngine:
         D = self.D
         mu0 = _host(mu0, (D,))
         S0 = _host(S0, (D, D))
-        out = {"J": torch.empty(B, dtype=torch.float64, device=self.device),
-               "grad": torch.empty((B, H, A), dtype=torch.float64, device=self.device)}
+        # one allocation, views into it: a caller that wants everything on the host needs ONE copy (`host_views`)
+        shapes = [("J", (B,)), ("grad", (B, H, A))]
         if trajectories:
-            out["mu"] = torch.empty((B, H + 1, D), dtype=torch.float64, device=self.device)
-            out["Sig"] = torch.empty((B, H + 1, D, D), dtype=torch.float64, device=self.device)
-            out["cost_mu"] = torch.empty((B, H + 1), dtype=torch.float64, device=self.device)
-            out["cost_var"] = torch.empty((B, H + 1), dtype=torch.float64, device=self.device)
+            shapes += [("mu", (B, H + 1, D)), ("Sig", (B, H + 1, D, D)), ("cost_mu", (B, H + 1)), ("cost_var", (B, H + 1))]
+        sizes = [int(np.prod(sh)) for _, sh in shapes]
+        pack = torch.empty(sum(sizes), dtype=torch.float64, device=self.device)
+        out, off = {"packed": pack, "layout": []}, 0
+        for (k, sh), n in zip(shapes, sizes):
+            out[k] = pack[off:off + n].view(sh)
+            out["layout"].append((k, sh, off, n))
+            off += n
         self._check(self.lib.gpmpc_rollout_grad(self._h, actions.data_ptr(), _hp(mu0), _hp(S0), B, H, A,
                                                 int(bool(include_time)), float(time0), out["J"].data_ptr(),
                                                 out["grad"].data_ptr(),
@@ -187,6 +191,12 @@ class HipEngine:
                                                 out["cost_mu"].data_ptr() if trajectories else None,
                                                 out["cost_var"].data_ptr() if trajectories else None, self._stream()))
         return out
+
+    @staticmethod
+    def host_views(out):
+        """All tensors of a `rollout_grad` result on the host with a single device-to-host copy."""
+        host = out["packed"].cpu()
+        return {k: host[off:off + n].view(sh) for k, sh, off, n in out["layout"]}
 
     def rollout_timed(self, actions, mu0, S0, reps, include_time=False, time0=0.0):
         """Average kernel milliseconds per launch, measured with HIP events on the launch stream."""
