@@ -15,14 +15,14 @@ int launch_moments(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s
         auto kern = pair_moments_kernel<DP, NXP, kMomThreads, 2>;
         int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
         if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3(g.H, g.B), dim3(kMomThreads), lds_bytes, s, g);
+        hipLaunchKernelGGL(kern, dim3(g.H, g.B, g.gz), dim3(kMomThreads), lds_bytes, s, g);
     } else {
         // 16 waves per (candidate, step) where the accumulators fit the 128-VGPR budget of a 1024-thread workgroup
         constexpr int NT = (DP <= 3) ? 1024 : kMomThreads;
         auto kern = pair_moments_kernel<DP, NXP, NT, 1>;
         int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
         if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3(g.H, g.B), dim3(NT), lds_bytes, s, g);
+        hipLaunchKernelGGL(kern, dim3(g.H, g.B, g.gz), dim3(NT), lds_bytes, s, g);
     }
     GPMPC_HIP_CHECK(h, hipGetLastError());
     return GPMPC_OK;
@@ -74,6 +74,15 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
         if ((size_t)L.total * 8 <= (size_t)h->lds_limit) { G = gg; mom_lds = (size_t)L.total * 8; break; }
     }
     const int sweep_nt = DP <= 4 ? 64 : 256;
+    // a small batch leaves most CUs idle: spread the pair groups of each (candidate, step) over up to P workgroups
+    int gz = 1;
+    if ((long long)B * H * 2 <= h->num_cu) {
+        int zmax = h->num_cu / (B * H);
+        if (zmax > P) zmax = P;
+        const int Gs = (P + zmax - 1) / zmax;            // pairs per workgroup
+        if (Gs < G) { G = Gs; const MomLayout L = make_mom_layout(N, D, E, G, RS, NR, wpp, NSP); mom_lds = (size_t)L.total * 8; }
+        gz = (P + G - 1) / G;
+    }
     const SweepLayout SL = make_sweep_layout(D, A, E, H, NSP, sweep_nt / 64, DP <= 4 ? 0 : kSweepAug);
     if (G == 0 || (size_t)SL.total * 8 > (size_t)h->lds_limit) {
         h->err = "gradient: N too large for the LDS-resident gradient kernels"; return GPMPC_ERR_LIMIT;
@@ -100,7 +109,7 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     g.N = N; g.D = D; g.A = A; g.E = E; g.H = H; g.B = B; g.include_time = a.include_time; g.time0 = a.time0;
     g.grad = grad_out;
     g.DP = DP; g.NXP = NXP; g.NSP = NSP;
-    g.G = G; g.CH = CH; g.RC = RC; g.wpp = wpp;
+    g.G = G; g.CH = CH; g.RC = RC; g.wpp = wpp; g.gz = gz;
     g.cols = cols;
     g.magic_N = magic((unsigned)NCU); g.magic_wpp = magic((unsigned)wpp);
 

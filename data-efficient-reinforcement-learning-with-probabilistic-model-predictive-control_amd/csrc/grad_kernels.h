@@ -45,6 +45,7 @@ struct GradArgs {
     int force_path;         // 0 auto, 1 always the direct exp form (tests)
     int cols;               // columns per lane in the pairwise pass (1 or 2)
     int G, CH, RC, wpp;
+    int gz;                 // workgroups per (candidate, step) in the moment pass (pair groups spread over blockIdx.z)
     unsigned magic_N, magic_wpp;
 };
 
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
     GPMPC_GTRACE(0);
     // moments of nu under the weights lb_ai up to third order (what the reverse sweep needs of the mean part)
     const int NM = mean_moment_count(D, NX);
-    for (int task = wave; task < D * NM; task += NW) {
+    for (int task = wave; task < ((blockIdx.z == 0) ? D * NM : 0); task += NW) {
         const int a = task / NM, comp = task - a * NM;
         int i1, i2, i3;
         decode_mean_moment(comp, D, NX, i1, i2, i3);
@@ -248,7 +249,9 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
         if (lane == 0) p.msum[(((size_t)c * H + t) * D + a) * NM + comp] = v;
     }
 
-    for (int q0 = 0; q0 < P; q0 += G) {
+    // small batches: the pair groups of one (candidate, step) are spread over gridDim.z workgroups (each repeats the
+    // per-point set-up; the mean moments are written by z = 0)
+    for (int q0 = (int)blockIdx.z * G; q0 < P; q0 += G * (int)gridDim.z) {
         const int Gc = (P - q0 < G) ? (P - q0) : G;
         if (tid < Gc) {
             const int gq = tid;
