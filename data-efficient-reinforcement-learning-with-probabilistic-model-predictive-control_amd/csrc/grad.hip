@@ -83,7 +83,12 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
         if (Gs < G) { G = Gs; const MomLayout L = make_mom_layout(N, D, E, G, RS, NR, wpp, NSP); mom_lds = (size_t)L.total * 8; }
         gz = (P + G - 1) / G;
     }
-    const SweepLayout SL = make_sweep_layout(D, A, E, H, NSP, sweep_nt / 64, DP <= 4 ? 0 : kSweepAug);
+    int pre_steps = 0;
+    if (DP <= 4) {               // state-independent small algebra of all steps up front when it fits beside the rest
+        const SweepLayout Lp = make_sweep_layout(D, A, E, H, NSP, sweep_nt / 64, 0, H);
+        if ((size_t)Lp.total * 8 <= 96 * 1024) pre_steps = H;
+    }
+    const SweepLayout SL = make_sweep_layout(D, A, E, H, NSP, sweep_nt / 64, DP <= 4 ? 0 : kSweepAug, pre_steps);
     if (G == 0 || (size_t)SL.total * 8 > (size_t)h->lds_limit) {
         h->err = "gradient: N too large for the LDS-resident gradient kernels"; return GPMPC_ERR_LIMIT;
     }
@@ -109,7 +114,7 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     g.N = N; g.D = D; g.A = A; g.E = E; g.H = H; g.B = B; g.include_time = a.include_time; g.time0 = a.time0;
     g.grad = grad_out;
     g.DP = DP; g.NXP = NXP; g.NSP = NSP;
-    g.G = G; g.CH = CH; g.RC = RC; g.wpp = wpp; g.gz = gz;
+    g.G = G; g.CH = CH; g.RC = RC; g.wpp = wpp; g.gz = gz; g.pre_steps = pre_steps;
     g.cols = cols;
     g.magic_N = magic((unsigned)NCU); g.magic_wpp = magic((unsigned)wpp);
 

@@ -41,6 +41,7 @@ struct GradArgs {
     double* msum;    // (B, H, D, NM)    moments of nu under lb_a up to third order (mean_moment_count)
     double* grad;    // (B, H, A)
     const double* xrange;   // (2, E) min / max of the memory points per input dimension
+    int pre_steps;          // sweep: H if the state-independent algebra of all steps fits the LDS (computed up front), else 0
     int DP, NXP, NSP;
     int force_path;         // 0 auto, 1 always the direct exp form (tests)
     int cols;               // columns per lane in the pairwise pass (1 or 2)
@@ -554,10 +555,15 @@ constexpr int kSweepPrefetch = (DP == 2) ? 1 : (DP == 3) ? 3 : (DP == 4) ? 6 : (
 
 struct SweepLayout {
     int c_ils2, c_var, cost, gmu, gSig, gu, ctmp, mubar, Sigbar, Sacc, mbar, m, Sig, ms, mom, Ai, cc, M, y, V, Sb, Vb, Mb, cb, s0b,
-        s1b, Gs, Aib, Ab, mba, Ri, Z, rdet, RZ, Kq, mq, aug, total;
+        s1b, Gs, Aib, Ab, mba, Ri, Z, rdet, RZ, Kq, mq, aug, pre, total;
 };
 
-__host__ __device__ inline SweepLayout make_sweep_layout(int D, int A, int E, int H, int NSP, int nwaves, int naug) {
+__host__ __device__ inline int sweep_pre_words(int D) {        // per step: Ai, c, Ri, Z, rdet, y, V, M
+    const int P = D * (D + 1) / 2, DD = D * D;
+    return D * DD + D + 2 * P * DD + P + 2 * DD + D;
+}
+
+__host__ __device__ inline SweepLayout make_sweep_layout(int D, int A, int E, int H, int NSP, int nwaves, int naug, int pre_steps) {
     SweepLayout L;
     const int P = D * (D + 1) / 2, DD = D * D, n = D + A, NX = E - D;
     int o = 0;
@@ -571,6 +577,7 @@ __host__ __device__ inline SweepLayout make_sweep_layout(int D, int A, int E, in
     take(L.Gs, D * (D + DD + NX)); take(L.Aib, D * DD); take(L.Ab, D * DD); take(L.mba, D * E);
     take(L.Ri, P * DD); take(L.Z, P * DD); take(L.rdet, P); take(L.RZ, P * DD); take(L.Kq, D <= 4 ? P * DD : 0); take(L.mq, P * E);
     take(L.aug, naug * D * 2 * D);
+    take(L.pre, pre_steps * sweep_pre_words(D));      // state-independent small algebra of every step, computed up front
     L.total = o;
     return L;
 }
@@ -676,12 +683,15 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
     const int NG = D + DD + NX;
     const int T2 = tri_count(D), NM = mean_moment_count(D, NX);
     const int LD = 2 * D;
-    const SweepLayout L = make_sweep_layout(D, A, E, H, NSP, NW, DP <= 4 ? 0 : kSweepAug);
+    const SweepLayout L = make_sweep_layout(D, A, E, H, NSP, NW, DP <= 4 ? 0 : kSweepAug, p.pre_steps);
     double* c_ils2 = smem + L.c_ils2; double* c_var = smem + L.c_var; double* c_cost = smem + L.cost;
     double* gmu = smem + L.gmu; double* gSig = smem + L.gSig; double* gu = smem + L.gu; double* ctmp = smem + L.ctmp;
     double* mubar = smem + L.mubar; double* Sigbar = smem + L.Sigbar; double* Sacc = smem + L.Sacc; double* mbar = smem + L.mbar;
     double* s_m = smem + L.m; double* s_Sig = smem + L.Sig; double* s_ms = smem + L.ms; double* s_mom = smem + L.mom;
     double* s_Ai = smem + L.Ai; double* s_cc = smem + L.cc; double* s_M = smem + L.M; double* s_y = smem + L.y; double* s_V = smem + L.V;
+    double* s_pre = smem + L.pre;
+    const bool pre = (DP <= 4) && p.pre_steps > 0;
+    const int NQ = sweep_pre_words(D);
     double* s_Sb = smem + L.Sb; double* s_Vb = smem + L.Vb; double* s_Mb = smem + L.Mb; double* s_cb = smem + L.cb;
     double* s_s0b = smem + L.s0b; double* s_s1b = smem + L.s1b; double* s_Gs = smem + L.Gs; double* s_Aib = smem + L.Aib;
     double* s_Ab = smem + L.Ab; double* s_mba = smem + L.mba; double* s_Ri = smem + L.Ri; double* s_Z = smem + L.Z;
@@ -721,6 +731,67 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
     }
     sync();
 
+    // ---- state-independent small algebra of every step, all steps in parallel (lanes over (step, problem)) -----------
+    const int oCC = D * DD, oRI = oCC + D, oZ = oRI + P * DD, oRD = oZ + P * DD, oY = oRD + P, oV = oY + DD, oM = oV + DD;
+    if constexpr (DP <= 4) {
+        if (pre) {
+            for (int idx = tid; idx < H * (D + P); idx += NT) {
+                const int t = idx / (D + P), prob = idx - t * (D + P);
+                const double* Sg = traj_Sig + t * DD;
+                double* base = s_pre + t * NQ;
+                int a = prob, b = prob;
+                if (prob >= D) pair_of(prob - D, a, b);
+                double m[DP][2 * DP];
+#pragma unroll
+                for (int i = 0; i < DP; ++i)
+#pragma unroll
+                    for (int j = 0; j < DP; ++j) {
+                        const bool in = (i < D && j < D);
+                        const double sg = in ? Sg[i * D + j] : 0.0;
+                        double v;
+                        if (prob < D) v = sg + ((i == j) ? (i < D ? 1.0 / c_ils2[a * E + i] : 1.0) : 0.0);
+                        else v = sg * (in ? c_ils2[a * E + j] + c_ils2[b * E + j] : 0.0) + (i == j ? 1.0 : 0.0);
+                        m[i][j] = v;
+                        m[i][DP + j] = (i == j) ? 1.0 : 0.0;
+                    }
+                const double det = small_solve<DP>(m);
+                double* dst = (prob < D) ? base + a * DD : base + oRI + (prob - D) * DD;
+#pragma unroll
+                for (int i = 0; i < DP; ++i)
+#pragma unroll
+                    for (int j = 0; j < DP; ++j)
+                        if (i < D && j < D) dst[i * D + j] = m[i][DP + j];
+                if (prob < D) {
+                    double prodil = 1.0;
+                    for (int i = 0; i < D; ++i) prodil *= c_ils2[a * E + i];
+                    base[oCC + a] = c_var[a] / sqrt(det * prodil);
+                } else {
+                    base[oRD + prob - D] = 1.0 / sqrt(det);
+                }
+            }
+            sync();
+            for (int idx = tid; idx < H * P * DD; idx += NT) {
+                const int t = idx / (P * DD), i = idx - t * (P * DD);
+                const int q = i / DD, r = (i - q * DD) / D, cc = i - q * DD - r * D;
+                const double* base = s_pre + t * NQ;
+                double v = 0.0;
+                for (int k = 0; k < D; ++k) v = fma(base[oRI + q * DD + r * D + k], traj_Sig[t * DD + k * D + cc], v);
+                s_pre[t * NQ + oZ + i] = v;
+            }
+            for (int idx = tid; idx < H * DD; idx += NT) {
+                const int t = idx / DD, i = idx - t * DD;
+                const int a = i / D, k = i - a * D;
+                const double* ms = p.msum + (((size_t)c * H + t) * D + a) * NM;
+                double* base = s_pre + t * NQ;
+                double v = 0.0;
+                for (int j = 0; j < D; ++j) v = fma(base[a * DD + k * D + j], ms[1 + j], v);
+                base[oY + a * D + k] = v;
+                base[oV + k * D + a] = base[oCC + a] * v;
+                if (k == 0) base[oM + a] = base[oCC + a] * ms[0];
+            }
+            sync();
+        }
+    }
     // NPF values per lane cover P*NSP and D*NM (host checks the bound); E, D*D <= NT
     double pf_mom[NPF], pf_ms[NPF], pf_m = 0.0, pf_Sig = 0.0;
     auto fetch = [&](int t) {
@@ -752,9 +823,19 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             if (tid < E) s_m[tid] = (tid < D + A) ? pf_m : p.time0 + (double)t;
             if (tid < DD) s_Sig[tid] = pf_Sig;
             if (t > 0) fetch(t - 1);
+            if (pre) {                       // this step's A^-1, c, R^-1, Z, 1/sqrt det R, y, V, M were computed up front
+                double* base = s_pre + t * NQ;
+                s_Ai = base; s_cc = base + oCC; s_Ri = base + oRI; s_Z = base + oZ; s_rdet = base + oRD;
+                s_y = base + oY; s_V = base + oV; s_M = base + oM;
+                for (int i = tid; i < DD; i += NT) {
+                    const int r = i / D, q = i - r * D;
+                    s_Sb[i] = 0.5 * (Sigbar[i] + Sigbar[q * D + r]);
+                }
+            }
         }
         sync();
         GPMPC_STRACE(0);
+        if (!pre) {
         // ---- small solves: A_a^-1, c_a;  R_ab^-1, Z_ab, 1/sqrt det R_ab --------------------------------
         constexpr int PSTEP = (DP <= 4) ? NT : kSweepAug;        // LDS solves: kSweepAug threads, one augmented block each
         for (int prob = tid; prob < D + P && tid < PSTEP; prob += PSTEP) {
@@ -825,6 +906,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         }
         for (int a = tid; a < D; a += NT) s_M[a] = s_cc[a] * s_ms[a * NM];
         sync();
+        }
         GPMPC_STRACE(2);
         // ---- Sigma' = Sigma + S + Sigma V + (Sigma V)^T,  mu' = mu + M,  S -= M M^T ------------------
         for (int i = tid; i < DD; i += NT) {
