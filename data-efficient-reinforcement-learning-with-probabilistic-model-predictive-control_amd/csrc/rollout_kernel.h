@@ -81,7 +81,7 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     L.aug = o;  o += (D + G) * 2 * D * D;       // D mean problems + G pair problems, [A | RHS]
     L.part = o; o += rnd2(G * wpp);
     L.mom = o;  o += G * 2 * rnd2(CM);
-    L.ints = o; o += rnd2((2 * P + 2 * G + 6 + ((N + 15) / 16 + 2) + 1) / 2);   // pa[P], pb[P], K[G], counter, noff, off[G], tri[RC+1] (ints)
+    L.ints = o; o += rnd2((2 * P + 2 * G + 6 + 16 + ((N + 15) / 16 + 2) + 1) / 2);   // pa[P], pb[P], K[G], counter, noff, off[G], mcum[16], tri[RC+1] (ints)
     L.c_ils2 = o;   o += rnd2(D * E);
     L.c_logvar = o; o += rnd2(D);
     L.c_var = o;    o += rnd2(D);
@@ -722,7 +722,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     int* s_counter = s_K + G;
     int* s_noff = s_counter + 1;            // off-diagonal pairs of the current group: count and their slots
     int* s_off = s_noff + 1;
-    int* s_tri = s_off + G;                 // diagonal pairs: column units of row chunks < r that can hold an element i <= j
+    int* s_mcum = s_off + G;                // monomials of degree <= k (copy of the launch argument: LDS instead of a kernarg load on the serial path)
+    int* s_tri = s_mcum + 16;               // diagonal pairs: column units of row chunks < r that can hold an element i <= j
 
     double* ppbase = smem;                  // per-point arrays live in LDS (large N: rollout_stream_kernel.h)
     double* a_nu = ppbase + L.nu;           // [d][p]
@@ -763,6 +764,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
         const int gq = i / (p.CH * RS), k = i - gq * (p.CH * RS);
         a_rows[((size_t)gq * NR + N) * RS + k] = 0.0;                      // zero padding rows
     }
+    if (tid >= 64 && tid < 80) s_mcum[tid - 64] = p.mono_cum[tid - 64];
     if (tid == 0) {
         int q = 0;
         for (int a = 0; a < D; ++a)
@@ -801,6 +803,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
             const int nmean = first ? D : 0;
 
             // ---- P1: small D x D algebra, one thread per problem ------------------------------
+            // (mean problems on wave 0, pair problems on wave 1: the two instruction streams are long dependent fp64
+            //  chains and would run one after the other as divergent branches of one wavefront)
+            constexpr int kPairBase = (NT >= 256) ? 64 : 0;
             if (first) {
                 // input mean of this step: [mu, a_t, (time)]  (gp_model.py:98-102)
                 for (int i = tid; i < E; i += NT) {
@@ -848,8 +853,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     detA = gauss_solve(aug, D, D, LD);
                 }
                 s_cc[a] = c_var[a] / sqrt(detA * prodil);            // c_a = var_a / sqrt(det B_a)  (:150)
-            } else if (tid < nmean + Gc) {
-                const int gq = tid - nmean;
+            } else if (tid >= kPairBase + (kPairBase ? 0 : nmean) && tid < kPairBase + (kPairBase ? 0 : nmean) + Gc) {
+                const int gq = tid - kPairBase - (kPairBase ? 0 : nmean);
                 const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
                 double* aug = s_aug + (D + gq) * (D * LD);
                 double detR;
@@ -867,21 +872,30 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                             m[i][j] = sg * dab + (i == j ? 1.0 : 0.0);                   // R (:156-159)
                             m[i][DP + j] = sg;
                         }
-                    detR = small_solve<DP>(m);                                            // Z = R^-1 Sigma = 2Q (:163)
+                    double ur[DP], wr[DP];                 // data-range bounds of |u_d|, |w_d|: independent of the solve
 #pragma unroll
                     for (int i = 0; i < DP; ++i) {
                         const double mi = (i < D) ? s_mu[i] : 0.0;
-                        const double ui = (i < D) ? fmax(fabs(c_xr[i] - mi), fabs(c_xr[E + i] - mi)) * c_ils2[a * E + i] : 0.0;
+                        const double rg = (i < D) ? fmax(fabs(c_xr[i] - mi), fabs(c_xr[E + i] - mi)) : 0.0;
+                        ur[i] = (i < D) ? rg * c_ils2[a * E + i] : 0.0;
+                        wr[i] = (i < D) ? rg * c_ils2[b * E + i] : 0.0;
+                    }
+                    detR = small_solve<DP>(m);                                            // Z = R^-1 Sigma = 2Q (:163)
+                    double rowc[DP];                       // row sums first: three short chains instead of one of D^2 FMAs
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) {
+                        double r = 0.0;
 #pragma unroll
                         for (int j = 0; j < DP; ++j) {
                             if (i < D && j < D) {
                                 aug[i * LD + D + j] = m[i][DP + j];
-                                const double mj = s_mu[j];
-                                const double wj = fmax(fabs(c_xr[j] - mj), fabs(c_xr[E + j] - mj)) * c_ils2[b * E + j];
-                                cmax = fma(fabs(m[i][DP + j]) * ui, wj, cmax);
+                                r = fma(fabs(m[i][DP + j]), wr[j], r);
                             }
                         }
+                        rowc[i] = r * ur[i];
                     }
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) cmax += rowc[i];
                 } else {
                     for (int i = 0; i < D; ++i)
                         for (int j = 0; j < D; ++j) {
@@ -914,8 +928,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     // wavefront instructions against ~(D + K + 3) per element of the pairwise loop.  D = 3 (compile-time
                     // monomial structure): ~2 per monomial and 64 points + the 8-value reductions; otherwise per block of 8
                     // monomials and side ~(6 + 8 (avg degree + 1)) per 64 points + one 8-value reduction
-                    const long long C_ = p.mono_cum[K < 3 ? 3 : K];
-                    const long long NBk = (p.mono_cum[K] + 7) / 8;
+                    const long long C_ = s_mcum[K < 3 ? 3 : K];
+                    const long long NBk = (s_mcum[K] + 7) / 8;
                     const long long cost_sep = (DX == 3) ? 2 * (((N + 63) / 64) * (2 * C_ + 40) + (C_ / 8 + 4) * 70)
                                                          : 2 * NBk * (((N + 63) / 64) * (6 + 8 * K) + 80);
                     const long long cost_el = (long long)N * N * (D + K + 3) / 64;
@@ -1079,7 +1093,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                         }
                         continue;
                     }
-                    const int C = p.mono_cum[K];
+                    const int C = s_mcum[K];
                     const int NBk = (C + 7) >> 3;
                     for (int blk = slot; blk < 2 * NBk; blk += wpp) {
                         const int side = blk >= NBk;
@@ -1208,7 +1222,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                 const int Kraw = s_K[gq];
                 double v = 0.0;
                 if (Kraw & 64) {
-                    const int C = p.mono_cum[Kraw & 63];
+                    const int C = s_mcum[Kraw & 63];
                     const double* Gm = s_mom + (gq * 2) * rnd2(CM);
                     const double* Wm = Gm + rnd2(CM);
                     for (int al = lane; al < C; al += 64) v = fma(Gm[al] * Wm[al], c_monow[al], v);
