@@ -30,6 +30,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 PEAK_F64_VECTOR_TFLOPS = 78.6     # MI355X fp64 vector peak (AMD spec; = 1/2 of the 157.3 TF fp32 vector peak)
+# what an FMA loop reaches on the box (tools/microbench/mfma_f64_rate.hip, 8 independent v_fma_f64 chains x 4 waves per SIMD,
+# 256 workgroups): reported beside the nominal peak as SURVEY.md 8(d) asks
+MEASURED_F64_FMA_LOOP_TFLOPS = 59.9
 
 
 def algorithmic_flops_per_rollout(N, D, A, E, H):
@@ -204,6 +207,12 @@ def main():
                        "parallelism": f"candidates sharded x{world}, RCCL gather of (J, idx) only"},
             "roofline": {"bound": "valu_f64", "achieved": achieved_tflops, "peak": PEAK_F64_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F64_VECTOR_TFLOPS, "traffic": traffic,
+                         "peak_measured_fma_loop": MEASURED_F64_FMA_LOOP_TFLOPS,
+                         "frac_of_measured_fma_loop": achieved_tflops / MEASURED_F64_FMA_LOOP_TFLOPS,
+                         "hbm_view": {"achieved_gbps": algorithmic_bytes_per_rollout(N, D, E, H) * Bg / (kernel_ms * 1e-3) / 1e9,
+                                      "peak_gbps": 8000.0,
+                                      "note": "compulsory bytes without cross-candidate reuse; above the HBM peak because the "
+                                              "T_a tiles are shared by the candidates and stay in L2 (see traffic)"},
                          "kernel": "rollout_kernel", "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_launch": flops_launch,
                          "algorithmic_bytes_per_launch": algorithmic_bytes_per_rollout(N, D, E, H) * Bg,

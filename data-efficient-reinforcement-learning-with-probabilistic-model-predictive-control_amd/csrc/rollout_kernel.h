@@ -54,7 +54,7 @@ constexpr int kMaxMono = 256;      // most monomials of the separable (off-diago
 // LDS / scratch layout (offsets in doubles), shared by host (sizing) and device (carving).
 struct Layout {
     int mu, Sig, m, M, cc, s1, Vs, Sp, misc, rdet, aug, part, mom, ints;
-    int c_ils2, c_ls2, c_logvar, c_var, c_xr, c_act, c_exptab, c_monow, c_monoe, c_X, c_beta;    // read-only tables copied to LDS once
+    int c_ils2, c_logvar, c_var, c_xr, c_act, c_exptab, c_monow, c_monoe, c_X;    // read-only tables copied to LDS once
     int lds_total;     // doubles of LDS
     // per-point arrays (LDS)
     int nu, lb, rows, kb;
@@ -83,7 +83,6 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     L.mom = o;  o += G * 2 * rnd2(CM);
     L.ints = o; o += rnd2((2 * P + 2 * G + 6 + 16 + ((N + 15) / 16 + 2) + 1) / 2);   // pa[P], pb[P], K[G], counter, noff, off[G], mcum[16], tri[RC+1] (ints)
     L.c_ils2 = o;   o += rnd2(D * E);
-    L.c_ls2 = o;    o += rnd2(D * D);           // l_a,d^2 of the state dimensions (no division on the serial path)
     L.c_logvar = o; o += rnd2(D);
     L.c_var = o;    o += rnd2(D);
     L.c_xr = o;     o += rnd2(2 * E);
@@ -92,7 +91,6 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     L.c_monow = o;  o += rnd2(CM);
     L.c_monoe = o;  o += rnd2((CM + 1) / 2);           // packed exponents, one int per monomial
     L.c_X = o;      o += x_in_lds ? rnd2(E * N) : 0;   // X^T cached for the per-point pass when it fits
-    L.c_beta = o;   o += x_in_lds ? rnd2(D * N) : 0;   // ... and beta with it
     int q = o;
     L.nu = q;   q += rnd2(D * N);
     L.lb = q;   q += rnd2(D * N);
@@ -230,52 +228,52 @@ __device__ inline double gauss_solve_reg(double (&a)[DP][2 * DP]) {
 // Sigma diag(.) + I with Sigma small, i.e. far from singular, so cofactor expansion is accurate to a
 // few ulps and an order of magnitude shorter than elimination (the solve sits on the serial
 // per-step critical path of one wavefront).  [A | RHS] -> RHS := A^-1 RHS, returns det(A).
-template <int DP, bool IDENT = false>
+template <int DP>
 __device__ inline double adjugate_solve(double (&a)[DP][2 * DP]) {
     static_assert(DP == 2 || DP == 3, "closed form only for 2x2 / 3x3");
-    double adj[DP][DP];
+    double inv[DP][DP];
     double det;
     if constexpr (DP == 2) {
         det = fma(a[0][0], a[1][1], -(a[0][1] * a[1][0]));
-        adj[0][0] = a[1][1];  adj[0][1] = -a[0][1];
-        adj[1][0] = -a[1][0]; adj[1][1] = a[0][0];
+        const double id = 1.0 / det;
+        inv[0][0] = a[1][1] * id;  inv[0][1] = -a[0][1] * id;
+        inv[1][0] = -a[1][0] * id; inv[1][1] = a[0][0] * id;
     } else {
-        adj[0][0] = fma(a[1][1], a[2][2], -(a[1][2] * a[2][1]));
-        adj[1][0] = fma(a[1][2], a[2][0], -(a[1][0] * a[2][2]));
-        adj[2][0] = fma(a[1][0], a[2][1], -(a[1][1] * a[2][0]));
-        det = fma(a[0][0], adj[0][0], fma(a[0][1], adj[1][0], a[0][2] * adj[2][0]));
-        adj[0][1] = fma(a[0][2], a[2][1], -(a[0][1] * a[2][2]));
-        adj[1][1] = fma(a[0][0], a[2][2], -(a[0][2] * a[2][0]));
-        adj[2][1] = fma(a[0][1], a[2][0], -(a[0][0] * a[2][1]));
-        adj[0][2] = fma(a[0][1], a[1][2], -(a[0][2] * a[1][1]));
-        adj[1][2] = fma(a[0][2], a[1][0], -(a[0][0] * a[1][2]));
-        adj[2][2] = fma(a[0][0], a[1][1], -(a[0][1] * a[1][0]));
+        const double c00 = fma(a[1][1], a[2][2], -(a[1][2] * a[2][1]));
+        const double c01 = fma(a[1][2], a[2][0], -(a[1][0] * a[2][2]));
+        const double c02 = fma(a[1][0], a[2][1], -(a[1][1] * a[2][0]));
+        det = fma(a[0][0], c00, fma(a[0][1], c01, a[0][2] * c02));
+        const double id = 1.0 / det;
+        inv[0][0] = c00 * id;
+        inv[1][0] = c01 * id;
+        inv[2][0] = c02 * id;
+        inv[0][1] = fma(a[0][2], a[2][1], -(a[0][1] * a[2][2])) * id;
+        inv[1][1] = fma(a[0][0], a[2][2], -(a[0][2] * a[2][0])) * id;
+        inv[2][1] = fma(a[0][1], a[2][0], -(a[0][0] * a[2][1])) * id;
+        inv[0][2] = fma(a[0][1], a[1][2], -(a[0][2] * a[1][1])) * id;
+        inv[1][2] = fma(a[0][2], a[1][0], -(a[0][0] * a[1][2])) * id;
+        inv[2][2] = fma(a[0][0], a[1][1], -(a[0][1] * a[1][0])) * id;
     }
-    // adj . RHS runs beside the division (both only need the cofactors); one multiplication after it
     double out[DP][DP];
 #pragma unroll
     for (int i = 0; i < DP; ++i)
 #pragma unroll
         for (int j = 0; j < DP; ++j) {
-            if constexpr (IDENT) out[i][j] = adj[i][j];
-            else {
-                double v = 0.0;
+            double v = 0.0;
 #pragma unroll
-                for (int k = 0; k < DP; ++k) v = fma(adj[i][k], a[k][DP + j], v);
-                out[i][j] = v;
-            }
+            for (int k = 0; k < DP; ++k) v = fma(inv[i][k], a[k][DP + j], v);
+            out[i][j] = v;
         }
-    const double id = 1.0 / det;
 #pragma unroll
     for (int i = 0; i < DP; ++i)
 #pragma unroll
-        for (int j = 0; j < DP; ++j) a[i][DP + j] = out[i][j] * id;
+        for (int j = 0; j < DP; ++j) a[i][DP + j] = out[i][j];
     return det;
 }
 
-template <int DP, bool IDENT = false>      // IDENT: the right-hand side is the identity (plain inverse)
+template <int DP>
 __device__ inline double small_solve(double (&a)[DP][2 * DP]) {
-    if constexpr (DP <= 3) return adjugate_solve<DP, IDENT>(a);
+    if constexpr (DP <= 3) return adjugate_solve<DP>(a);
     else return gauss_solve_reg<DP>(a);
 }
 
@@ -735,13 +733,11 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
 
     double* c_ils2 = smem + L.c_ils2;
     double* c_logvar = smem + L.c_logvar;
-    double* c_ls2 = smem + L.c_ls2;
     double* c_var = smem + L.c_var;
     double* c_xr = smem + L.c_xr;
     double* c_act = smem + L.c_act;
     double* c_exptab = smem + L.c_exptab;
     const double* Xs = p.x_in_lds ? (smem + L.c_X) : p.Xt;     // X^T (E, N): LDS copy or HBM/L2
-    const double* betas = p.x_in_lds ? (smem + L.c_beta) : p.beta;
     double* c_monow = smem + L.c_monow;
     int* c_monoe = reinterpret_cast<int*>(smem + L.c_monoe);
     const double* act = p.actions + (size_t)c * H * A;
@@ -755,14 +751,11 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     for (int i = tid; i < D; i += NT) { s_mu[i] = p.mu0[i]; c_logvar[i] = p.logvar[i]; c_var[i] = p.var[i]; }
     for (int i = tid; i < D * D; i += NT) s_Sig2[i] = p.S0[i];
     for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
-    for (int i = tid; i < D * D; i += NT) c_ls2[i] = 1.0 / p.ils2[(i / D) * E + (i % D)];
     for (int i = tid; i < 2 * E; i += NT) c_xr[i] = p.xrange[i];
     for (int i = tid; i < H * A; i += NT) c_act[i] = act[i];
     for (int i = tid; i < 64; i += NT) c_exptab[i] = kExp2Tab[i];
     if (p.x_in_lds)
         for (int i = tid; i < E * N; i += NT) smem[L.c_X + i] = p.Xt[i];
-    if (p.x_in_lds)
-        for (int i = tid; i < D * N; i += NT) smem[L.c_beta + i] = p.beta[i];
     for (int i = tid; i < CM; i += NT) {
         c_monow[i] = p.mono_w[i];
         c_monoe[i] = p.mono_exp[i * 4] | (p.mono_exp[i * 4 + 1] << 8) | (p.mono_exp[i * 4 + 2] << 16) | (p.mono_exp[i * 4 + 3] << 24);
@@ -838,11 +831,11 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
 #pragma unroll
                         for (int j = 0; j < DP; ++j) {
                             const bool in = (i < D && j < D);
-                            m[i][j] = (in ? s_Sig[i * D + j] : 0.0) + (i == j ? (i < D ? c_ls2[a * D + i] : 1.0) : 0.0);
+                            m[i][j] = (in ? s_Sig[i * D + j] : 0.0) + (i == j ? 1.0 / il2 : 0.0);
                             m[i][DP + j] = (in && i == j) ? 1.0 : 0.0;
                         }
                     }
-                    detA = small_solve<DP, true>(m);
+                    detA = small_solve<DP>(m);
 #pragma unroll
                     for (int i = 0; i < DP; ++i)
 #pragma unroll
@@ -859,7 +852,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     }
                     detA = gauss_solve(aug, D, D, LD);
                 }
-                s_cc[a] = c_var[a] * rsqrt(detA * prodil);           // c_a = var_a / sqrt(det B_a)  (:150)
+                s_cc[a] = c_var[a] / sqrt(detA * prodil);            // c_a = var_a / sqrt(det B_a)  (:150)
             } else if (tid >= kPairBase + (kPairBase ? 0 : nmean) && tid < kPairBase + (kPairBase ? 0 : nmean) + Gc) {
                 const int gq = tid - kPairBase - (kPairBase ? 0 : nmean);
                 const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
@@ -922,7 +915,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                         }
                     }
                 }
-                s_rdet[gq] = rsqrt(detR);                                                // (:176)
+                s_rdet[gq] = 1.0 / sqrt(detR);                                           // (:176)
                 // smallest K with cmax^(K+1)/(K+1)! * exp(2 cmax) <= 2^-54 (truncation below fp64 rounding)
                 int K = 0;
                 if (p.force_path != 1 && cmax <= kTaylorMaxArg[kMaxTaylor]) {
@@ -949,11 +942,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
 #endif
             if (tid == NT - 1) {
                 *s_counter = 0;
-                int no = 0, nd = 0;                 // off-diagonal pairs from the front, diagonal pairs from the back of s_off
-                for (int gq = 0; gq < Gc; ++gq) {
+                int no = 0;
+                for (int gq = 0; gq < Gc; ++gq)
                     if (s_pa[q0 + gq] != s_pb[q0 + gq]) s_off[no++] = gq;
-                    else s_off[G - 1 - nd++] = gq;
-                }
                 *s_noff = no;
             }
             __syncthreads();
@@ -987,7 +978,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                         const double v = Xs[e * N + pt] - s_m[e];
                         q = fma(v * v, c_ils2[a * E + e], q);
                     }
-                    a_lb[a * N + pt] = fast_exp(-0.5 * q, c_exptab) * betas[a * N + pt];   // lb (:148)
+                    a_lb[a * N + pt] = fast_exp(-0.5 * q, c_exptab) * p.beta[a * N + pt];   // lb (:148)
                     if (a == 0) {
 #pragma unroll
                         for (int d = 0; d < DP; ++d)
@@ -1028,7 +1019,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                         }
                     }
                     const double kk = c_logvar[c] - 0.5 * ks + 0.5 * qq;                  // k (:168) + u^T Q u
-                    const double bc = betas[c * N + pt];
+                    const double bc = p.beta[c * N + pt];
                     if (rowside) {
                         double* rec = a_rows + ((size_t)gq * NR + pt) * RS;
 #pragma unroll
@@ -1053,20 +1044,17 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
 
             // ---- P3: work queue: pairwise items, moment sums, mean sums, stage cost ----------------
             const int npair = Gc * wpp;
-            // Queue order = largest items first (the tail of a greedy queue is one item long): tiles of the diagonal pairs,
-            // then the off-diagonal pairs (separable items are ~1/2 of a tile), then the D mean sums (~1/5).
-            const int nextra = first ? D : 0;
+            const int nextra = first ? D : 0;                // items 0..D-1: mean sums (pulled first)
             const int total = nextra + npair;
-            const int ndiag = Gc - __builtin_amdgcn_readfirstlane(n_off);
             auto pull_item = [&]() -> int {
                 int pulled = 0;
                 if (lane == 0) pulled = __hip_atomic_fetch_add(s_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 return __builtin_amdgcn_readfirstlane(pulled);       // wave-uniform (SGPR) work item
             };
             for (int wq = pull_item(); wq < total; wq = pull_item()) {
-                if (wq >= npair) {
+                if (wq < nextra) {
                     // s1[a][0] = sum_p lb, s1[a][1+d] = sum_p lb nu_d  (fixed order)
-                    const int a = wq - npair;
+                    const int a = wq;
                     for (int dd = 0; dd <= D; ++dd) {
                         double v = 0.0;
                         if (dd == 0) { for (int pt = lane; pt < N; pt += 64) v += a_lb[a * N + pt]; }
@@ -1076,10 +1064,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     }
                     continue;
                 }
-                const int kq = p.magic_wpp ? (int)__umulhi((unsigned)wq, p.magic_wpp) : wq;   // wq / wpp (magic 0: wpp == 1)
-                const int slot = wq - kq * wpp;
-                const int gq = __builtin_amdgcn_readfirstlane(kq < ndiag ? s_off[G - 1 - kq] : s_off[kq - ndiag]);
-                const int wi = gq * wpp + slot;
+                const int wi = wq - nextra;
+                const int gq = p.magic_wpp ? (int)__umulhi((unsigned)wi, p.magic_wpp) : wi;   // wi / wpp (magic 0: wpp == 1)
+                const int slot = wi - gq * wpp;
                 const int a = __builtin_amdgcn_readfirstlane(s_pa[q0 + gq]);
                 const int b = __builtin_amdgcn_readfirstlane(s_pb[q0 + gq]);
                 const int Kraw = __builtin_amdgcn_readfirstlane(s_K[gq]);
@@ -1192,7 +1179,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                         double acc0, acc1;
                         if (K == 0) {
                             item_exp2<DP>(rec, nrows, w, w1, kbj, kb1, diag, Tp, N, c_exptab, acc0, acc1);
-                            acc = acc0 * (diag ? 2.0 : betas[b * N + j]) + (valid1 ? acc1 * (diag ? 2.0 : betas[b * N + j + 1]) : 0.0);
+                            acc = acc0 * (diag ? 2.0 : p.beta[b * N + j]) + (valid1 ? acc1 * (diag ? 2.0 : p.beta[b * N + j + 1]) : 0.0);
                         } else {
                             if (K <= 2) item_taylor2<DP, 2>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
                             else if (K == 3) item_taylor2<DP, 3>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
@@ -1208,7 +1195,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                         }
                     } else if (K == 0) {
                         acc = item_exp<DP>(rec, nrows, w, kbj, diag, Tp, N, c_exptab);
-                        acc *= diag ? 2.0 : betas[b * N + j];
+                        acc *= diag ? 2.0 : p.beta[b * N + j];
                     } else {
                         if (K <= 2) acc = item_taylor<DP, 2>(rec, nrows, w, diag, Tp, N);
                         else if (K == 3) acc = item_taylor<DP, 3>(rec, nrows, w, diag, Tp, N);
