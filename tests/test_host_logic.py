@@ -26,6 +26,39 @@ def test_library_exports_every_declared_symbol():
     assert os.path.basename(gp_mpc_amd.LIB_PATH) == "libgpmpc_hip.so"
 
 
+def test_header_is_plain_c_and_a_c_program_links_against_the_library(tmp_path):
+    """The boundary is a C ABI: include/gpmpc.h must compile as C99 (not only as C++), and a C program that takes the
+    address of every entry point must link against libgpmpc_hip.so and run (no GPU needed for gpmpc_abi_version)."""
+    import shutil
+    import subprocess
+    import gp_mpc_amd
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    header = open(os.path.join(ROOT, "include", "gpmpc.h")).read()
+    names = sorted(set(re.findall(r"\b(gpmpc_[a-z_]+)\s*\(", header)))
+    src = tmp_path / "consumer.c"
+    src.write_text(
+        '#include <stdio.h>\n#include "gpmpc.h"\n'
+        "typedef void (*entry_t)(void);\n"
+        "int main(void) {\n"
+        "    entry_t entry[] = {" + ", ".join(f"(entry_t){n}" for n in names) + "};\n"
+        "    unsigned i, n = 0;\n"
+        "    for (i = 0; i < sizeof entry / sizeof entry[0]; ++i) n += entry[i] != 0;\n"
+        '    printf("%u %d\\n", n, gpmpc_abi_version());\n'
+        "    return 0;\n}\n")
+    libdir = os.path.dirname(gp_mpc_amd.LIB_PATH)
+    exe = tmp_path / "consumer"
+    cmd = ["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe),
+           "-L", libdir, "-lgpmpc_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath-link,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    n, ver = r.stdout.split()
+    from gp_mpc_amd import _lib
+    assert int(n) == len(names) and int(ver) == _lib.ABI_VERSION
+
+
 def test_no_cpu_fallback_without_gpu():
     import gp_mpc_amd
     if torch.cuda.is_available():
