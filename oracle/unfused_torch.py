@@ -133,3 +133,31 @@ def time_rollouts(w, n_rollouts, factors=None):
             J.append(float(m.lcb(mus, Sigs, acts[i % B], target, W, W_T, w.kappa)))
         dt = time.perf_counter() - t0
     return n_rollouts / dt, dt, np.array(J)
+
+
+def time_gradients(w, n_evals, factors=None):
+    """Objective + gradient evaluations/s of the unfused CPU path: the reference's per-evaluation cost with
+    optimize=True (forward + autograd backward through predict_trajectory, gp_mpc_controller.py:268-285)."""
+    import time
+    import numpy as np
+    from .gpmpc_oracle import Factors
+    f = factors or Factors(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    m = UnfusedTorchModel(w.X, f.iK, f.beta, w.lengthscales, w.outputscales)
+    tt = lambda a: torch.as_tensor(np.asarray(a), dtype=torch.float64)  # noqa: E731
+    mu0, S0, target, W, W_T = tt(w.mu0), tt(w.S0), tt(w.target), tt(w.W), tt(w.W_T)
+    acts = tt(w.actions)
+    B = acts.shape[0]
+
+    def one(i):
+        a = acts[i % B].clone().requires_grad_(True)
+        mus, Sigs = m.predict_trajectory(a, mu0, S0, w.include_time, w.time0)
+        J = m.lcb(mus, Sigs, a, target, W, W_T, w.kappa)
+        (g,) = torch.autograd.grad(J, a)
+        return float(J.detach()), g
+
+    one(0)                                                                                 # warm-up
+    t0 = time.perf_counter()
+    for i in range(n_evals):
+        one(i)
+    dt = time.perf_counter() - t0
+    return n_evals / dt, dt
