@@ -285,3 +285,23 @@ def test_pending_best_combines_rank_records_like_the_reference_loop():
     host = torch.tensor([rec(float("inf"), -1, 0.0)], dtype=torch.float64).reshape(-1)
     with pytest.raises(FloatingPointError):
         PendingBest(host, None, 1, H, A).result()
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r01_c2_bench.json is the line bench.py printed on the MI355X: schema of the driver's contract."""
+    import json
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r01_c2_bench.json")).read().strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["metric"] == "MPC trajectory rollouts/sec" and d["dtype"] == "f64" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(d["value"] - d["config"]["B_total"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference")
