@@ -32,6 +32,27 @@ def rel_err(a, b):
     return float(np.max(np.abs(a - b)) / (den if den > 0 else 1.0))
 
 
+_REPORT = {}
+
+
+def record(test, **values):
+    """Keep the ACHIEVED error of a parity test (not just pass / fail): collected into gpurun_out/parity_report.json
+    at interpreter exit; the GPU run's copy is committed under profiles/."""
+    import atexit
+    import json
+    if not _REPORT:
+        def dump():
+            out = os.path.join(os.path.dirname(GOLDEN), "..", "gpurun_out")
+            try:
+                os.makedirs(out, exist_ok=True)
+                with open(os.path.join(out, "parity_report.json"), "w") as fh:
+                    json.dump(_REPORT, fh, indent=1, sort_keys=True)
+            except OSError:
+                pass
+        atexit.register(dump)
+    _REPORT.setdefault(test, {}).update({k: float(v) for k, v in values.items()})
+
+
 def make_controller(w, limit_action_change=False, optimize=False, restarts=1, clip=False, engine=None,
                     optimizer_params=None):
     """A GpMpcController of THIS package configured like the golden generator configured the

@@ -253,8 +253,24 @@ def factor_case(name, w):
 
 
 def main():
+    """`python tools/gen_golden.py` regenerates the round-1 set; `--only NAME [NAME ...]` regenerates just those
+    (the large ones -- traj_c4_n1000, optimize_trace_* -- are only made on request or with --all)."""
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", nargs="*", default=None)
+    ap.add_argument("--all", action="store_true")
+    args = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     mk = synth.make_workload
+    if args.only is not None or args.all:
+        big = {
+            # (iii') config 4 at its full memory size (the round-1 fixture stops at N = 600)
+            "traj_c4_n1000": lambda: traj_case("traj_c4_n1000", mk(1000, 4, 2, 30, 2, seed=29)),
+        }
+        for name in (args.only if args.only is not None else big):
+            big[name]()
+        if not args.all:
+            return
     # (i) factorisation
     factor_case("factor_n50", mk(50, 3, 1, 2, 1, seed=10))
     factor_case("factor_n96_d2", mk(96, 2, 1, 2, 1, seed=11))

@@ -1,23 +1,37 @@
 #!/usr/bin/env python3
-"""Config-5 scale fixture (N=4096, D=16, A=4): one moment-matched step for 2 candidates, computed by the
-CPU oracle (the reference formulation cannot run this size: its (D,D,N,N) temporaries are 34 GB each,
-SURVEY F7).  The oracle itself is pinned against reference-generated goldens at small N.
-Inputs are regenerated from the seed by oracle/synth.py; only expected outputs are stored."""
-import os, sys, time
+"""Config-5 scale fixtures (N=4096, D=16, A=4), computed by the CPU oracle (the reference formulation cannot run
+this size: its (D,D,N,N) temporaries are 34 GB each).  The oracle itself is pinned against
+reference-generated goldens at small N.  Inputs are regenerated from the seed by oracle/synth.py; only expected
+outputs are stored.
+
+  python tools/gen_golden_c5.py            one moment-matched step, 2 candidates  -> oracle_c5_step.npz   (~ minutes)
+  python tools/gen_golden_c5.py --steps 5  five horizon steps,     2 candidates  -> oracle_c5_traj.npz   (~ 5x that)
+"""
+import argparse
+import os
+import sys
+import time
+
 import numpy as np
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import synth
-from oracle import gpmpc_oracle as orc
+from oracle import synth  # noqa: E402
+from oracle import gpmpc_oracle as orc  # noqa: E402
 
-N, D, A, H, B, SEED = 4096, 16, 4, 1, 2, 77
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=1)
+args = ap.parse_args()
+N, D, A, H, B = 4096, 16, 4, args.steps, 2
+SEED = 77 if H == 1 else 78
+name = "oracle_c5_step.npz" if H == 1 else "oracle_c5_traj.npz"
 w = synth.make_workload(N, D, A, H, B, seed=SEED)
 t0 = time.time()
 f = orc.Factors(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
 print("factorised", time.time() - t0, flush=True)
 out = orc.evaluate_candidates(f, w)
 print("evaluated", time.time() - t0, flush=True)
-np.savez_compressed(os.path.join(ROOT, "tests", "golden", "oracle_c5_step.npz"),
+np.savez_compressed(os.path.join(ROOT, "tests", "golden", name),
                     N=N, D=D, A=A, H=H, B=B, seed=SEED, beta_head=f.beta[:, :64], mu=out["mu"], Sig=out["Sig"],
                     cost_mu=out["cost_mu"], cost_var=out["cost_var"], J=out["J"],
                     x_checksum=np.array([w.X.sum(), w.Y.sum(), w.actions.sum()]))
