@@ -10,12 +10,14 @@ ONE launch of the HIP rollout kernel:
 
   * optimize=False (random shooting, :142-144): all `restarts_optim` candidates at once, argmin on
     the device, candidates optionally sharded across GPUs (sharding.py);
-  * optimize=True (scipy L-BFGS-B with jac=True, :132-141): value + gradient per evaluation, the
-    gradient from a 4th-order central difference over the H*A model actions, i.e. 4*H*A + 1
-    candidates in one launch (the analytic adjoint kernel is SURVEY 8(f) row 1, not built yet).
-    The reference's two pass-through clamps (action clamp of DerivativeActionMapper, optional
-    clip of the UCB at 0) have identity backward; the finite difference is taken where those
-    clamps are transparent so the returned gradient has the same meaning.
+  * optimize=True (scipy L-BFGS-B with jac=True, :132-141): value + ANALYTIC gradient per evaluation
+    (gpmpc_rollout_grad: forward rollout + pairwise moment pass + reverse sweep, what the reference gets
+    from `mean_cost.backward()`, :277).  Shapes outside the gradient kernels (GPMPC_ERR_LIMIT) fall
+    back to a 4th-order central difference over the H*A model actions, 4*H*A + 1 candidates in one
+    launch -- in `compute_mean_lcb_trajectory` and in the batched `objective_and_gradient_batch` alike.
+    The reference's two pass-through clamps (action clamp of DerivativeActionMapper, optional clip of
+    the UCB at 0) have identity backward; the finite difference is taken where those clamps are
+    transparent so the returned gradient has the same meaning.
 """
 import multiprocessing
 
@@ -131,26 +133,37 @@ class GpMpcController(BaseControllerObject):
                 grad = self.actions_mapper.chain_grad_model_to_mpc(host["grad"][0].numpy())
                 self._cache_trajectory(host, 0)
                 return float(host["J"][0]), grad
-        cand = np.repeat(base[None], 4 * n + 1, axis=0)            # [base, +h, -h, +2h, -2h] per coordinate
-        flat = cand.reshape(4 * n + 1, n)
+        J, g_model, out = self._objective_and_gradient_by_differences(base[None], obs_mu, obs_var, trajectories=True)
+        grad = self.actions_mapper.chain_grad_model_to_mpc(g_model[0])
+        self._cache_trajectory(out, 0)
+        return float(J[0]), grad
+
+    def _objective_and_gradient_by_differences(self, bases, obs_mu, obs_var, trajectories=False):
+        """Fallback for shapes outside the gradient kernels (GPMPC_ERR_LIMIT): J and dJ/d(model actions) of `bases`
+        (C, H, A) from a 4th-order central difference of the rollout, all C * (4*H*A + 1) candidates in ONE launch
+        ([base, +h, -h, +2h, -2h] per coordinate; the base candidates come first, so out[...][c] is candidate c)."""
+        C, H, A = bases.shape
+        n = H * A
+        cand = np.empty((C, 4 * n + 1, n))
+        cand[:] = bases.reshape(C, 1, n)
         k = np.arange(n)
-        flat[1 + k, k] += FD_STEP
-        flat[1 + n + k, k] -= FD_STEP
-        flat[1 + 2 * n + k, k] += 2 * FD_STEP
-        flat[1 + 3 * n + k, k] -= 2 * FD_STEP
+        cand[:, 1 + k, k] += FD_STEP
+        cand[:, 1 + n + k, k] -= FD_STEP
+        cand[:, 1 + 2 * n + k, k] += 2 * FD_STEP
+        cand[:, 1 + 3 * n + k, k] -= 2 * FD_STEP
+        order = np.concatenate([np.arange(C) * (4 * n + 1)] + [c * (4 * n + 1) + 1 + np.arange(4 * n) for c in range(C)])
+        flat = cand.reshape(C * (4 * n + 1), H, A)[order]
         self.transition_model.set_cost(self.config.reward)
-        out = self.transition_model.predict_trajectory_batch(cand, obs_mu, obs_var, H, self.iter_ctrl,
-                                                             trajectories=True, stage_costs=True)
-        self.num_rollouts += cand.shape[0]
+        out = self.transition_model.predict_trajectory_batch(flat, obs_mu, obs_var, H, self.iter_ctrl,
+                                                             trajectories=trajectories, stage_costs=True)
+        self.num_rollouts += flat.shape[0]
         cm = out["cost_mu"].cpu().numpy()
         cv = out["cost_var"].cpu().numpy()
-        J_clip = out["J"].cpu().numpy()
+        J_clip = out["J"].cpu().numpy()[:C]
         J_free = np.mean(cm - self.config.reward.exploration_factor * np.sqrt(cv), axis=1)   # clamp transparent
-        g_model = (8.0 * (J_free[1:1 + n] - J_free[1 + n:1 + 2 * n])
-                   - (J_free[1 + 2 * n:1 + 3 * n] - J_free[1 + 3 * n:])) / (12.0 * FD_STEP)
-        grad = self.actions_mapper.chain_grad_model_to_mpc(g_model.reshape(H, A))
-        self._cache_trajectory(out, 0)
-        return float(J_clip[0]), grad
+        Jd = J_free[C:].reshape(C, 4, n)
+        g_model = (8.0 * (Jd[:, 0] - Jd[:, 1]) - (Jd[:, 2] - Jd[:, 3])) / (12.0 * FD_STEP)
+        return J_clip, g_model.reshape(C, H, A), out
 
     def compute_cost_unnormalized(self, obs, action, obs_var=None):
         """Reference :287-305: cost of an un-normalised (obs, action) pair -> (mean, variance)."""
@@ -183,10 +196,19 @@ class GpMpcController(BaseControllerObject):
     def check_and_close_processes(self):
         """Reference :216-227: collect finished training, load the new hyper-parameters, refactorise."""
         if hasattr(self, "p_train") and not self.p_train._closed and not self.p_train.is_alive():
-            params = self.queue_train.get()
+            # train() always queues exactly one result; a child that died before it could (killed, import error)
+            # must not block the control loop: wait briefly, then keep the current hyper-parameters
+            import queue as _queue
+            try:
+                params = self.queue_train.get(timeout=5.0 if self.p_train.exitcode == 0 else 0.5)
+            except _queue.Empty:
+                print(f"training process ended with exit code {self.p_train.exitcode} and no result: "
+                      "keeping the current hyper-parameters")
+                params = None
             self.p_train.join()
-            for model, p in zip(self.transition_model.models, params):
-                model.initialize(**p)
+            if params is not None:
+                for model, p in zip(self.transition_model.models, params):
+                    model.initialize(**p)
             self.p_train.close()
             x_mem, y_mem = self.memory.get()
             self.transition_model.prepare_inference(x_mem, y_mem)
@@ -205,6 +227,16 @@ class GpMpcController(BaseControllerObject):
         self.rewards_trajectory = -out["cost_mu"][idx].cpu()
         self.rewards_traj_var = out["cost_var"][idx].cpu()
         self.cost_traj_mean_lcb = -out["J"][idx].cpu()
+
+    def _cache_packed_trajectory(self, packed, H, D):
+        """The same caches from the [mu, Sig, cost_mu, cost_var, J] record another rank shipped (sharded shooting)."""
+        n1, n2, n3 = (H + 1) * D, (H + 1) * D * D, H + 1
+        o = np.cumsum([0, n1, n2, n3, n3])
+        self.states_mu_pred = packed[o[0]:o[1]].view(H + 1, D).clone()
+        self.states_var_pred = packed[o[1]:o[2]].view(H + 1, D, D).clone()
+        self.rewards_trajectory = -packed[o[2]:o[3]].clone()
+        self.rewards_traj_var = packed[o[3]:o[4]].clone()
+        self.cost_traj_mean_lcb = -packed[o[4]].clone()
 
     def _prepare(self):
         x_mem, y_mem = self.memory.get()
@@ -251,14 +283,27 @@ class GpMpcController(BaseControllerObject):
         B = cands.shape[0]
         world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
         rank = torch.distributed.get_rank() if world > 1 else 0
+        # Every rank draws the SAME B candidates (the reference's global numpy generator, seeded identically on all
+        # ranks by the launcher) and evaluates its contiguous slice; a rank whose slice is empty (B < world) launches
+        # nothing and contributes an (inf, -1) record.
         lo, hi = sharding.shard_bounds(B, world, rank)
-        out = self.evaluate_candidates(cands[lo:hi], state_mu, state_var, trajectories=True)
         eng = self.transition_model.engine
+        out = self.evaluate_candidates(cands[lo:hi], state_mu, state_var, trajectories=True) if hi > lo else None
         local = torch.as_tensor(cands[lo:hi].reshape(hi - lo, H, A), device=eng.device)
-        J, best, win = sharding.select_best_on_device(eng, out["J"], local, lo, B)
-        # the reference caches the LAST evaluated trajectory, not the winner's (:279-283)
-        if world == 1 or rank == world - 1:
-            self._cache_trajectory(out, hi - lo - 1)
+        if world == 1:
+            J, best, win = sharding.select_best_on_device(eng, out["J"], local, lo, B)
+            self._cache_trajectory(out, B - 1)       # the reference caches the LAST evaluated trajectory, not the winner's (:279-283)
+        else:
+            # ... and so must every rank here (get_action reads the caches on all of them): the owner of the last
+            # global candidate appends that trajectory to its record, so the step's whole exchange is ONE all_gather.
+            D = self.transition_model.dim_state
+            last_owner = sharding.owner_of(B - 1, B, world)
+            if rank == last_owner:
+                extra = torch.cat([out[k][-1].reshape(-1) for k in ("mu", "Sig", "cost_mu", "cost_var")] + [out["J"][-1:]])
+            else:
+                extra = torch.zeros((H + 1) * (D + D * D + 2) + 1, dtype=F64, device=eng.device)
+            J, best, win, extras = sharding.select_best_on_device(eng, None if out is None else out["J"], local, lo, B, extra=extra)
+            self._cache_packed_trajectory(extras[last_owner], H, D)
         self.best_candidate_index, self.best_candidate_J = best, J
         self.actions_mpc_previous_iter = win.numpy().reshape(-1).copy()
         return self.actions_mapper.transform_action_mpc_to_action_model(self.actions_mpc_previous_iter)
@@ -303,12 +348,19 @@ class GpMpcController(BaseControllerObject):
         X = np.asarray(actions_mpc_batch, dtype=np.float64)
         acts = self.actions_mapper.mpc_to_model_batch(X)
         self.transition_model.set_cost(self.config.reward)
-        out = self.transition_model.objective_and_gradient_batch(acts, obs_mu, obs_var, self.iter_ctrl)
-        self.num_rollouts += X.shape[0]
-        host = self.transition_model.engine.host_views(out)
-        J = host["J"].numpy()
-        G = self.actions_mapper.chain_grad_model_to_mpc_batch(host["grad"].numpy())
-        return J, G
+        if self.analytic_gradient:
+            try:
+                out = self.transition_model.objective_and_gradient_batch(acts, obs_mu, obs_var, self.iter_ctrl)
+            except GpmpcError as e:
+                if e.code != GPMPC_ERR_LIMIT:
+                    raise
+                self.analytic_gradient = False         # shape outside the gradient kernels: difference the rollout
+            else:
+                self.num_rollouts += X.shape[0]
+                host = self.transition_model.engine.host_views(out)
+                return host["J"].numpy(), self.actions_mapper.chain_grad_model_to_mpc_batch(host["grad"].numpy())
+        J, g_model, _ = self._objective_and_gradient_by_differences(acts, obs_mu, obs_var)
+        return J, self.actions_mapper.chain_grad_model_to_mpc_batch(g_model)
 
     def _batched_lbfgs_search(self, state_mu, state_var):
         """All restarts at once.  The reference runs `restarts_optim` scipy L-BFGS-B solves one after

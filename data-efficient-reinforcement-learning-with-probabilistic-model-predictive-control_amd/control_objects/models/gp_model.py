@@ -5,14 +5,14 @@ arithmetic runs in the HIP library (C ABI of include/gpmpc.h):
     predict_trajectory  -> gpmpc_rollout   (H-step moment matching;     reference :60-180)
 
 plus the batched entry points the reference lacks (`predict_trajectory_batch`,
-`evaluate_candidates`): B candidate action sequences per launch.
+`objective_and_gradient_batch`): B candidate action sequences per launch.
 
 No gpytorch: the three hyper-parameters the hot path reads (lengthscale (1,E), outputscale (),
 likelihood noise (1,), reference :189-190,427) live in small holder objects that keep the
 reference's attribute paths and its `initialize(**{...})` contract
 (controllers/gp_mpc_controller.py:223-224).  `train` (exact marginal likelihood, LBFGS, random
-re-initialisation inside the constraint box; reference :193-306) is host-side plain torch, off the
-hot path, and still runs in the spawned process the controller manages.
+re-initialisation inside the constraint box; reference :193-306) keeps the reference's optimiser loop in the
+spawned process the controller manages; its loss and gradient come from gpmpc_mll on the GPU.
 """
 import time
 from types import SimpleNamespace
@@ -164,26 +164,31 @@ class GpStateTransitionModel(AbstractStateTransitionModel):
         self.engine.prepare(inputs, state_changes, self.lengthscales, self.variances, self.noises)
 
     def set_cost(self, reward_config):
-        """Load the quadratic-cost / LCB settings into the engine (once per config)."""
-        key = (id(self), id(reward_config))
-        if self._cost_key == key and getattr(self.engine, "_cost_token", None) == key:
-            return
+        """Load the quadratic-cost / LCB settings into the engine.  The reference reads its reward config on every
+        evaluation (setpoint_distance_reward_mapper.py:36-66), so in-place edits of the config must take effect:
+        the (tiny) packed settings are compared by CONTENT with what this engine last received and re-sent when
+        they differ -- a few hundred bytes of host work per call, no launch."""
         smin = reward_config.state_min if reward_config.use_constraints else None
         smax = reward_config.state_max if reward_config.use_constraints else None
-        self.engine.set_cost(reward_config.target_state_action_norm.numpy(), reward_config.weight_matrix_cost.numpy(),
-                             reward_config.weight_matrix_cost_terminal.numpy(), float(reward_config.exploration_factor),
-                             bool(reward_config.clip_lower_bound_cost_to_0),
-                             None if smin is None else smin.numpy(), None if smax is None else smax.numpy())
+        args = (reward_config.target_state_action_norm.numpy(), reward_config.weight_matrix_cost.numpy(),
+                reward_config.weight_matrix_cost_terminal.numpy(), float(reward_config.exploration_factor),
+                bool(reward_config.clip_lower_bound_cost_to_0),
+                None if smin is None else smin.numpy(), None if smax is None else smax.numpy())
+        key = tuple(None if a is None else (np.asarray(a, dtype=np.float64).tobytes()) for a in args)
+        if getattr(self.engine, "_cost_token", None) == key:
+            self._cost_key = key
+            return
+        self.engine.set_cost(*args)
         self._cost_key = key
-        self.engine._cost_token = key          # engines can be shared between models: remember whose cost is loaded
+        self.engine._cost_token = key          # engines can be shared between models: remember WHAT is loaded
 
     # -- a3/a4 -------------------------------------------------------------------------
     def predict_trajectory_batch(self, actions, obs_mu, obs_var, len_horizon=None, current_time_idx=0,
                                  trajectories=True, stage_costs=True):
         """actions (B,H,A) -> dict of DEVICE tensors: J (B,), mu (B,H+1,D), Sig (B,H+1,D,D),
         cost_mu / cost_var (B,H+1).  Costs need set_cost() first."""
-        if self._cost_key is None:
-            raise RuntimeError("call set_cost(reward_config) before predicting")
+        if self._cost_key is None and stage_costs:
+            raise RuntimeError("call set_cost(reward_config) before predicting costs")
         actions = torch.as_tensor(np.asarray(actions) if not isinstance(actions, torch.Tensor) else actions, dtype=F64)
         if len_horizon is not None and actions.shape[1] != len_horizon:
             raise ValueError("actions.shape[1] != len_horizon")
@@ -218,75 +223,82 @@ class GpStateTransitionModel(AbstractStateTransitionModel):
 
     @staticmethod
     def train(queue, saved_state, lr_train, num_iter_train, clip_grad_value, print_train=False, step_print_train=25,
-              device="auto"):
+              device="auto", loss_evaluator=None):
         """Exact-MLL hyper-parameter search (reference :193-306), one GP at a time: random restart inside
         the constraint box, LBFGS(strong_wolfe), keep the best, never return something worse than the
         incoming parameters.  Runs in the spawned training process, fp64.  The loss and its gradient come from
-        gpmpc_mll (K build + Cholesky + inverse + gradient contraction on the GPU, an engine of this process's own)
-        when `device` is "hip", or "auto" with a GPU visible; "cpu" keeps the plain torch expression."""
+        gpmpc_mll (K build + Cholesky + inverse + gradient contraction on the GPU) through an engine of this
+        process's own; there is no CPU expression of the loss in this package.  `loss_evaluator(X, y, ls, os, nz)`
+        replaces it in tests (the oracle's torch expression, as the checker of the driver logic).
+
+        Whatever happens in here, exactly ONE list of parameter dicts is put on the queue -- the incoming
+        parameters when the engine cannot be created or nothing better was found -- so the controller's
+        check_and_close_processes never waits on a dead child."""
         t0 = time.time()
-        saved_state.to_tensors()
-        X, Y = saved_state.inputs, saved_state.states_change
-        cons = saved_state.constraints_hyperparams
-        N, E = X.shape
-        engine = None
-        if device == "hip" or (device == "auto" and torch.cuda.is_available()):
-            from ...engine import HipEngine
-            engine = HipEngine(0)
-            X_dev = torch.as_tensor(X, dtype=F64).to(engine.device).contiguous()
-        out = []
-        for a, p in enumerate(saved_state.parameters):
-            lo = {"ls": _t(cons["min_lengthscale"])[a], "os": _t(cons["min_outputscale"])[a],
-                  "nz": _t(cons["min_std_noise"])[a] ** 2}
-            hi = {"ls": _t(cons["max_lengthscale"])[a], "os": _t(cons["max_outputscale"])[a],
-                  "nz": _t(cons["max_std_noise"])[a] ** 2}
-            y = Y[:, a]
-
-            if engine is not None:
-                y_dev = torch.as_tensor(y, dtype=F64).reshape(N, 1).to(engine.device).contiguous()
-
-            def neg_mll(ls, osc, nz):
+        incoming = [{k: np.asarray(v).copy() for k, v in p.items()} for p in saved_state.parameters]
+        out, engine = None, None
+        try:
+            saved_state.to_tensors()
+            X, Y = saved_state.inputs, saved_state.states_change
+            cons = saved_state.constraints_hyperparams
+            N, E = X.shape
+            if loss_evaluator is None:
+                if device not in ("auto", "hip"):
+                    raise ValueError(f"training device {device!r}: the loss runs on the GPU only ('auto' or 'hip')")
+                from ...engine import HipEngine       # raises without a GPU / without the HIP library
+                engine = HipEngine(0)
+                X_dev = torch.as_tensor(X, dtype=F64).to(engine.device).contiguous()
+            out = []
+            for a, p in enumerate(saved_state.parameters):
+                lo = {"ls": _t(cons["min_lengthscale"])[a], "os": _t(cons["min_outputscale"])[a],
+                      "nz": _t(cons["min_std_noise"])[a] ** 2}
+                hi = {"ls": _t(cons["max_lengthscale"])[a], "os": _t(cons["max_outputscale"])[a],
+                      "nz": _t(cons["max_std_noise"])[a] ** 2}
+                y = Y[:, a]
                 if engine is not None:
-                    return _DeviceNegMll.apply(ls, osc, nz, engine, X_dev, y_dev)
-                d = (X[:, None, :] - X[None, :, :]) / ls
-                K = osc * torch.exp(-0.5 * (d * d).sum(-1)) + nz * torch.eye(N, dtype=F64)
-                L = torch.linalg.cholesky(K)
-                alpha = torch.cholesky_solve(y[:, None], L)[:, 0]
-                ll = -0.5 * (y @ alpha) - torch.log(torch.diagonal(L)).sum() - 0.5 * N * np.log(2 * np.pi)
-                return -ll / N
+                    y_dev = torch.as_tensor(y, dtype=F64).reshape(N, 1).to(engine.device).contiguous()
 
-            best = {"ls": p[GpHyperParameters.KEYS[0]].reshape(-1), "os": p[GpHyperParameters.KEYS[1]].reshape(()),
-                    "nz": p[GpHyperParameters.KEYS[2]].reshape(())}
-            try:
-                best_loss = float(neg_mll(best["ls"], best["os"], best["nz"]))
-            except Exception:
-                best_loss = float("inf")
-            raw = {k: torch.logit(torch.rand(best[k].shape, dtype=F64).clamp(1e-6, 1 - 1e-6)).requires_grad_(True)
-                   for k in ("ls", "os", "nz")}
+                def neg_mll(ls, osc, nz):
+                    if engine is not None:
+                        return _DeviceNegMll.apply(ls, osc, nz, engine, X_dev, y_dev)
+                    return loss_evaluator(X, y, ls, osc, nz)
 
-            def val(k):
-                return lo[k] + (hi[k] - lo[k]) * torch.sigmoid(raw[k])
-            opt = torch.optim.LBFGS(list(raw.values()), lr=lr_train, line_search_fn="strong_wolfe")
-            try:
-                for i in range(num_iter_train):
-                    def closure():
-                        opt.zero_grad()
-                        loss = neg_mll(val("ls"), val("os"), val("nz"))
-                        loss.backward()
-                        return loss
-                    loss = float(opt.step(closure))
-                    if print_train and i % step_print_train == 0:
-                        print(f"train gp {a} iter {i + 1}/{num_iter_train} loss {loss:.5f}")
-                    if loss < best_loss:
-                        best_loss = loss
-                        best = {k: val(k).detach().clone() for k in raw}
-            except Exception as e:         # keep the best found so far, like the reference (:289-290)
-                print(e)
-            out.append({GpHyperParameters.KEYS[0]: best["ls"].reshape(1, E).numpy(),
-                        GpHyperParameters.KEYS[1]: best["os"].reshape(()).numpy(),
-                        GpHyperParameters.KEYS[2]: best["nz"].reshape(1).numpy()})
-        if engine is not None:
-            engine.close()
-        if print_train:
-            print(f"training process: {time.time() - t0:.2f} s")
-        queue.put(out)
+                best = {"ls": p[GpHyperParameters.KEYS[0]].reshape(-1), "os": p[GpHyperParameters.KEYS[1]].reshape(()),
+                        "nz": p[GpHyperParameters.KEYS[2]].reshape(())}
+                try:
+                    best_loss = float(neg_mll(best["ls"], best["os"], best["nz"]))
+                except Exception:
+                    best_loss = float("inf")
+                raw = {k: torch.logit(torch.rand(best[k].shape, dtype=F64).clamp(1e-6, 1 - 1e-6)).requires_grad_(True)
+                       for k in ("ls", "os", "nz")}
+
+                def val(k):
+                    return lo[k] + (hi[k] - lo[k]) * torch.sigmoid(raw[k])
+                opt = torch.optim.LBFGS(list(raw.values()), lr=lr_train, line_search_fn="strong_wolfe")
+                try:
+                    for i in range(num_iter_train):
+                        def closure():
+                            opt.zero_grad()
+                            loss = neg_mll(val("ls"), val("os"), val("nz"))
+                            loss.backward()
+                            return loss
+                        loss = float(opt.step(closure))
+                        if print_train and i % step_print_train == 0:
+                            print(f"train gp {a} iter {i + 1}/{num_iter_train} loss {loss:.5f}")
+                        if loss < best_loss:
+                            best_loss = loss
+                            best = {k: val(k).detach().clone() for k in raw}
+                except Exception as e:         # keep the best found so far, like the reference (:289-290)
+                    print(e)
+                out.append({GpHyperParameters.KEYS[0]: best["ls"].reshape(1, E).numpy(),
+                            GpHyperParameters.KEYS[1]: best["os"].reshape(()).numpy(),
+                            GpHyperParameters.KEYS[2]: best["nz"].reshape(1).numpy()})
+            if print_train:
+                print(f"training process: {time.time() - t0:.2f} s")
+        except BaseException as e:
+            print(f"training process failed ({e!r}): keeping the incoming hyper-parameters")
+            out = None
+        finally:
+            if engine is not None:
+                engine.close()
+            queue.put(out if out is not None and len(out) == len(incoming) else incoming)

@@ -159,13 +159,13 @@ int gpmpc_set_cost(gpmpc_t* g, const double* target, const double* W, const doub
 }
 
 static int fill_args(gpmpc_t* g, RolloutArgs& a, const double* actions, const double* mu0, const double* S0,
-                     int B, int H, int A, int include_time, double time0) {
+                     int B, int H, int A, int include_time, double time0, bool need_cost = true) {
     Handle* h = H_(g);
     if (!h->ready) return bad(g, "rollout before prepare / set_factors");
     if (!actions || !mu0 || !S0) return bad(g, "null argument");
     if (B < 1 || H < 1 || A < 0) return bad(g, "need B >= 1, H >= 1");
     if (h->D + A + (include_time ? 1 : 0) != h->E) return bad(g, "D + A (+1 with time) must equal the model's input dim E");
-    if (h->cost_D != h->D || h->cost_A != A) return bad(g, "gpmpc_set_cost not called for this (D, A)");
+    if (need_cost && (h->cost_D != h->D || h->cost_A != A)) return bad(g, "gpmpc_set_cost not called for this (D, A)");
     memset(&a, 0, sizeof a);
     a.Xt = h->Xt.p; a.beta = h->beta.p; a.Tm = h->Tm.p; a.ils2 = h->ils2.p; a.var = h->var.p; a.logvar = h->logvar.p;
     a.cost = h->cost.p; a.kappa = h->kappa; a.clip = h->clip; a.use_constraints = h->use_constraints;
@@ -182,7 +182,8 @@ int gpmpc_rollout(gpmpc_t* g, const double* actions, const double* mu0, const do
                   double* J_out, void* stream) {
     if (!g) return GPMPC_ERR_ARG;
     RolloutArgs a;
-    int rc = fill_args(g, a, actions, mu0, S0, B, H, A, include_time, time0);
+    // the trajectory alone (predict_trajectory, gp_model.py:60-110) needs no cost settings
+    int rc = fill_args(g, a, actions, mu0, S0, B, H, A, include_time, time0, cm_out || cv_out || J_out);
     if (rc) return rc;
     GPMPC_HIP_CHECK(H_(g), hipSetDevice(g->h.device));
     a.mu_out = mu_out; a.Sig_out = Sig_out; a.cm_out = cm_out; a.cv_out = cv_out; a.J_out = J_out;

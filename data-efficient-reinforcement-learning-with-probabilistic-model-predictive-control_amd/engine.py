@@ -146,21 +146,23 @@ class HipEngine:
         mu0 = _host(mu0, (D,))
         S0 = _host(S0, (D, D))
         if out is None:
-            out = {"J": torch.empty(B, dtype=torch.float64, device=self.device)}
+            out = {}
+            if stage_costs or self._cost is not None:          # the objective needs gpmpc_set_cost; the trajectory does not
+                out["J"] = torch.empty(B, dtype=torch.float64, device=self.device)
             if trajectories:
                 out["mu"] = torch.empty((B, H + 1, D), dtype=torch.float64, device=self.device)
                 out["Sig"] = torch.empty((B, H + 1, D, D), dtype=torch.float64, device=self.device)
             if stage_costs:
                 out["cost_mu"] = torch.empty((B, H + 1), dtype=torch.float64, device=self.device)
                 out["cost_var"] = torch.empty((B, H + 1), dtype=torch.float64, device=self.device)
-        elif out["J"].shape != (B,) or ("mu" in out and out["mu"].shape != (B, H + 1, D)):
+        elif ("J" in out and out["J"].shape != (B,)) or ("mu" in out and out["mu"].shape != (B, H + 1, D)):
             raise ValueError("`out` does not match the batch shape")
 
         def ptr(k):
             return out[k].data_ptr() if k in out else None
         self._check(self.lib.gpmpc_rollout(self._h, actions.data_ptr(), _hp(mu0), _hp(S0), B, H, A, int(bool(include_time)),
                                            float(time0), ptr("mu"), ptr("Sig"), ptr("cost_mu"), ptr("cost_var"),
-                                           out["J"].data_ptr(), self._stream()))
+                                           ptr("J"), self._stream()))
         return out
 
     def rollout_grad(self, actions, mu0, S0, include_time=False, time0=0.0, trajectories=False):

@@ -83,6 +83,37 @@ def sharded_argmin(evaluate_slice, actions_local, lo, num_candidates, device, gr
     return J, i, win
 
 
+def _local_record(engine, J, actions_local, lo, out=None):
+    """Device record [best J, global index (-1: nothing selectable), winning (H*A) sequence] of this rank's slice.
+    An EMPTY slice (more ranks than candidates) launches nothing and contributes (inf, -1)."""
+    n, H, A = actions_local.shape
+    if n == 0:
+        rec = torch.zeros(2 + H * A, dtype=torch.float64, device=actions_local.device) if out is None else out.zero_()
+        rec[0], rec[1] = math.inf, -1.0
+        return rec
+    return engine.argmin_async(J, first_global_index=lo, actions=actions_local, out=out)     # one kernel: rule + gather
+
+
+def _gather_records(rec, group=None):
+    """(world, flat (world * len(rec)) tensor): ONE all_gather over RCCL (gloo in the CPU tests) when a process
+    group is initialised, otherwise the record itself."""
+    if dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        flat = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)
+        dist.all_gather_into_tensor(flat, rec.contiguous(), group=group)
+        return world, flat
+    return 1, rec
+
+
+def _winner_of(host, world, H, A):
+    """Cross-rank keep-the-best rule on the gathered host records (world, 2 + H*A [+ extra])."""
+    bJ, bi = combine_best([(float(host[r, 0]), int(host[r, 1])) for r in range(world)])
+    if bi < 0:
+        raise FloatingPointError("no selectable candidate (all objectives NaN)")
+    owner = [r for r in range(world) if int(host[r, 1]) == bi][0]
+    return bJ, bi, host[owner, 2:2 + H * A].view(H, A).clone()
+
+
 class PendingBest:
     """Winner selection in flight: the packed per-rank records are on their way to a pinned host buffer; `result()`
     waits for THAT copy only (an event), so the host can enqueue the next batch's launches before it looks at this
@@ -95,12 +126,7 @@ class PendingBest:
     def result(self):
         if self.event is not None:
             self.event.synchronize()
-        host = self.host.view(self.world, -1)
-        bJ, bi = combine_best([(float(host[r, 0]), int(host[r, 1])) for r in range(self.world)])
-        if bi < 0:
-            raise FloatingPointError("no selectable candidate (all objectives NaN)")
-        owner = [r for r in range(self.world) if int(host[r, 1]) == bi][0]
-        return bJ, bi, host[owner, 2:].view(self.H, self.A).clone()
+        return _winner_of(self.host.view(self.world, -1), self.world, self.H, self.A)
 
 
 def select_best_async(engine, J, actions_local, lo, num_candidates, group=None, host_buffer=None, record=None):
@@ -108,13 +134,8 @@ def select_best_async(engine, J, actions_local, lo, num_candidates, group=None, 
     of the packed records, an asynchronous copy into pinned host memory and an event.  `host_buffer` / `record`:
     reusable pinned / device buffers of a previous call with the same shapes.  Returns a PendingBest."""
     n, H, A = actions_local.shape
-    rec = engine.argmin_async(J, first_global_index=lo, actions=actions_local, out=record)
-    if dist.is_available() and dist.is_initialized():
-        world = dist.get_world_size(group)
-        flat = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)
-        dist.all_gather_into_tensor(flat, rec, group=group)
-    else:
-        world, flat = 1, rec
+    rec = _local_record(engine, J, actions_local, lo, out=record)
+    world, flat = _gather_records(rec, group)
     if rec.device.type != "cuda":
         return PendingBest(flat.clone(), None, world, H, A, rec)
     if host_buffer is None or host_buffer.numel() != flat.numel():
@@ -125,22 +146,23 @@ def select_best_async(engine, J, actions_local, lo, num_candidates, group=None, 
     return PendingBest(host_buffer, ev, world, H, A, rec)
 
 
-def select_best_on_device(engine, J, actions_local, lo, num_candidates, group=None):
+def select_best_on_device(engine, J, actions_local, lo, num_candidates, group=None, extra=None):
     """Device-resident variant of sharded_argmin for the HIP engine: local keep-the-best on the GPU
     (gpmpc_argmin_async), the record [J, global index, winning (H*A) sequence] packed on the device, ONE
     RCCL all_gather of 16 + 8*H*A bytes per rank, one device-to-host copy, the cross-rank rule applied on
-    the host.  Returns (best_J, best_index, best_actions (H, A) host tensor)."""
+    the host.  Returns (best_J, best_index, best_actions (H, A) host tensor).
+
+    `extra`: an optional 1-D device tensor every rank appends to its record (same length on every rank); the
+    gathered (world, len) host tensor is returned as a fourth value.  The controller ships the trajectory of the
+    LAST global candidate this way (what the reference leaves in its logging caches, gp_mpc_controller.py:279-283),
+    so the whole exchange of a control step stays one collective."""
     n, H, A = actions_local.shape
-    rec = engine.argmin_async(J, first_global_index=lo, actions=actions_local)     # one kernel: rule + gather
-    if dist.is_available() and dist.is_initialized():
-        world = dist.get_world_size(group)
-        flat = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)
-        dist.all_gather_into_tensor(flat, rec, group=group)
-    else:
-        world, flat = 1, rec
+    rec = _local_record(engine, J, actions_local, lo)
+    if extra is not None:
+        rec = torch.cat([rec, extra.to(rec.device, torch.float64).reshape(-1)])
+    world, flat = _gather_records(rec, group)
     host = flat.cpu().view(world, rec.numel())
-    bJ, bi = combine_best([(float(host[r, 0]), int(host[r, 1])) for r in range(world)])
-    if bi < 0:
-        raise FloatingPointError("no selectable candidate (all objectives NaN)")
-    owner = [r for r in range(world) if int(host[r, 1]) == bi][0]
-    return bJ, bi, host[owner, 2:].view(H, A).clone()
+    bJ, bi, win = _winner_of(host, world, H, A)
+    if extra is None:
+        return bJ, bi, win
+    return bJ, bi, win, host[:, 2 + H * A:].clone()

@@ -133,6 +133,8 @@ int gpmpc_set_cost(gpmpc_t* h, const double* target_host, const double* W_host,
  *   mu_out_dev (B,H+1,D)  Sig_out_dev (B,H+1,D,D)   index 0 = input state (gp_model.py:91-92)
  *   cost_mu_out_dev (B,H+1) = -rewards   cost_var_out_dev (B,H+1)
  *   J_out_dev (B) = mean-LCB objective the optimiser / argmin sees
+ * The three cost outputs need gpmpc_set_cost for this (D, A); with all three NULL the call is the
+ * plain predict_trajectory and needs no cost settings.
  */
 int gpmpc_rollout(gpmpc_t* h, const double* actions_dev, const double* mu0_host,
                   const double* S0_host, int B, int H, int A, int include_time, double time0,

@@ -180,6 +180,7 @@ def test_training_on_the_gpu_follows_the_cpu_expression():
     same LBFGS => the same hyper-parameters as with the plain torch expression, up to the fp64 agreement of the
     gradients (LBFGS amplifies 1e-8 differences over its iterations: 1e-4 relative on the result)."""
     import queue
+    from oracle.gp_training import neg_mll_torch
     from gp_mpc_amd.control_objects.models.gp_model import GpStateTransitionModel, SavedState, GpHyperParameters
     rng = np.random.default_rng(0)
     X = rng.uniform(size=(60, 3))
@@ -194,7 +195,7 @@ def test_training_on_the_gpu_follows_the_cpu_expression():
         st.to_arrays()
         q = queue.Queue()
         torch.manual_seed(0)
-        GpStateTransitionModel.train(q, st, 1e-1, 8, 1e-3, device=dev)
+        GpStateTransitionModel.train(q, st, 1e-1, 8, 1e-3, device="hip", loss_evaluator=neg_mll_torch if dev == "cpu" else None)
         res[dev] = q.get()
     for a in range(2):
         for k in res["cpu"][a]:

@@ -181,8 +181,10 @@ def test_hyperparameter_holder_contract():
 
 
 def test_training_improves_marginal_likelihood_cpu():
-    """GpStateTransitionModel.train is host-side torch: can run here."""
+    """The optimiser loop of GpStateTransitionModel.train (restart inside the box, LBFGS, keep the best) with the
+    oracle's torch expression standing in for gpmpc_mll (the product evaluates the loss on the GPU only)."""
     import queue
+    from oracle.gp_training import neg_mll_torch
     from gp_mpc_amd.control_objects.models.gp_model import GpStateTransitionModel, SavedState, GpHyperParameters
     rng = np.random.default_rng(0)
     X = rng.uniform(size=(40, 2))
@@ -194,10 +196,55 @@ def test_training_improves_marginal_likelihood_cpu():
     st.to_arrays()
     q = queue.Queue()
     torch.manual_seed(0)
-    GpStateTransitionModel.train(q, st, 1e-1, 10, 1e-3)
+    GpStateTransitionModel.train(q, st, 1e-1, 10, 1e-3, loss_evaluator=neg_mll_torch)
     (out,) = q.get()
     assert out["covar_module.base_kernel.lengthscale"].shape == (1, 2) and out["likelihood.noise"].shape == (1,)
     assert 4e-3 <= out["covar_module.base_kernel.lengthscale"].min() and out["likelihood.noise"][0] <= 0.09 + 1e-12
+
+
+def test_training_always_answers_the_queue():
+    """a training child that cannot create its engine (no GPU here) must still put exactly one result --
+    the incoming hyper-parameters -- on the queue, so check_and_close_processes never blocks on a dead child."""
+    import queue
+    from gp_mpc_amd.control_objects.models.gp_model import GpStateTransitionModel, SavedState, GpHyperParameters
+    p0 = GpHyperParameters([0.7, 0.8], 0.05, 1e-4).state_dict()
+    st = SavedState(np.zeros((5, 2)), np.zeros((5, 1)), [p0],
+                    {"min_lengthscale": np.full((1, 2), 4e-3), "max_lengthscale": np.full((1, 2), 10.0),
+                     "min_outputscale": np.array([1e-3]), "max_outputscale": np.array([0.95]),
+                     "min_std_noise": np.array([1e-3]), "max_std_noise": np.array([3e-1])})
+    st.to_arrays()
+    for dev in ("hip", "cpu"):                 # no GPU in this container / a device the product does not have
+        q = queue.Queue()
+        GpStateTransitionModel.train(q, st, 1e-1, 3, 1e-3, device=dev)
+        (out,) = q.get_nowait()
+        assert np.array_equal(out["covar_module.base_kernel.lengthscale"], np.asarray(p0["covar_module.base_kernel.lengthscale"]))
+        assert q.empty()
+
+
+def test_set_cost_follows_in_place_edits_of_the_reward_config():
+    """the reference reads its reward config on every evaluation; the engine's copy is keyed on content."""
+    from gp_mpc_amd.control_objects.models.gp_model import GpStateTransitionModel
+    from gp_mpc_amd.config_classes import ModelConfig, RewardConfig
+
+    class Eng:
+        def __init__(self):
+            self.sent = []
+
+        def set_cost(self, *a):
+            self.sent.append(a)
+    eng = Eng()
+    m = GpStateTransitionModel(ModelConfig(), 3, 1, engine=eng)
+    rc = RewardConfig(target_state_norm=[0.5] * 3, weight_state=[1.0] * 3, weight_state_terminal=[1.0] * 3,
+                      target_action_norm=[0.5], weight_action=[0.1])
+    m.set_cost(rc)
+    m.set_cost(rc)
+    assert len(eng.sent) == 1
+    rc.exploration_factor = 2.5
+    m.set_cost(rc)
+    assert len(eng.sent) == 2 and eng.sent[-1][3] == 2.5
+    rc.target_state_action_norm[0] = 0.25
+    m.set_cost(rc)
+    assert len(eng.sent) == 3
 
 
 def test_lockstep_restarts_drive_scipy_exactly_like_the_sequential_loop():

@@ -87,3 +87,115 @@ def test_combine_best_rules():
     assert i == 0 and J != J
     assert combine_best([(float("inf"), -1), (2.0, 9)]) == (2.0, 9)
     assert combine_best([(float("inf"), -1)])[1] == -1
+
+
+# ------------------------------------------------------------------- the code path that ships (missing 2)
+def _shipping_worker(rank, world, port, mode, B, ret):
+    """select_best_async / select_best_on_device (what bench.py and the controller call) with >1 rank."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from gp_mpc_amd import sharding
+        from oracle import gpmpc_oracle as orc
+        from stub_engine import OracleEngine
+        rng = np.random.default_rng(17)
+        H, A = 4, 2
+        acts_all = rng.uniform(size=(B, H, A))
+        J_all = rng.uniform(size=B)
+        if mode == "nan0":
+            J_all[0] = np.nan
+        elif mode == "nan_mid" and B > 2:
+            J_all[int(np.argmin(J_all))] = np.nan
+        elif mode == "tie" and B > 8:
+            J_all[7] = J_all[2] = J_all.min() - 1.0
+        want = orc.first_wins_argmin(J_all)
+        lo, hi = sharding.shard_bounds(B, world, rank)
+        eng = OracleEngine()
+        acts = torch.as_tensor(acts_all[lo:hi])
+        J = torch.as_tensor(J_all[lo:hi])
+        ok = True
+        for variant in ("blocking", "async", "async_reuse", "extra"):
+            if variant == "blocking":
+                bJ, bi, win = sharding.select_best_on_device(eng, J, acts, lo, B)
+            elif variant == "extra":
+                payload = torch.full((5,), float(rank))
+                bJ, bi, win, extras = sharding.select_best_on_device(eng, J, acts, lo, B, extra=payload)
+                ok = ok and extras.shape == (world, 5) and all(float(extras[r, 0]) == r for r in range(world))
+            else:
+                pend = sharding.select_best_async(eng, J, acts, lo, B)
+                if variant == "async_reuse":
+                    pend = sharding.select_best_async(eng, J, acts, lo, B, host_buffer=pend.host, record=pend.record)
+                bJ, bi, win = pend.result()
+            ok = ok and bi == want and np.array_equal(win.numpy(), acts_all[want])
+            ok = ok and (np.isnan(bJ) if np.isnan(J_all[want]) else bJ == J_all[want])
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B", [(2, 11), (3, 11), (2, 1), (3, 2)])
+@pytest.mark.parametrize("mode", ["plain", "nan0", "nan_mid", "tie"])
+def test_shipping_selection_paths_with_several_ranks(world, B, mode):
+    """B < world leaves ranks with an EMPTY slice: they launch nothing and contribute (inf, -1)."""
+    port = 31500 + (os.getpid() + world * 13 + B * 3 + len(mode)) % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_shipping_worker, args=(world, port, mode, B, ret), nprocs=world, join=True)
+    assert all(ret.get(r) for r in range(world)), dict(ret)
+
+
+def _controller_step(restarts, seed):
+    """One get_action of a GpMpcController (random shooting) on the stub engine; returns what a caller can see."""
+    from helpers import make_controller
+    from oracle import synth
+    from stub_engine import OracleEngine
+    w = synth.make_workload(N=30, D=3, A=1, H=4, B=1, seed=3)
+    eng = OracleEngine()
+    c = make_controller(w, optimize=False, restarts=restarts, engine=eng)
+    np.random.seed(seed)                       # the reference's global generator: every rank seeds it identically
+    out = []
+    for step in range(2):                      # second step exercises init_from_previous_actions
+        a = c.get_action(w.mu0)
+        info = c.get_iter_info()
+        out.append(dict(action=np.asarray(a), best=int(c.best_candidate_index), J=float(c.best_candidate_J),
+                        prev=c.actions_mpc_previous_iter.copy(),
+                        states=np.asarray(info.predicted_states), std=np.asarray(info.predicted_states_std),
+                        costs=np.asarray(info.predicted_costs), lcb=float(info.lower_bound_mean_predicted_cost),
+                        launches=eng.launches))
+    return out
+
+
+def _controller_worker(rank, world, port, restarts, seed, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = _controller_step(restarts, seed)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,restarts", [(2, 5), (2, 1), (3, 4)])
+def test_controller_random_shooting_sharded_over_ranks(world, restarts):
+    """GpMpcController.get_action with torch.distributed initialised: every rank returns the
+    action, winner and logging caches (IterationInformation) of the single-process run -- including ranks that do
+    not own the last candidate and ranks whose slice is empty (restarts < world)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    want = _controller_step(restarts, seed=5)
+    port = 33500 + (os.getpid() + world * 17 + restarts) % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_controller_worker, args=(world, port, restarts, 5, ret), nprocs=world, join=True)
+    for r in range(world):
+        got = ret[r]
+        for step, (g, e) in enumerate(zip(got, want)):
+            assert g["best"] == e["best"] and g["J"] == e["J"], (r, step)
+            for k in ("action", "prev", "states", "std", "costs"):
+                assert np.array_equal(g[k], e[k]), (r, step, k)
+            assert g["lcb"] == e["lcb"]
+    lo_hi = [(__import__("gp_mpc_amd").sharding.shard_bounds(restarts, world, r)) for r in range(world)]
+    for r, (lo, hi) in enumerate(lo_hi):          # a rank with an empty slice never launched
+        assert (ret[r][0]["launches"] > 0) == (hi > lo)

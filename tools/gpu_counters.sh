@@ -1,0 +1,27 @@
+#!/bin/bash
+# rocprofv3 kernel trace + PMC passes (each counter group in its own run, no trace domains mixed in) of one bench
+# workload; summaries -> gpurun_out/<tag>_*.txt, per-launch averages merged into profiles/pmc_counters.json and
+# profiles/pmc_traffic.json under the key bench.py looks up.
+#   tools/gpu_counters.sh <tag> <key> <kernel-name-substring> <bench args...>
+#   e.g. tools/gpu_counters.sh r02_c2 c2:N200:B256 rollout_kernel --workload c2
+TAG=$1; KEY=$2; KSUB=$3; shift 3
+REPO=$PWD
+OUT=$REPO/gpurun_out
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+B="python $REPO/bench.py --no-cpu-baseline $@"
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- $B --steps 20 --warmup 3 > $OUT/${TAG}_trace.log 2>&1
+DBS=""
+for grp in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS" \
+           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA"; do
+  name=$(echo $grp | cut -d' ' -f1)
+  timeout 300 rocprofv3 --pmc $grp -d $OUT/${TAG}_pmc_$name -o bench -- $B --steps 3 --warmup 1 > $OUT/${TAG}_pmc_$name.log 2>&1
+  DBS="$DBS $OUT/${TAG}_pmc_$name/bench_results.db"
+done
+cd $REPO
+python tools/rocpd_summary.py trace $OUT/${TAG}_trace/bench_results.db > $OUT/${TAG}_kernel_trace_stats.txt
+python tools/rocpd_summary.py pmc $DBS > $OUT/${TAG}_pmc.txt
+python tools/rocpd_summary.py json $KEY $KSUB $DBS | cut -c1-300
+cp profiles/pmc_counters.json profiles/pmc_traffic.json $OUT/
+head -6 $OUT/${TAG}_kernel_trace_stats.txt | cut -c1-150

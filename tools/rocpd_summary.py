@@ -4,6 +4,7 @@
 
   python tools/rocpd_summary.py trace gpurun_out/prof_trace/bench_results.db
   python tools/rocpd_summary.py pmc   gpurun_out/prof_pmc_fetch/bench_results.db [...]
+  python tools/rocpd_summary.py json  c2:N200:B256 rollout_kernel <pmc dbs...>   (merge into profiles/pmc_*.json)
 """
 import sqlite3
 import sys
@@ -44,8 +45,47 @@ def pmc(paths):
             print(f"{kname[:70]:70s} {cname:22s} {len(vals):10d} {sum(vals)/len(vals):18.2f} {max(vals):16.2f}")
 
 
+def merge_json(key, kernel_substr, paths):
+    """Average per-dispatch counter values of the kernels whose name contains `kernel_substr` -> merged into
+    profiles/pmc_counters.json[key] (all counters) and profiles/pmc_traffic.json[key] (HBM bytes per launch =
+    (2 x FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE under-counts by 2, MI355X_MICROARCH.md HBM section)."""
+    import json
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    vals = {}
+    for path in paths:
+        cur = sqlite3.connect(path).cursor()
+        acc = defaultdict(lambda: defaultdict(float))
+        for kname, disp, cname, val in cur.execute(
+                "select kernel_name, dispatch_id, counter_name, value from counters_collection"):
+            if kernel_substr in kname:
+                acc[cname][disp] += val
+        for cname, d in acc.items():
+            # the largest launches only: warm-up / timing launches of other batch sizes share the kernel name
+            v = sorted(d.values())
+            top = [x for x in v if x >= 0.5 * v[-1]] if v[-1] > 0 else v
+            vals[cname] = sum(top) / len(top)
+    if not vals:
+        raise SystemExit(f"no dispatch of a kernel matching {kernel_substr!r}")
+
+    def update(fname, value):
+        fp = os.path.join(root, fname)
+        try:
+            cur = json.load(open(fp))
+        except Exception:
+            cur = {}
+        cur[key] = value
+        json.dump(cur, open(fp, "w"), indent=1, sort_keys=True)
+    update("pmc_counters.json", vals)
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        update("pmc_traffic.json", int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024))
+    print(key, vals)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
         trace(sys.argv[2])
+    elif sys.argv[1] == "json":
+        merge_json(sys.argv[2], sys.argv[3], sys.argv[4:])
     else:
         pmc(sys.argv[2:])
