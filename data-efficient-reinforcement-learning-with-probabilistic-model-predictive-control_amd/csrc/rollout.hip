@@ -253,7 +253,8 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     }
     if (gs) {
         // large-N variant (rollout_stream_kernel.h): column factors + a double-buffered 64-row stage in LDS
-        CH = (N >= 64) ? 64 : ((N + 3) & ~3);
+        // (matrix-core pair pass, DP = 8 / 16: always four 16-row tiles per chunk; rows past the data are zero records)
+        CH = (N >= 64 || (DP % 4 == 0 && DP >= 8)) ? 64 : ((N + 3) & ~3);
         RC = (N + CH - 1) / CH;
         G = 1;
         StreamLayout SL = make_stream_layout(N, D, A, E, DP, CH, a.H * A);

@@ -12,10 +12,107 @@
 //     accumulator across all row chunks, so a pair costs a single wavefront reduction.
 // Row operands are therefore LDS broadcasts exactly as in the LDS-resident kernel (the first round-1
 // version of this variant re-read the records from L2 for every wave and ran ~7x off its VALU bound).
+//
+// Pairwise pass on the fp64 matrix cores (DP = 8, 16).  At D = 16 a row record is 18 doubles; broadcasting it from LDS to every
+// wave for every row (the layout of the LDS-resident kernel) made the round-1 version of this kernel LDS-bound at 0.3 of its
+// VALU roofline.  The exponent's bilinear part  c_ij = g_i . w_j  (inner dimension D) is GEMM-shaped at this size: a
+// 16 x 16 tile of c is DP/4 v_mfma_f64_16x16x4_f64 -- A operand g_i straight from the LDS stage (one conflict-free
+// ds_read_b64 per MFMA: lane l reads component 4q + (l >> 4) of row l & 15; record stride DP + 2 doubles puts the 16 rows
+// on distinct bank quadruples), B operand w_j in registers for all row tiles of the chunk.  The matrix pipe then carries
+// the D multiply-adds per element and the VALU only the degree-K polynomial and the weighting of the 4 results per lane,
+// the two pipes running side by side.  A wave owns 16-column blocks cb = wave, wave + 16, ...; lanes (l & 15) = column,
+// (l >> 4) + 4r = row inside the tile (C/D layout of the f64 MFMA); summation order is fixed (bitwise reproducible).
 #pragma once
 #include "rollout_kernel.h"
 
 namespace gpmpc_hip {
+
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+
+// c tiles of TWO 16-row tiles (rows 16 t0 .., 16 t0 + 16 ..) of the stage against the wave's 16 columns.
+template <int DP>
+__device__ inline void mfma_c_tiles(const double* st, int t0, const double (&bw)[DP / 4], int lane, mfma_d4& c0, mfma_d4& c1) {
+    constexpr int RS = DP + 2;
+    const double* a0p = st + (size_t)(16 * t0 + (lane & 15)) * RS + 2 + (lane >> 4);
+    const double* a1p = a0p + 16 * RS;
+    double a0[DP / 4], a1[DP / 4];
+#pragma unroll
+    for (int q = 0; q < DP / 4; ++q) { a0[q] = a0p[4 * q]; a1[q] = a1p[4 * q]; }
+    c0 = {0.0, 0.0, 0.0, 0.0};
+    c1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < DP / 4; ++q) {
+        c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[q], bw[q], c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[q], bw[q], c1, 0, 0, 0);
+    }
+}
+
+// Taylor form of one (row chunk, 16-column block) item: ntiles 16-row tiles (processed two at a time; a tile past `ntiles`
+// only meets zero weights: zero padding records or the zero lower triangle of T).
+//   diagonal pair : sum_i T[i][j] ea_i P_K(c_ij)       off-diagonal : sum_i ra_i P_K(c_ij)
+// Tp = &T_a[chunk row 0 + (lane >> 4)][j] for this lane's column.
+template <int DP, int K>
+__device__ inline double block_mfma_taylor(const double* st, int ntiles, const double (&bw)[DP / 4], bool diag, const double* Tp,
+                                           int N, int lane) {
+    constexpr int RS = DP + 2;
+    double acc = 0.0;
+    const double* wrow = st + (size_t)(lane >> 4) * RS;
+    for (int t = 0; t < ntiles; t += 2) {
+        double wv0[4], wv1[4];
+        if (diag) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                wv0[r] = Tp[(size_t)(16 * t + 4 * r) * N];
+                wv1[r] = Tp[(size_t)(16 * t + 16 + 4 * r) * N];
+            }
+        }
+        mfma_d4 c0, c1;
+        mfma_c_tiles<DP>(st, t, bw, lane, c0, c1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double* w0 = wrow + (size_t)(16 * t + 4 * r) * RS;
+            const double* w1 = w0 + 16 * RS;
+            if (diag) { wv0[r] *= w0[0]; wv1[r] *= w1[0]; } else { wv0[r] = w0[1]; wv1[r] = w1[1]; }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc = fma(taylor_exp<K>(c0[r]), wv0[r], acc);
+            acc = fma(taylor_exp<K>(c1[r]), wv1[r], acc);
+        }
+    }
+    return acc;
+}
+
+// Direct form exp(ka'_i + kb'_j + c_ij) of the same item (record [0] = ka'_i, [1] = beta_ai).
+template <int DP>
+__device__ inline double block_mfma_exp(const double* st, int ntiles, const double (&bw)[DP / 4], double kbj, bool diag,
+                                        const double* Tp, int N, int lane, const double* tab) {
+    constexpr int RS = DP + 2;
+    double acc = 0.0;
+    const double* wrow = st + (size_t)(lane >> 4) * RS;
+    for (int t = 0; t < ntiles; t += 2) {
+        double wv0[4], wv1[4];
+        if (diag) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                wv0[r] = Tp[(size_t)(16 * t + 4 * r) * N];
+                wv1[r] = Tp[(size_t)(16 * t + 16 + 4 * r) * N];
+            }
+        }
+        mfma_d4 c0, c1;
+        mfma_c_tiles<DP>(st, t, bw, lane, c0, c1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double* w0 = wrow + (size_t)(16 * t + 4 * r) * RS;
+            const double* w1 = w0 + 16 * RS;
+            const double e0 = fast_exp(w0[0] + kbj + c0[r], tab);
+            const double e1 = fast_exp(w1[0] + kbj + c1[r], tab);
+            acc = fma(e0, diag ? wv0[r] : w0[1], acc);
+            acc = fma(e1, diag ? wv1[r] : w1[1], acc);
+        }
+    }
+    return acc;
+}
 
 struct StreamLayout {
     int mu, Sig, m, M, cc, s1, Vs, Sp, aug, red, kb, stage, ints;
@@ -38,7 +135,7 @@ __host__ __device__ inline StreamLayout make_stream_layout(int N, int D, int A, 
     L.aug = o;      o += 2 * D * D;
     L.red = o;      o += rnd2(16 * (DP + 1));
     L.kb = o;       o += rnd2(N);
-    L.stage = o;    o += 2 * CH * (DP + 2);
+    L.stage = o;    o += 2 * (CH + 16) * (DP + 2);      // + 16 rows: the matrix-core items take row tiles two at a time
     L.ints = o;     o += 4;
     L.c_ils2 = o;   o += rnd2(D * E);
     L.c_logvar = o; o += rnd2(D);
@@ -57,6 +154,8 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
     constexpr int RS = DP + 2;
     constexpr int DPC = DP <= 2 ? 2 : (DP <= 4 ? 4 : (DP <= 8 ? 8 : 16));     // lanes that share one row record
     static_assert(NT == 1024, "stage fill maps 64 rows x 16 components onto 1024 threads");
+    constexpr bool kMfma = (DP % 4 == 0) && DP >= 8;          // pairwise pass on the fp64 matrix cores
+    const int SSTR = (p.CH + 16) * RS;                        // doubles per stage buffer
     const int tid0 = threadIdx.x;
     const int c = blockIdx.x;
     const int D = p.D, N = p.N, A = p.A, E = p.E, H = p.H, CH = p.CH;
@@ -290,10 +389,48 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
 
                 double acc = 0.0;
                 for (int r = 0; r < RC; ++r) {
-                    if (r + 1 < RC) fill_stage(r + 1, s_stage + ((r + 1) & 1) * CH * RS);
-                    const double* rec = s_stage + (r & 1) * CH * RS;
+                    if (r + 1 < RC) fill_stage(r + 1, s_stage + ((r + 1) & 1) * SSTR);
+                    const double* rec = s_stage + (r & 1) * SSTR;
                     int nch = N - r * CH;
                     if (nch > CH) nch = CH;
+                    if constexpr (kMfma) {
+                        const int tiles_in_chunk = (nch + 15) >> 4;             // rows past the data are zero records
+                        const int NCB16 = (N + 15) >> 4;
+                        for (int cb = wave; cb < NCB16; cb += NW) {
+                            const int j0 = cb * 16;
+                            if (diag && j0 + 15 < r * CH) continue;             // T is zero below its diagonal
+                            int ntiles = tiles_in_chunk;
+                            if (diag) { const int lim = (j0 + 16 - r * CH + 15) >> 4; if (lim < ntiles) ntiles = lim; }
+                            const int j = j0 + (lane & 15);
+                            const bool valid = j < N;
+                            const int jc = valid ? j : N - 1;
+                            double bw[DP / 4];
+#pragma unroll
+                            for (int qq = 0; qq < DP / 4; ++qq) {
+                                const int k = 4 * qq + (lane >> 4);
+                                bw[qq] = (k < D) ? (p.Xt[(size_t)k * N + jc] - s_m[k]) * c_ils2[b * E + k] : 0.0;
+                            }
+                            const double kbj = s_kb[jc];
+                            const double* Tp = p.Tm + ((size_t)a * (N + kTPad) + (size_t)r * CH + (lane >> 4)) * N + jc;
+                            double v;
+                            if (K == 0) {
+                                v = block_mfma_exp<DP>(rec, ntiles, bw, kbj, diag, Tp, N, lane, c_exptab);
+                                v *= diag ? 2.0 : p.beta[(size_t)b * N + jc];
+                            } else {
+                                if (K <= 2) v = block_mfma_taylor<DP, 2>(rec, ntiles, bw, diag, Tp, N, lane);
+                                else if (K <= 4) v = block_mfma_taylor<DP, 4>(rec, ntiles, bw, diag, Tp, N, lane);
+                                else if (K <= 6) v = block_mfma_taylor<DP, 6>(rec, ntiles, bw, diag, Tp, N, lane);
+                                else if (K <= 8) v = block_mfma_taylor<DP, 8>(rec, ntiles, bw, diag, Tp, N, lane);
+                                else if (K <= 10) v = block_mfma_taylor<DP, 10>(rec, ntiles, bw, diag, Tp, N, lane);
+                                else if (K <= 12) v = block_mfma_taylor<DP, 12>(rec, ntiles, bw, diag, Tp, N, lane);
+                                else v = block_mfma_taylor<DP, 14>(rec, ntiles, bw, diag, Tp, N, lane);
+                                v *= diag ? 2.0 * kbj : kbj;
+                            }
+                            acc += valid ? v : 0.0;
+                        }
+                        __syncthreads();
+                        continue;
+                    }
                     nch = (nch + 3) & ~3;                                   // rows past the data are zero records
                     for (int cb = wave; cb < NCB; cb += NW) {
                         const int j0 = cb * 64;
