@@ -253,8 +253,15 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     }
     if (gs) {
         // large-N variant (rollout_stream_kernel.h): column factors + a double-buffered 64-row stage in LDS
-        // (matrix-core pair pass, DP = 8 / 16: always four 16-row tiles per chunk; rows past the data are zero records)
-        CH = (N >= 64 || (DP % 4 == 0 && DP >= 8)) ? 64 : ((N + 3) & ~3);
+        // matrix-core pair pass (DP = 8 / 16): chunks of 64 / 128 / 256 rows = 4 / 8 / 16 row tiles per (chunk, 16-column
+        // block) item -- an item's set-up (column operands, addresses) is ~100 instructions and one L2 round trip, so long
+        // items matter; rows past the data are zero records.  Option "rows_per_chunk" overrides (tests, A/B).
+        if (DP % 4 == 0 && DP >= 8) {
+            CH = (N >= 1024) ? 256 : 64;
+            if (h->opt_rows_per_chunk > 0) CH = h->opt_rows_per_chunk <= 64 ? 64 : (h->opt_rows_per_chunk <= 128 ? 128 : 256);
+        } else {
+            CH = (N >= 64) ? 64 : ((N + 3) & ~3);
+        }
         RC = (N + CH - 1) / CH;
         G = 1;
         StreamLayout SL = make_stream_layout(N, D, A, E, DP, CH, a.H * A);

@@ -27,6 +27,58 @@
 
 namespace gpmpc_hip {
 
+// Gaussian elimination with partial pivoting on [A | RHS] in LDS (row stride ld) by ONE wavefront: same algorithm and pivot
+// rule as gauss_solve (first largest |entry| of the column), the D - 1 - k by D + nrhs - 1 - k trailing elements of a step
+// spread over the 64 lanes, the back substitution one right-hand side per lane.  A single thread doing this on a 16 x 32
+// block took ~0.7 M cycles (dependent LDS round trips) -- 152 of them were 100 ms of a config-5 horizon step.
+// Returns det(A) on every lane.  Call from one whole wavefront; ends with the LDS writes visible to that wavefront.
+__device__ inline double wave_gauss_solve(double* aug, int D, int nrhs, int ld, int lane) {
+    double det = 1.0;
+    const int nc = D + nrhs;
+    for (int k = 0; k < D; ++k) {
+        double best = (lane >= k && lane < D) ? fabs(aug[lane * ld + k]) : -1.0;
+        int piv = lane;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const double ob = __shfl_xor(best, off, 64);
+            const int op = __shfl_xor(piv, off, 64);
+            if (ob > best || (ob == best && op < piv)) { best = ob; piv = op; }
+        }
+        piv = __builtin_amdgcn_readfirstlane(piv);
+        if (piv != k) {
+            for (int c = lane; c < nc; c += kWave) {
+                const double t = aug[k * ld + c];
+                aug[k * ld + c] = aug[piv * ld + c];
+                aug[piv * ld + c] = t;
+            }
+            det = -det;
+            wave_lds_sync();
+        }
+        const double pv = aug[k * ld + k];
+        det *= pv;
+        const double ip = 1.0 / pv;
+        const int ncols = nc - 1 - k;
+        const int total = (D - 1 - k) * ncols;
+        for (int idx = lane; idx < total; idx += kWave) {
+            const int rr = idx / ncols;
+            const int r = k + 1 + rr, c = k + 1 + (idx - rr * ncols);
+            const double f = aug[r * ld + k] * ip;
+            aug[r * ld + c] -= f * aug[k * ld + c];
+        }
+        wave_lds_sync();
+    }
+    if (lane < nrhs) {
+        const int c = D + lane;
+        for (int k = D - 1; k >= 0; --k) {
+            double sacc = aug[k * ld + c];
+            for (int r = k + 1; r < D; ++r) sacc -= aug[k * ld + r] * aug[r * ld + c];
+            aug[k * ld + c] = sacc / aug[k * ld + k];
+        }
+    }
+    wave_lds_sync();
+    return det;
+}
+
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
 // c tiles of TWO 16-row tiles (rows 16 t0 .., 16 t0 + 16 ..) of the stage against the wave's 16 columns.
@@ -51,19 +103,21 @@ __device__ inline void mfma_c_tiles(const double* st, int t0, const double (&bw)
 // only meets zero weights: zero padding records or the zero lower triangle of T).
 //   diagonal pair : sum_i T[i][j] ea_i P_K(c_ij)       off-diagonal : sum_i ra_i P_K(c_ij)
 // Tp = &T_a[chunk row 0 + (lane >> 4)][j] for this lane's column.
-template <int DP, int K>
-__device__ inline double block_mfma_taylor(const double* st, int ntiles, const double (&bw)[DP / 4], bool diag, const double* Tp,
-                                           int N, int lane) {
+// The 8 polynomials of an iteration are evaluated as 8 INTERLEAVED Horner chains and summed into 4 accumulators: a dependent
+// v_fma_f64 issues only every ~40 cycles, so 8 serial chains of K + 1 links (what the compiler makes of the obvious loop,
+// to save registers) cost 8 (K + 1) x 40 cycles per iteration against 512 cycles of matrix-core work.
+template <int DP, int K, bool DIAG>
+__device__ inline double block_mfma_taylor(const double* st, int ntiles, const double (&bw)[DP / 4], const double* Tp, int N, int lane) {
     constexpr int RS = DP + 2;
-    double acc = 0.0;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const double* wrow = st + (size_t)(lane >> 4) * RS;
     for (int t = 0; t < ntiles; t += 2) {
-        double wv0[4], wv1[4];
-        if (diag) {
+        double wt[8];
+        if (DIAG) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                wv0[r] = Tp[(size_t)(16 * t + 4 * r) * N];
-                wv1[r] = Tp[(size_t)(16 * t + 16 + 4 * r) * N];
+                wt[r] = Tp[(size_t)(16 * t + 4 * r) * N];
+                wt[4 + r] = Tp[(size_t)(16 * t + 16 + 4 * r) * N];
             }
         }
         mfma_d4 c0, c1;
@@ -72,46 +126,55 @@ __device__ inline double block_mfma_taylor(const double* st, int ntiles, const d
         for (int r = 0; r < 4; ++r) {
             const double* w0 = wrow + (size_t)(16 * t + 4 * r) * RS;
             const double* w1 = w0 + 16 * RS;
-            if (diag) { wv0[r] *= w0[0]; wv1[r] *= w1[0]; } else { wv0[r] = w0[1]; wv1[r] = w1[1]; }
+            if (DIAG) { wt[r] *= w0[0]; wt[4 + r] *= w1[0]; } else { wt[r] = w0[1]; wt[4 + r] = w1[1]; }
+        }
+        double cv[8], pv[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { cv[r] = c0[r]; cv[4 + r] = c1[r]; }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pv[e] = kInvFact[K];
+#pragma unroll
+        for (int k = K - 1; k >= 0; --k) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = fma(pv[e], cv[e], kInvFact[k]);
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc = fma(taylor_exp<K>(c0[r]), wv0[r], acc);
-            acc = fma(taylor_exp<K>(c1[r]), wv1[r], acc);
-        }
+        for (int e = 0; e < 8; ++e) acc[e & 3] = fma(pv[e], wt[e], acc[e & 3]);
     }
-    return acc;
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
 // Direct form exp(ka'_i + kb'_j + c_ij) of the same item (record [0] = ka'_i, [1] = beta_ai).
-template <int DP>
-__device__ inline double block_mfma_exp(const double* st, int ntiles, const double (&bw)[DP / 4], double kbj, bool diag,
-                                        const double* Tp, int N, int lane, const double* tab) {
+template <int DP, bool DIAG>
+__device__ inline double block_mfma_exp(const double* st, int ntiles, const double (&bw)[DP / 4], double kbj, const double* Tp, int N,
+                                        int lane, const double* tab) {
     constexpr int RS = DP + 2;
-    double acc = 0.0;
+    double acc[2] = {0.0, 0.0};
     const double* wrow = st + (size_t)(lane >> 4) * RS;
     for (int t = 0; t < ntiles; t += 2) {
-        double wv0[4], wv1[4];
-        if (diag) {
+        double wt[8];
+        if (DIAG) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                wv0[r] = Tp[(size_t)(16 * t + 4 * r) * N];
-                wv1[r] = Tp[(size_t)(16 * t + 16 + 4 * r) * N];
+                wt[r] = Tp[(size_t)(16 * t + 4 * r) * N];
+                wt[4 + r] = Tp[(size_t)(16 * t + 16 + 4 * r) * N];
             }
         }
         mfma_d4 c0, c1;
         mfma_c_tiles<DP>(st, t, bw, lane, c0, c1);
+        double arg[8];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const double* w0 = wrow + (size_t)(16 * t + 4 * r) * RS;
             const double* w1 = w0 + 16 * RS;
-            const double e0 = fast_exp(w0[0] + kbj + c0[r], tab);
-            const double e1 = fast_exp(w1[0] + kbj + c1[r], tab);
-            acc = fma(e0, diag ? wv0[r] : w0[1], acc);
-            acc = fma(e1, diag ? wv1[r] : w1[1], acc);
+            arg[r] = w0[0] + kbj + c0[r];
+            arg[4 + r] = w1[0] + kbj + c1[r];
+            if (!DIAG) { wt[r] = w0[1]; wt[4 + r] = w1[1]; }
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e & 1] = fma(fast_exp(arg[e], tab), wt[e], acc[e & 1]);
     }
-    return acc;
+    return acc[0] + acc[1];
 }
 
 struct StreamLayout {
@@ -219,18 +282,17 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
 
         // ---- mean part: M_a, V_a for one output dimension at a time (gp_model.py:140-153) -------------------
         for (int a = 0; a < D; ++a) {
-            if (tid == 0) {
+            if (wave == 0) {
                 double prodil = 1.0;
-                for (int i = 0; i < D; ++i) {
-                    const double il2 = c_ils2[a * E + i];
-                    prodil *= il2;
-                    for (int j = 0; j < D; ++j) {
-                        s_aug[i * LD + j] = s_Sig[i * D + j] + (i == j ? 1.0 / il2 : 0.0);
-                        s_aug[i * LD + D + j] = (i == j ? 1.0 : 0.0);
-                    }
+                for (int i = 0; i < D; ++i) prodil *= c_ils2[a * E + i];
+                for (int idx = lane; idx < D * D; idx += kWave) {
+                    const int i = idx / D, j = idx - i * D;
+                    s_aug[i * LD + j] = s_Sig[idx] + (i == j ? 1.0 / c_ils2[a * E + i] : 0.0);
+                    s_aug[i * LD + D + j] = (i == j ? 1.0 : 0.0);
                 }
-                const double detA = gauss_solve(s_aug, D, D, LD);
-                s_cc[a] = c_var[a] / sqrt(detA * prodil);
+                wave_lds_sync();
+                const double detA = wave_gauss_solve(s_aug, D, D, LD, lane);
+                if (lane == 0) s_cc[a] = c_var[a] / sqrt(detA * prodil);
             }
             __syncthreads();
             double acc[DP + 1];
@@ -287,32 +349,35 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
         for (int a = 0; a < D; ++a) {
             for (int b = a; b < D; ++b, ++q) {
                 const bool diag = (a == b);
-                if (tid == 0) {
-                    for (int i = 0; i < D; ++i)
-                        for (int j = 0; j < D; ++j) {
-                            const double dab = c_ils2[a * E + j] + c_ils2[b * E + j];
-                            s_aug[i * LD + j] = s_Sig[i * D + j] * dab + (i == j ? 1.0 : 0.0);
-                            s_aug[i * LD + D + j] = s_Sig[i * D + j];
-                        }
-                    const double detR = gauss_solve(s_aug, D, D, LD);
-                    s_rdet[0] = 1.0 / sqrt(detR);
+                if (wave == 0) {
+                    for (int idx = lane; idx < D * D; idx += kWave) {
+                        const int i = idx / D, j = idx - i * D;
+                        const double dab = c_ils2[a * E + j] + c_ils2[b * E + j];
+                        s_aug[i * LD + j] = s_Sig[idx] * dab + (i == j ? 1.0 : 0.0);
+                        s_aug[i * LD + D + j] = s_Sig[idx];
+                    }
+                    wave_lds_sync();
+                    const double detR = wave_gauss_solve(s_aug, D, D, LD, lane);
                     const double* Z = s_aug + D;
-                    double cmax = 0.0;
-                    for (int i = 0; i < D; ++i) {
-                        const double mi = s_mu[i];
+                    // |g_i . w_j| <= cmax = sum_dd' |Z_dd'| umax_d wmax_d' over the data range of the memory points
+                    double cpart = 0.0;
+                    for (int idx = lane; idx < D * D; idx += kWave) {
+                        const int i = idx / D, j = idx - i * D;
+                        const double mi = s_mu[i], mj = s_mu[j];
                         const double ui = fmax(fabs(c_xr[i] - mi), fabs(c_xr[E + i] - mi)) * c_ils2[a * E + i];
-                        for (int j = 0; j < D; ++j) {
-                            const double mj = s_mu[j];
-                            const double wj = fmax(fabs(c_xr[j] - mj), fabs(c_xr[E + j] - mj)) * c_ils2[b * E + j];
-                            cmax = fma(fabs(Z[i * LD + j]) * ui, wj, cmax);
+                        const double wj = fmax(fabs(c_xr[j] - mj), fabs(c_xr[E + j] - mj)) * c_ils2[b * E + j];
+                        cpart = fma(fabs(Z[i * LD + j]) * ui, wj, cpart);
+                    }
+                    const double cmax = wave_sum(cpart);
+                    if (lane == 0) {
+                        s_rdet[0] = 1.0 / sqrt(detR);
+                        int K = 0;
+                        if (p.force_path != 1 && cmax <= kTaylorMaxArg[kMaxTaylor]) {
+                            K = 1;
+                            for (int k = 1; k < kMaxTaylor; ++k) K += (cmax > kTaylorMaxArg[k]) ? 1 : 0;
                         }
+                        s_int[0] = K;
                     }
-                    int K = 0;
-                    if (p.force_path != 1 && cmax <= kTaylorMaxArg[kMaxTaylor]) {
-                        K = 1;
-                        for (int k = 1; k < kMaxTaylor; ++k) K += (cmax > kTaylorMaxArg[k]) ? 1 : 0;
-                    }
-                    s_int[0] = K;
                 }
                 __syncthreads();
                 const int K = __builtin_amdgcn_readfirstlane(s_int[0]);
@@ -322,15 +387,25 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
                 for (int j = tid; j < N; j += NT) {
                     double w[DP];
                     double ks = 0.0;
+                    double xv[DP];
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) xv[d] = p.Xt[(size_t)(d < D ? d : D - 1) * N + j];      // independent loads
+                    double xe[8];
+                    const int ne = E - D;                                                               // <= 8 action / time inputs
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) xe[e] = p.Xt[(size_t)(e < ne ? D + e : D) * N + j];
 #pragma unroll
                     for (int d = 0; d < DP; ++d) {
-                        const double nu = (d < D) ? (p.Xt[(size_t)d * N + j] - s_m[d]) : 0.0;
+                        const double nu = (d < D) ? (xv[d] - s_m[d]) : 0.0;
                         w[d] = (d < D) ? nu * c_ils2[b * E + d] : 0.0;
                         ks = fma(nu, w[d], ks);
                     }
-                    for (int e = D; e < E; ++e) {
-                        const double v = p.Xt[(size_t)e * N + j] - s_m[e];
-                        ks = fma(v * v, c_ils2[b * E + e], ks);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        if (e < ne) {
+                            const double v = xe[e] - s_m[D + e];
+                            ks = fma(v * v, c_ils2[b * E + D + e], ks);
+                        }
                     }
                     double qb = 0.0;
 #pragma unroll
@@ -349,21 +424,35 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
 
                 // row records of one chunk -> LDS stage; DPC lanes share a row (lane group = one record)
                 auto fill_stage = [&](int r, double* stage) {
-                    const int trow = tid / DPC, comp = tid - trow * DPC;
-                    if (trow < CH) {
+                  const int comp = tid % DPC;
+                  for (int trow = tid / DPC; trow < CH; trow += NT / DPC) {
+                    {
                         const int i = r * CH + trow;
                         double gcomp = 0.0, part = 0.0, ks = 0.0;
                         if (i < N) {
-                            for (int d = 0; d < D; ++d) {
-                                const double nu = p.Xt[(size_t)d * N + i] - s_m[d];
-                                const double u = nu * c_ils2[a * E + d];
-                                ks = fma(nu, u, ks);
-                                if (comp < D) gcomp = fma(Z[d * LD + comp], u, gcomp);      // g = Z^T u
-                                if (d == comp) part = u;
+                            double xv[DP];
+#pragma unroll
+                            for (int d = 0; d < DP; ++d) xv[d] = p.Xt[(size_t)(d < D ? d : D - 1) * N + i];      // independent loads
+                            double xe[8];
+                            const int ne = E - D;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) xe[e] = p.Xt[(size_t)(e < ne ? D + e : D) * N + i];
+#pragma unroll
+                            for (int d = 0; d < DP; ++d) {
+                                if (d < D) {
+                                    const double nu = xv[d] - s_m[d];
+                                    const double u = nu * c_ils2[a * E + d];
+                                    ks = fma(nu, u, ks);
+                                    if (comp < D) gcomp = fma(Z[d * LD + comp], u, gcomp);      // g = Z^T u
+                                    if (d == comp) part = u;
+                                }
                             }
-                            for (int e = D; e < E; ++e) {
-                                const double v = p.Xt[(size_t)e * N + i] - s_m[e];
-                                ks = fma(v * v, c_ils2[a * E + e], ks);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) {
+                                if (e < ne) {
+                                    const double v = xe[e] - s_m[D + e];
+                                    ks = fma(v * v, c_ils2[a * E + D + e], ks);
+                                }
                             }
                             part *= gcomp;                                                   // u_comp g_comp
                         }
@@ -383,6 +472,7 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
                             rec[1] = r1;
                         }
                     }
+                  }
                 };
                 fill_stage(0, s_stage);
                 __syncthreads();
@@ -396,37 +486,56 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
                     if constexpr (kMfma) {
                         const int tiles_in_chunk = (nch + 15) >> 4;             // rows past the data are zero records
                         const int NCB16 = (N + 15) >> 4;
-                        for (int cb = wave; cb < NCB16; cb += NW) {
+                        // column operands of an item (B operand w_j, column factor): loaded one item ahead, so that their L2
+                        // latency is covered by the previous item's matrix-core work
+                        auto col_operands = [&](int cb, double (&bwv)[DP / 4], double& kbv) {
+                            int j = cb * 16 + (lane & 15);
+                            if (j >= N) j = N - 1;
+#pragma unroll
+                            for (int qq = 0; qq < DP / 4; ++qq) {
+                                const int k = 4 * qq + (lane >> 4);
+                                const double x = p.Xt[(size_t)(k < D ? k : D - 1) * N + j];
+                                bwv[qq] = (k < D) ? (x - s_m[k < D ? k : 0]) * c_ils2[b * E + (k < D ? k : 0)] : 0.0;
+                            }
+                            kbv = s_kb[j];
+                        };
+                        int cb = wave;
+                        if (diag) { const int first = (r * CH) >> 4; cb += ((first - wave + NW - 1) / NW) * NW; if (cb < wave) cb = wave; }
+                        double bw[DP / 4], kbj;
+                        if (cb < NCB16) col_operands(cb, bw, kbj);
+                        for (; cb < NCB16; cb += NW) {
+                            double bwn[DP / 4], kbn;
+                            const int cbn = (cb + NW < NCB16) ? cb + NW : cb;
+                            col_operands(cbn, bwn, kbn);
                             const int j0 = cb * 16;
-                            if (diag && j0 + 15 < r * CH) continue;             // T is zero below its diagonal
                             int ntiles = tiles_in_chunk;
                             if (diag) { const int lim = (j0 + 16 - r * CH + 15) >> 4; if (lim < ntiles) ntiles = lim; }
                             const int j = j0 + (lane & 15);
                             const bool valid = j < N;
                             const int jc = valid ? j : N - 1;
-                            double bw[DP / 4];
-#pragma unroll
-                            for (int qq = 0; qq < DP / 4; ++qq) {
-                                const int k = 4 * qq + (lane >> 4);
-                                bw[qq] = (k < D) ? (p.Xt[(size_t)k * N + jc] - s_m[k]) * c_ils2[b * E + k] : 0.0;
-                            }
-                            const double kbj = s_kb[jc];
                             const double* Tp = p.Tm + ((size_t)a * (N + kTPad) + (size_t)r * CH + (lane >> 4)) * N + jc;
                             double v;
                             if (K == 0) {
-                                v = block_mfma_exp<DP>(rec, ntiles, bw, kbj, diag, Tp, N, lane, c_exptab);
+                                v = diag ? block_mfma_exp<DP, true>(rec, ntiles, bw, kbj, Tp, N, lane, c_exptab)
+                                         : block_mfma_exp<DP, false>(rec, ntiles, bw, kbj, Tp, N, lane, c_exptab);
                                 v *= diag ? 2.0 : p.beta[(size_t)b * N + jc];
                             } else {
-                                if (K <= 2) v = block_mfma_taylor<DP, 2>(rec, ntiles, bw, diag, Tp, N, lane);
-                                else if (K <= 4) v = block_mfma_taylor<DP, 4>(rec, ntiles, bw, diag, Tp, N, lane);
-                                else if (K <= 6) v = block_mfma_taylor<DP, 6>(rec, ntiles, bw, diag, Tp, N, lane);
-                                else if (K <= 8) v = block_mfma_taylor<DP, 8>(rec, ntiles, bw, diag, Tp, N, lane);
-                                else if (K <= 10) v = block_mfma_taylor<DP, 10>(rec, ntiles, bw, diag, Tp, N, lane);
-                                else if (K <= 12) v = block_mfma_taylor<DP, 12>(rec, ntiles, bw, diag, Tp, N, lane);
-                                else v = block_mfma_taylor<DP, 14>(rec, ntiles, bw, diag, Tp, N, lane);
+#define GPMPC_TAYLOR_BLOCK(KK) (diag ? block_mfma_taylor<DP, KK, true>(rec, ntiles, bw, Tp, N, lane) \
+                                     : block_mfma_taylor<DP, KK, false>(rec, ntiles, bw, Tp, N, lane))
+                                if (K <= 2) v = GPMPC_TAYLOR_BLOCK(2);
+                                else if (K <= 4) v = GPMPC_TAYLOR_BLOCK(4);
+                                else if (K <= 6) v = GPMPC_TAYLOR_BLOCK(6);
+                                else if (K <= 8) v = GPMPC_TAYLOR_BLOCK(8);
+                                else if (K <= 10) v = GPMPC_TAYLOR_BLOCK(10);
+                                else if (K <= 12) v = GPMPC_TAYLOR_BLOCK(12);
+                                else v = GPMPC_TAYLOR_BLOCK(14);
+#undef GPMPC_TAYLOR_BLOCK
                                 v *= diag ? 2.0 * kbj : kbj;
                             }
                             acc += valid ? v : 0.0;
+#pragma unroll
+                            for (int qq = 0; qq < DP / 4; ++qq) bw[qq] = bwn[qq];
+                            kbj = kbn;
                         }
                         __syncthreads();
                         continue;

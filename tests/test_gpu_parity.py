@@ -394,6 +394,43 @@ def test_padded_and_odd_shapes_against_oracle(engine, N, D, A, H, B, tm):
         assert rel_err(out["J"].cpu().numpy(), ref["J"]) < 1e-8, force_path
 
 
+@pytest.mark.parametrize("N,D,A,H,B,tm,s0", [(33, 8, 2, 3, 3, False, 1e-6), (100, 7, 1, 2, 2, True, 1e-3), (130, 12, 3, 2, 2, False, 1e-4),
+                                            (17, 16, 4, 3, 2, False, 5e-2), (257, 16, 2, 2, 3, False, 1e-6), (64, 9, 1, 2, 1, False, 1e-2)])
+def test_matrix_core_pair_pass_against_oracle(engine, N, D, A, H, B, tm, s0):
+    """The streaming kernel's pairwise pass on the fp64 matrix cores (padded state dimension 8 or 16; config 5's path),
+    forced at small N: ragged N (not a multiple of 16 / 64, N < 16), D below the padded size, time input, input
+    variances that select low and high Taylor degrees and the direct-exp form, each in all three evaluation modes."""
+    w = synth.make_workload(N, D, A, H, B, include_time=tm, seed=300 + N, s0=s0, noise_var=1e-4, time0=float(N) if tm else 0.0)
+    f = factors_of(w)
+    ref = orc.evaluate_candidates(f, w)
+    engine.set_option("force_global_scratch", 1)
+    try:
+        engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+        _set_cost(engine, w)
+        for force_path in (0, 1, 2):
+            engine.set_option("force_path", force_path)
+            out = engine.rollout(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+            tag = (N, D, force_path)
+            e_S = np.max(np.abs(out["Sig"].cpu().numpy() - ref["Sig"]))
+            record(f"matrix_core_pair_pass[N{N},D{D},path{force_path}]", mu=rel_err(out["mu"].cpu().numpy(), ref["mu"]),
+                   Sig_abs=e_S, J=rel_err(out["J"].cpu().numpy(), ref["J"]))
+            assert rel_err(out["mu"].cpu().numpy(), ref["mu"]) < 1e-9, tag
+            assert e_S < 1e-7 * np.max(np.abs(ref["Sig"])) + 2e-11, (tag, e_S)
+            assert rel_err(out["J"].cpu().numpy(), ref["J"]) < 1e-8, tag
+        again = engine.rollout(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+        assert np.array_equal(again["Sig"].cpu().numpy(), out["Sig"].cpu().numpy())          # fixed summation order
+        for rows in (128, 256):              # the long row chunks used from N = 1024 up (8 / 16 row tiles per item)
+            engine.set_option("rows_per_chunk", rows)
+            engine.set_option("force_path", 0)
+            big = engine.rollout(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+            assert rel_err(big["mu"].cpu().numpy(), ref["mu"]) < 1e-9, rows
+            assert np.max(np.abs(big["Sig"].cpu().numpy() - ref["Sig"])) < 1e-7 * np.max(np.abs(ref["Sig"])) + 2e-11, rows
+    finally:
+        engine.set_option("rows_per_chunk", 0)
+        engine.set_option("force_path", 0)
+        engine.set_option("force_global_scratch", 0)
+
+
 def test_config5_full_size_step_against_oracle_fixture(engine):
     """BASELINE configs[4] at full size (N=4096, D=16, A=4, E=20): K build + factorisation + one
     moment-matched step for 2 candidates vs tests/golden/oracle_c5_step.npz (CPU oracle, tools/gen_golden_c5.py;

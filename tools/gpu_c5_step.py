@@ -1,12 +1,19 @@
-import sys, os, time
+"""Time one launch of the streaming rollout kernel at config-5 class shapes (D = 16, A = 4, B = 256 = one workgroup per CU).
+  python tools/gpu_c5_step.py [N:H[:s0] ...]      default: 1024:1 2048:1 4096:1 4096:2   (s0: initial state variance, 1e-6)"""
+import os
+import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np, torch
 import gp_mpc_amd
 from oracle import synth
+
+shapes = [tuple(float(v) for v in a.split(":")) for a in sys.argv[1:]] or [(1024, 1), (2048, 1), (4096, 1), (4096, 2)]
 eng = gp_mpc_amd.HipEngine(0)
-for (N, D, A, H, B) in [(1024, 16, 4, 1, 256), (2048, 16, 4, 1, 256), (4096, 16, 4, 1, 256), (4096, 16, 4, 2, 256)]:
-    w = synth.make_workload(N, D, A, H, B, seed=0)
+for sh in shapes:
+    N, H = int(sh[0]), int(sh[1])
+    s0 = sh[2] if len(sh) > 2 else 1e-6
+    D, A, B = 16, 4, 256
+    w = synth.make_workload(N, D, A, H, B, seed=0, s0=s0)
     eng.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
     eng.set_cost(w.target, w.W, w.W_T, w.kappa)
     ms, J = eng.rollout_timed(w.actions, w.mu0, w.S0, 1)
-    print(f"N={N} D={D} H={H} B={B}: {ms:.1f} ms/launch = {ms/H:.1f} ms per horizon step of 256 candidates; J[0]={float(J[0]):.6g}", flush=True)
+    print(f"N={N} D={D} H={H} B={B} s0={s0:g}: {ms:.1f} ms/launch = {ms/H:.1f} ms per horizon step of 256 candidates; J[0]={float(J[0]):.6g}", flush=True)

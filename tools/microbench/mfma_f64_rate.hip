@@ -42,6 +42,57 @@ __global__ void fma_kernel(double* out, int iters, long long* cyc) {
     if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
 }
 
+// Do the fp64 matrix pipe and the fp64 vector ALU run side by side?  Every wave issues, per loop iteration, ONE
+// v_mfma_f64_16x16x4_f64 (64 cycles of matrix pipe) and NF independent v_fma_f64 (4 cycles of vector ALU each).
+// Overlap: max(64, 4 NF) cycles per iteration per SIMD; one shared fp64 datapath: 64 + 4 NF.
+template <int NF>
+__global__ void mix_kernel(double* out, int iters, long long* cyc) {
+    d4 macc[2];
+    macc[0] = {0.0, 0.0, 0.0, 0.0};
+    macc[1] = {0.0, 0.0, 0.0, 0.0};
+    double facc[NF > 0 ? NF : 1];
+    for (int c = 0; c < NF; ++c) facc[c] = c;
+    double a = threadIdx.x * 1e-3, b = 1.0 + threadIdx.x * 1e-4, fa = 1.0 + threadIdx.x * 1e-9;
+    __syncthreads();
+    long long t0 = __builtin_readcyclecounter();
+    for (int i = 0; i < iters; i += 2) {
+        macc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, macc[0], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NF; ++c) facc[c] = fma(facc[c], fa, b);
+        macc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, macc[1], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NF; ++c) facc[c] = fma(facc[c], fa, b);
+    }
+    __syncthreads();
+    long long t1 = __builtin_readcyclecounter();
+    double s = macc[0][0] + macc[0][1] + macc[0][2] + macc[0][3] + macc[1][0] + macc[1][1] + macc[1][2] + macc[1][3];
+    for (int c = 0; c < NF; ++c) s += facc[c];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+    if (threadIdx.x == 0 && blockIdx.x == 0) *cyc = t1 - t0;
+}
+
+template <int NF>
+void run_mix(int threads) {
+    double* out; long long* cyc;
+    const int blocks = 256, iters = 20000;
+    hipMalloc(&out, sizeof(double) * threads * blocks);
+    hipMalloc(&cyc, sizeof(long long));
+    hipLaunchKernelGGL(mix_kernel<NF>, dim3(blocks), dim3(threads), 0, 0, out, 100, cyc);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(mix_kernel<NF>, dim3(blocks), dim3(threads), 0, 0, out, iters, cyc);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    long long c; hipMemcpy(&c, cyc, sizeof c, hipMemcpyDeviceToHost);
+    const int waves_per_simd = threads / 256;
+    printf("mix: 1 mfma_f64_16x16x4 + %2d v_fma_f64 per iteration, %d waves/SIMD: %7.1f counter ticks per iteration per SIMD "
+           "(matrix alone %d, vector alone %d, sum %d), %8.3f ms\n", NF, waves_per_simd,
+           (double)c / iters / waves_per_simd,
+           64, 4 * NF, 64 + 4 * NF, ms);
+    hipFree(out); hipFree(cyc);
+}
+
 template <typename K>
 void run(const char* name, K kern, int chains, int threads, int blocks, double flops_per_inst) {
     double* out; long long* cyc;
@@ -74,5 +125,12 @@ int main() {
         run("v_fma_f64 8 chains", fma_kernel<8>, 8, threads, 256, 128.0);
     }
     run("mfma 4 chains, 2 WG/CU", mfma_kernel<4>, 4, 512, 512, 2048.0);
+    for (int threads : {256, 1024}) {
+        run_mix<0>(threads);
+        run_mix<4>(threads);
+        run_mix<8>(threads);
+        run_mix<16>(threads);
+        run_mix<32>(threads);
+    }
     return 0;
 }
