@@ -125,6 +125,7 @@ struct Handle {
     int opt_cols_per_lane = 0;       // 0 auto, 1 / 2: columns per lane in the pairwise pass of the rollout kernel
     int opt_incremental = 1;         // reuse / border-update the cached factors when the memory only grew
     int opt_refresh_every = 32;      // full refactorisation after this many border updates (bounds drift)
+    int opt_fused_prepare = 1;       // N <= 256: the whole factorisation in one launch (prepare_small.hip); 0: panel path (A/B, tests)
     int last_prepare_mode = 0;       // 0 full, 1 border update(s), 2 unchanged (cache hit)
     int lds_limit = 160 * 1024;
     int num_cu = 256;
@@ -165,5 +166,8 @@ int ensure_model_buffers(Handle* h, int N, int D, int E, bool need_factor_ws);
 int run_mll(Handle* h, const double* X, const double* Y, const double* ls, const double* os, const double* noise,
             int N, int D, int E, double* out_host, hipStream_t s);
 int grow(Handle* h, Buf& b, size_t need);
+// prepare_small.hip: 1 = handled (N <= 256), 0 = not applicable, < 0 = error
+int run_prepare_small(Handle* h, const double* X, const double* Y, const double* ls, const double* os, const double* noise,
+                      int N, int D, int E, hipStream_t s);
 
 }  // namespace gpmpc_hip

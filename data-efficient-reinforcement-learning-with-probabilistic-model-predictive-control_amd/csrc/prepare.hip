@@ -20,6 +20,25 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 constexpr int NB = 32;   // panel width
 constexpr int kTPadRows = 72;   // zero rows after every T_a (= kTPad of rollout_kernel.h)
 
+// acc += sum over p in [pbeg, pend) of A(p) B(p) for one 16 x 16 tile with the operands straight from global memory:
+// the loads of U k-steps are issued before the first MFMA of the group, so a group costs one memory round trip, not U
+// (without it every v_mfma waited for its own two loads: the N^3 kernels ran at L2 latency, 8-21 TFLOP/s at N = 4096).
+template <int U, typename FA, typename FB>
+__device__ inline void mfma_kloop(d4& acc, int pbeg, int pend, int lk, FA loadA, FB loadB) {
+    for (int pp = pbeg; pp < pend; pp += 4 * U) {
+        double av[U], bv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int pk = pp + 4 * u + lk;
+            const bool in = pk < pend;
+            av[u] = in ? loadA(pk) : 0.0;
+            bv[u] = in ? loadB(pk) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 __global__ void pack_inputs_kernel(const double* __restrict__ X, const double* __restrict__ ls,
                                    const double* __restrict__ os, int N, int D, int E,
@@ -196,16 +215,19 @@ __global__ __launch_bounds__(256) void syrk_trailing_kernel(double* __restrict__
     const int li = lane & 15, lk = lane >> 4;
     d4 acc = {0.0, 0.0, 0.0, 0.0};
     const int ri = i0 + li, rj = j0 + li;
-    for (int kk = 0; kk < nb; kk += 4) {
-        const int k = kk + lk;
-        const double av = (ri < N && k < nb) ? K[(size_t)ri * N + k0 + k] : 0.0;
-        const double bv = (rj < N && k < nb) ? K[(size_t)rj * N + k0 + k] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+    const double* Ar = K + (size_t)(ri < N ? ri : N - 1) * N + k0;
+    const double* Br = K + (size_t)(rj < N ? rj : N - 1) * N + k0;
+    double cold[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                            // the old values travel while the products are formed
+        const int row = i0 + lk + 4 * r, col = j0 + li;
+        cold[r] = (row < N && col <= row) ? K[(size_t)row * N + col] : 0.0;
     }
+    mfma_kloop<8>(acc, 0, nb, lk, [&](int k) { return ri < N ? Ar[k] : 0.0; }, [&](int k) { return rj < N ? Br[k] : 0.0; });
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = i0 + lk + 4 * r, col = j0 + li;
-        if (row < N && col <= row) K[(size_t)row * N + col] -= acc[r];
+        if (row < N && col <= row) K[(size_t)row * N + col] = cold[r] - acc[r];
     }
 }
 
@@ -226,14 +248,13 @@ __global__ __launch_bounds__(256) void trinv_row_kernel(const double* __restrict
         ykk[r][c] = (r < nb && c <= r) ? Y[(size_t)(k0 + r) * N + (k0 + c)] : 0.0;
     }
     d4 acc = {0.0, 0.0, 0.0, 0.0};
-    const int rowA = k0 + wi + li;              // row of L in block k
-    const int colB = c0 + wj + li;              // column of Y
-    for (int p = c0; p < k0; p += 4) {
-        const int pk = p + lk;
-        const double av = (wi + li < nb && pk < k0) ? L[(size_t)rowA * N + pk] : 0.0;
-        const double bv = (pk < k0 && colB < k0) ? Y[(size_t)pk * N + colB] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
+    const bool rowin = (wi + li < nb);
+    const int rowA = k0 + (rowin ? wi + li : 0);              // row of L in block k
+    const bool colin = (c0 + wj + li < k0);
+    const int colB = colin ? c0 + wj + li : 0;                // column of Y
+    const double* Ar = L + (size_t)rowA * N;
+    const double* Bc = Y + colB;
+    mfma_kloop<8>(acc, c0, k0, lk, [&](int pk) { return rowin ? Ar[pk] : 0.0; }, [&](int pk) { return colin ? Bc[(size_t)pk * N] : 0.0; });
 #pragma unroll
     for (int r = 0; r < 4; ++r) w[wi + lk + 4 * r][wj + li] = acc[r];
     __syncthreads();
@@ -296,14 +317,9 @@ __global__ __launch_bounds__(256) void syrk_inverse_kernel(const double* __restr
     const int j0 = tj * 32 + (wave & 1) * 16;
     const int li = lane & 15, lk = lane >> 4;
     d4 acc = {0.0, 0.0, 0.0, 0.0};
-    const int ci = i0 + li, cj = j0 + li;
+    const int ci = (i0 + li < N) ? i0 + li : N - 1, cj = (j0 + li < N) ? j0 + li : N - 1;    // clamped: masked on store
     const int pstart = (i0 > j0 ? i0 : j0) & ~3;
-    for (int p = pstart; p < N; p += 4) {
-        const int pk = p + lk;
-        const double av = (pk < N && ci < N) ? Y[(size_t)pk * N + ci] : 0.0;
-        const double bv = (pk < N && cj < N) ? Y[(size_t)pk * N + cj] : 0.0;
-        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-    }
+    mfma_kloop<8>(acc, pstart, N, lk, [&](int pk) { return Y[(size_t)pk * N + ci]; }, [&](int pk) { return Y[(size_t)pk * N + cj]; });
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = i0 + lk + 4 * r, col = j0 + li;
@@ -701,26 +717,41 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     if (rc) return rc;
     h->ready = false;
     h->have_state = false;
-    if ((rc = pack(h, X, ls, os, N, D, E, s))) return rc;
-    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->info, 0, kMaxD * sizeof(int), s));
-    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->linv.p, 0, (size_t)D * N * N * sizeof(double), s));
+    // small memories: one launch, one workgroup per GP (prepare_small.hip) -- everything, or (rc == 2) the factorisation only
+    rc = run_prepare_small(h, X, Y, ls, os, noise, N, D, E, s);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+        if ((rc = check_info(h, D, s))) return rc;
+        h->have_state = true;                    // the kernel recorded (X, Y, hyper-parameters)
+        h->inc_updates = 0;
+        h->N = N; h->D = D; h->E = E; h->ready = true;
+        return GPMPC_OK;
+    }
+    const bool factored = (rc == 2);
+    if (!factored) {
+        if ((rc = pack(h, X, ls, os, N, D, E, s))) return rc;
+        GPMPC_HIP_CHECK(h, hipMemsetAsync(h->info, 0, kMaxD * sizeof(int), s));
+        GPMPC_HIP_CHECK(h, hipMemsetAsync(h->linv.p, 0, (size_t)D * N * N * sizeof(double), s));
+    }
     GPMPC_HIP_CHECK(h, hipMemsetAsync(h->Tm.p, 0, (size_t)D * (N + kTPadRows) * N * sizeof(double), s));
-    {
+    if (!factored) {
         const dim3 grid((N + 63) / 64, (N + 63) / 64, D);
         if (E <= 4) hipLaunchKernelGGL(gram_kernel<4>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
         else if (E <= 8) hipLaunchKernelGGL(gram_kernel<8>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
         else if (E <= 16) hipLaunchKernelGGL(gram_kernel<16>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
         else hipLaunchKernelGGL(gram_kernel<24>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
     }
-    GPMPC_HIP_CHECK(h, hipGetLastError());
     for (int k0 = 0; k0 < N; k0 += NB) {
         const int nb = (N - k0 < NB) ? (N - k0) : NB;
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
-        const int M = N - k0 - nb;
-        if (M > 0) {
-            hipLaunchKernelGGL(trsm_panel_kernel, dim3((M + 255) / 256, D), dim3(256), 0, s, h->gram.p, N, k0, nb);
-            const int nt = (M + 31) / 32;
-            hipLaunchKernelGGL(syrk_trailing_kernel, dim3(nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb);
+        if (!factored) {
+            hipLaunchKernelGGL(potrf_diag_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
+            const int M = N - k0 - nb;
+            if (M > 0) {
+                hipLaunchKernelGGL(trsm_panel_kernel, dim3((M + 255) / 256, D), dim3(256), 0, s, h->gram.p, N, k0, nb);
+                const int nt = (M + 31) / 32;
+                hipLaunchKernelGGL(syrk_trailing_kernel, dim3(nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb);
+            }
         }
         if (k0 > 0) {
             hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb);
@@ -733,7 +764,8 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     hipLaunchKernelGGL(syrk_inverse_kernel, dim3(nt, nt, D), dim3(256), 0, s, h->linv.p, h->beta.p, N, h->iK.p, h->Tm.p);
     GPMPC_HIP_CHECK(h, hipGetLastError());
     if ((rc = check_info(h, D, s))) return rc;
-    if ((rc = record_state(h, X, Y, ls, os, noise, N, D, E, s))) return rc;
+    if (factored) h->have_state = true;           // recorded by the factorisation kernel
+    else if ((rc = record_state(h, X, Y, ls, os, noise, N, D, E, s))) return rc;
     h->inc_updates = 0;
     h->N = N; h->D = D; h->E = E; h->ready = true;
     return GPMPC_OK;

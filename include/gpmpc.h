@@ -105,7 +105,8 @@ int gpmpc_read_factors(gpmpc_t* h, double* iK_dst_dev, double* beta_dst_dev, voi
  * "force_global_scratch" (0/1, the large-N streaming kernel at any N), "cols_per_lane" (0 auto, 1, 2: columns per
  * lane in the pairwise pass of the rollout kernel), "grad_cols_per_lane" (same for the gradient's moment pass),
  * "exact_dim" (2: never the compile-time-D kernel instantiation),
- * "incremental" (0/1, default 1), "refresh_every" (default 32). */
+ * "incremental" (0/1, default 1), "refresh_every" (default 32), "fused_prepare" (0/1, default 1: memories of
+ * up to 256 points are factorised by one launch, one workgroup per GP; 0 = the panel-by-panel path). */
 int gpmpc_set_option(gpmpc_t* h, const char* name, long long value);
 
 /*
