@@ -66,6 +66,52 @@ def test_random_shooting_reproduces_reference_trace(engine):
     assert np.allclose(c.states_mu_pred.numpy(), last.states_mu_pred.numpy(), rtol=0, atol=1e-14)
 
 
+REF_OPT = {"disp": None, "maxcor": 4, "ftol": 1e-15, "gtol": 1e-15, "eps": 1e-2, "iprint": -1, "maxls": 4,
+           "finite_diff_rel_step": None}
+
+
+@pytest.mark.parametrize("name", ["optimize_trace", "optimize_trace_deriv"])
+@pytest.mark.parametrize("mode", ["sequential", "lockstep"])
+def test_optimize_true_follows_the_reference_trace(engine, name, mode):
+    """The reference's DEFAULT path (optimize=True: scipy L-BFGS-B, jac=True, one forward + autograd backward per
+    evaluation, gp_mpc_controller.py:125-141) traced by tools/gen_golden.py with the example configs' optimiser
+    settings: this package's controller, fed the same seed, must ask for the same points in the same order and get
+    the same values and gradients (the analytic gradient kernels agree with autograd to 1e-7, so L-BFGS-B's line
+    searches take the same branches), and keep the same winner.  `lockstep` runs the restarts as batched launches
+    (candidate_optimizer = "lbfgs"): same evaluations per restart, same winner."""
+    g = load(name)
+    w = workload_of(g)
+    deriv = bool(g["limit_action_change"])
+    params = dict(REF_OPT, maxfun=int(g["maxfun"]), maxiter=int(g["maxfun"]))
+    c = make_controller(w, limit_action_change=deriv, optimize=True, restarts=int(g["restarts"]), engine=engine,
+                        optimizer_params=params)
+    if deriv:
+        c.actions_mapper.action_model_previous_iter = torch.as_tensor(g["action_prev"])
+    if mode == "lockstep":
+        c.config.controller.candidate_optimizer = "lbfgs"
+    seen = []
+    if mode == "sequential":
+        orig = c.compute_mean_lcb_trajectory
+
+        def spy(x, mu, var):
+            J, gr = orig(x, mu, var)
+            seen.append((np.array(x, dtype=np.float64).copy(), J, np.array(gr).copy()))
+            return J, gr
+        c.compute_mean_lcb_trajectory = spy
+    np.random.seed(int(g["np_seed"]))
+    best = c._get_optimal_actions(torch.as_tensor(w.mu0), torch.as_tensor(w.S0))
+    if mode == "sequential":
+        assert len(seen) == len(g["eval_J"])
+        for k, (x, J, gr) in enumerate(seen):
+            assert np.max(np.abs(x - g["eval_x"][k])) < 1e-6, k
+            assert abs(J - g["eval_J"][k]) < 1e-7 * abs(g["eval_J"][k]), k
+            assert rel_err(gr, g["eval_grad"][k]) < 1e-5, k
+    assert np.max(np.abs(c.actions_mpc_previous_iter - g["best_flat"])) < 1e-6
+    assert np.max(np.abs(best.numpy() - g["best_actions"])) < 1e-6
+    if mode == "lockstep":
+        assert abs(c.best_candidate_J - g["eval_J"].min()) < 1e-7 * abs(g["eval_J"].min())
+
+
 def test_get_action_fills_iteration_information(engine):
     g = load("argmin_trace")
     w = workload_of(g)

@@ -176,6 +176,28 @@ def test_numpy_adjoint_matches_reference_autograd(name):
         assert rel_err(grad.reshape(-1), g["grad"][b]) < 1e-7
 
 
+@pytest.mark.parametrize("name", ["optimize_trace", "optimize_trace_deriv"])
+def test_numpy_adjoint_replays_the_reference_optimize_true_trace(name):
+    """Every point the reference's L-BFGS-B asked for in its `optimize=True` run (tools/gen_golden.py
+    optimize_trace_case): the oracle's objective and gradient at that point vs what the reference computed there."""
+    from oracle import adjoint
+    g = load(name)
+    w = workload_of(g)
+    f = factors_of(w)
+    H, A = w.actions.shape[1:]
+    for k in range(len(g["eval_J"])):
+        u = g["eval_x"][k].reshape(H, A)
+        if bool(g["limit_action_change"]):           # derivative_action_mapper.py:28-35 (clamp transparent here or not: value only)
+            acts = np.clip(g["action_prev"] + np.cumsum(2.0 * g["max_change"] * u - g["max_change"], axis=0), 0.0, 1.0)
+        else:
+            acts = u
+        J, grad, *_ = adjoint.lcb_and_gradient(f, acts, w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
+        assert abs(J - g["eval_J"][k]) < 1e-9 * abs(g["eval_J"][k]), k
+        if bool(g["limit_action_change"]):
+            grad = 2.0 * g["max_change"] * np.cumsum(grad[::-1], axis=0)[::-1]
+        assert rel_err(grad.reshape(-1), g["eval_grad"][k]) < 1e-6, k
+
+
 @pytest.mark.parametrize("N,D,A,H,tm", [(30, 3, 1, 5, False), (25, 2, 2, 4, True), (40, 4, 2, 3, False)])
 def test_numpy_adjoint_matches_torch_autograd_of_the_reference_op_sequence(N, D, A, H, tm):
     import torch

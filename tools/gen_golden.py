@@ -244,6 +244,35 @@ def argmin_trace_case(name, w, restarts, np_seed):
     print(f"{name}: evaluated {len(seen)} candidates, best J={min(s[1] for s in seen):.12g}")
 
 
+def optimize_trace_case(name, w, restarts, np_seed, limit_action_change=False, maxfun=4):
+    """`optimize=True` (the reference's default path): scipy L-BFGS-B with jac=True over `restarts_optim` restarts,
+    every evaluation a forward + autograd backward of compute_mean_lcb_trajectory (gp_mpc_controller.py:125-141),
+    with the example configs' optimiser settings (examples/*/config_*.py: maxfun 4 / 8 / 15).  Records every
+    evaluation (optimiser vector, J, gradient) in call order, and the winner."""
+    N, D, A, E, H, B = w.dims
+    c = make_ref_controller(w, limit_action_change, optimize=True, restarts=restarts)
+    c.config.controller.actions_optimizer_params.update(maxfun=maxfun, maxiter=maxfun)
+    seen = []
+    orig = c.compute_mean_lcb_trajectory
+
+    def spy(actions_mpc, mu, var):
+        J, g = orig(actions_mpc, mu, var)
+        seen.append((np.array(actions_mpc, dtype=np.float64).copy(), float(J), np.array(g, dtype=np.float64).copy()))
+        return J, g
+    c.compute_mean_lcb_trajectory = spy
+    np.random.seed(np_seed)
+    best_model = c._get_optimal_actions(torch.tensor(w.mu0), torch.tensor(w.S0))
+    d = inputs_dict(w)
+    d.update(np_seed=np.array(np_seed), restarts=np.array(restarts), maxfun=np.array(maxfun),
+             limit_action_change=np.array(limit_action_change), max_change=np.full(A, 0.3), action_prev=np.full(A, 0.4),
+             eval_x=np.stack([s[0] for s in seen]), eval_J=np.array([s[1] for s in seen]),
+             eval_grad=np.stack([s[2] for s in seen]), best_actions=best_model.detach().numpy(),
+             best_flat=c.actions_mpc_previous_iter,
+             mu_last=c.states_mu_pred.detach().numpy(), Sig_last=c.states_var_pred.detach().numpy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(f"{name}: {len(seen)} evaluations over {restarts} restarts, J first {seen[0][1]:.10g} best {min(s[1] for s in seen):.10g}")
+
+
 def factor_case(name, w):
     m = ref_model(w)
     d = inputs_dict(w)
@@ -266,6 +295,10 @@ def main():
         big = {
             # (iii') config 4 at its full memory size (the round-1 fixture stops at N = 600)
             "traj_c4_n1000": lambda: traj_case("traj_c4_n1000", mk(1000, 4, 2, 30, 2, seed=29)),
+            # (v') the reference's DEFAULT path: optimize=True, L-BFGS-B with autograd gradients, example settings
+            "optimize_trace": lambda: optimize_trace_case("optimize_trace", mk(50, 3, 1, 15, 1, seed=41), restarts=2, np_seed=321, maxfun=8),
+            "optimize_trace_deriv": lambda: optimize_trace_case("optimize_trace_deriv", mk(50, 3, 2, 8, 1, seed=42), restarts=2, np_seed=322,
+                                                               limit_action_change=True, maxfun=4),
         }
         for name in (args.only if args.only is not None else big):
             big[name]()
