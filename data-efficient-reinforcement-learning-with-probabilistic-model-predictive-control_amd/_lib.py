@@ -47,12 +47,13 @@ SIGNATURES = {
     "gpmpc_rollout": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P]),
     "gpmpc_rollout_grad": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _P]),
     "gpmpc_rollout_timed": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _I, C.POINTER(C.c_float), _P]),
+    "gpmpc_cem_search": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _D, _I, _I, C.c_ulonglong, _P, _I, _P, _P, _P, _P, _P]),
     "gpmpc_argmin_async": (C.c_int, [_P, _P, _I, C.c_longlong, _P, _I, _P, _P]),
     "gpmpc_argmin": (C.c_int, [_P, _P, _I, C.c_longlong, C.POINTER(_D), C.POINTER(C.c_longlong), _P]),
 }
 
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def load(path=LIB_PATH):

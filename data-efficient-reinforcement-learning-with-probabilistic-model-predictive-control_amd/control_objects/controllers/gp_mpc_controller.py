@@ -251,6 +251,8 @@ class GpMpcController(BaseControllerObject):
             return self._random_shooting(state_mu, state_var)
         if getattr(cc, "candidate_optimizer", None) == "cem":
             return self._cross_entropy_search(state_mu, state_var)
+        if getattr(cc, "candidate_optimizer", None) == "cem_device":
+            return self._device_cross_entropy_search(state_mu, state_var)
         if getattr(cc, "candidate_optimizer", None) == "lbfgs":
             return self._batched_lbfgs_search(state_mu, state_var)
         opt_fun, best = np.inf, None
@@ -339,6 +341,39 @@ class GpMpcController(BaseControllerObject):
             mean, std = elites.mean(axis=0), elites.std(axis=0) + 1e-3
         if best_x is None:
             raise FloatingPointError("no finite objective among the candidates")
+        self.best_candidate_J = best_J
+        self.actions_mpc_previous_iter = best_x.copy()
+        return self.actions_mapper.transform_action_mpc_to_action_model(best_x)
+
+    def _device_cross_entropy_search(self, state_mu, state_var):
+        """candidate_optimizer = "cem_device": the cross-entropy search of `_cross_entropy_search` with its whole loop
+        on the GPU (gpmpc_cem_search: sampling, action mapper, rollout, elite selection and refit enqueued back to back,
+        nothing read back between iterations).  Two host synchronisations per control step -- the winner, then its
+        trajectory for the logging caches -- instead of one per iteration; the draws are Philox, keyed by a seed taken
+        from numpy's global generator (so `np.random.seed` still makes a run reproducible)."""
+        cc = self.config.controller
+        H, A = cc.len_horizon, self.actions_mapper.dim_action
+        B = int(cc.cem_candidates)
+        n_elite = max(2, int(round(B * cc.cem_elite_fraction)))
+        first = None
+        if cc.init_from_previous_actions and self.actions_mpc_previous_iter is not None:
+            first = generate_mpc_action_init_frompreviousiter(self.actions_mpc_previous_iter, dim_action=A)
+        kw = {}
+        if isinstance(self.actions_mapper, DerivativeActionMapper):
+            kw = dict(max_change=np.asarray(self.config.actions.max_change_action_norm, dtype=np.float64),
+                      action_prev=self.actions_mapper.action_model_previous_iter.numpy())
+        seed = int(np.random.randint(0, 2 ** 62))
+        tm = self.transition_model
+        tm.set_cost(self.config.reward)
+        best_x, best_J = tm.engine.cem_search(
+            np.asarray(state_mu, dtype=np.float64), np.asarray(state_var, dtype=np.float64), B, H, A,
+            int(cc.cem_iterations), n_elite, seed=seed, include_time=tm.config.include_time_model,
+            time0=float(self.iter_ctrl), first_candidate=first, **kw)
+        if not np.isfinite(best_J):
+            raise FloatingPointError("no finite objective among the candidates")
+        self.num_rollouts += B * int(cc.cem_iterations)
+        out = self.evaluate_candidates(best_x[None], state_mu, state_var, trajectories=True)
+        self._cache_trajectory(out, 0)
         self.best_candidate_J = best_J
         self.actions_mpc_previous_iter = best_x.copy()
         return self.actions_mapper.transform_action_mpc_to_action_model(best_x)

@@ -1,8 +1,36 @@
 // abi.hip -- extern "C" entry points of libgpmpc_hip.so (declared in include/gpmpc.h).
 #include <cstring>
 #include <new>
+#include <dlfcn.h>
 
 #include "gpmpc_internal.h"
+
+// ROCTx ranges around the entry points (tracing row): visible in `rocprofv3 --marker-trace` timelines
+// as gpmpc_prepare / gpmpc_rollout / gpmpc_rollout_grad / gpmpc_argmin.  The marker library is looked up at first use
+// (rocprofiler-sdk's roctx, then the older roctracer one); without it the ranges cost one predictable branch.
+namespace {
+struct Roctx {
+    int (*push)(const char*) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        for (const char* lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+            void* hnd = dlopen(lib, RTLD_LAZY | RTLD_LOCAL);
+            if (!hnd) continue;
+            push = reinterpret_cast<int (*)(const char*)>(dlsym(hnd, "roctxRangePushA"));
+            pop = reinterpret_cast<int (*)()>(dlsym(hnd, "roctxRangePop"));
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+struct Range {
+    static const Roctx& api() { static Roctx r; return r; }
+    explicit Range(const char* name) { if (api().push) api().push(name); }
+    ~Range() { if (api().pop) api().pop(); }
+    Range(const Range&) = delete;
+    Range& operator=(const Range&) = delete;
+};
+}  // namespace
 
 using namespace gpmpc_hip;
 
@@ -25,7 +53,7 @@ static void free_buf(Buf& b) {
 
 extern "C" {
 
-int gpmpc_abi_version(void) { return 7; }
+int gpmpc_abi_version(void) { return 8; }
 
 int gpmpc_create(gpmpc_t** out, int device_id) {
     if (!out) return GPMPC_ERR_ARG;
@@ -53,7 +81,7 @@ int gpmpc_destroy(gpmpc_t* g) {
     (void)hipSetDevice(h->device);
     Buf* all[] = {&h->Xt, &h->beta, &h->iK, &h->Tm, &h->ils2, &h->var, &h->logvar, &h->gram,
                   &h->linv, &h->zvec, &h->cost, &h->best, &h->xrange, &h->mono_w, &h->traj, &h->Xc, &h->Yc,
-                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws};
+                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws, &h->cemws};
     for (Buf* b : all) free_buf(*b);
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);
@@ -90,6 +118,7 @@ static int check_dims(gpmpc_t* g, int N, int D, int E) {
 
 int gpmpc_prepare(gpmpc_t* g, const double* X, const double* Y, const double* ls, const double* os,
                   const double* noise, int N, int D, int E, void* stream) {
+    Range roctx_range("gpmpc_prepare");
     if (!g || !X || !Y || !ls || !os || !noise) return bad(g, "null argument");
     int rc = check_dims(g, N, D, E);
     if (rc) return rc;
@@ -99,6 +128,7 @@ int gpmpc_prepare(gpmpc_t* g, const double* X, const double* Y, const double* ls
 
 int gpmpc_set_factors(gpmpc_t* g, const double* X, const double* iK, const double* beta, const double* ls,
                       const double* os, int N, int D, int E, void* stream) {
+    Range roctx_range("gpmpc_set_factors");
     if (!g || !X || !iK || !beta || !ls || !os) return bad(g, "null argument");
     int rc = check_dims(g, N, D, E);
     if (rc) return rc;
@@ -125,6 +155,7 @@ int gpmpc_read_factors(gpmpc_t* g, double* iK_dst, double* beta_dst, void* strea
 
 int gpmpc_mll(gpmpc_t* g, const double* X, const double* Y, const double* ls, const double* os, const double* noise,
               int N, int D, int E, double* out_host, void* stream) {
+    Range roctx_range("gpmpc_mll");
     if (!g) return GPMPC_ERR_ARG;
     if (!X || !Y || !ls || !os || !noise || !out_host) return bad(g, "null argument");
     int rc = check_dims(g, N, D, E);
@@ -181,6 +212,7 @@ static int fill_args(gpmpc_t* g, RolloutArgs& a, const double* actions, const do
 int gpmpc_rollout(gpmpc_t* g, const double* actions, const double* mu0, const double* S0, int B, int H, int A,
                   int include_time, double time0, double* mu_out, double* Sig_out, double* cm_out, double* cv_out,
                   double* J_out, void* stream) {
+    Range roctx_range("gpmpc_rollout");
     if (!g) return GPMPC_ERR_ARG;
     RolloutArgs a;
     // the trajectory alone (predict_trajectory, gp_model.py:60-110) needs no cost settings
@@ -194,6 +226,7 @@ int gpmpc_rollout(gpmpc_t* g, const double* actions, const double* mu0, const do
 int gpmpc_rollout_grad(gpmpc_t* g, const double* actions, const double* mu0, const double* S0, int B, int H, int A,
                        int include_time, double time0, double* J_out, double* grad_out, double* mu_out, double* Sig_out,
                        double* cm_out, double* cv_out, void* stream) {
+    Range roctx_range("gpmpc_rollout_grad");
     if (!g) return GPMPC_ERR_ARG;
     if (!grad_out) return bad(g, "null argument");
     RolloutArgs a;
@@ -203,6 +236,24 @@ int gpmpc_rollout_grad(gpmpc_t* g, const double* actions, const double* mu0, con
     GPMPC_HIP_CHECK(H_(g), hipSetDevice(g->h.device));
     a.mu_out = mu_out; a.Sig_out = Sig_out; a.J_out = J_out; a.cm_out = cm_out; a.cv_out = cv_out;
     return launch_rollout_grad(H_(g), a, grad_out, (hipStream_t)stream);
+}
+
+int gpmpc_cem_search(gpmpc_t* g, const double* mu0, const double* S0, int B, int H, int A, int include_time, double time0,
+                     int iterations, int n_elite, unsigned long long seed, const double* first_candidate, int mapper,
+                     const double* max_change, const double* action_prev, const double* noise_dev, double* best_out_dev,
+                     void* stream) {
+    Range roctx_range("gpmpc_cem_search");
+    if (!g) return GPMPC_ERR_ARG;
+    if (!best_out_dev) return bad(g, "null argument");
+    Handle* h = H_(g);
+    if (!h->ready) return bad(g, "search before prepare / set_factors");
+    // fill_args wants an actions pointer; the search supplies its own device buffer afterwards
+    RolloutArgs a;
+    int rc = fill_args(g, a, best_out_dev, mu0, S0, B, H, A, include_time, time0);
+    if (rc) return rc;
+    GPMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    return run_cem_search(h, a, iterations, n_elite, seed, first_candidate, mapper, max_change, action_prev, noise_dev,
+                          best_out_dev, (hipStream_t)stream);
 }
 
 int gpmpc_rollout_timed(gpmpc_t* g, const double* actions, const double* mu0, const double* S0, int B, int H, int A,
@@ -234,6 +285,7 @@ int gpmpc_rollout_timed(gpmpc_t* g, const double* actions, const double* mu0, co
 }
 
 int gpmpc_argmin(gpmpc_t* g, const double* J, int B, long long first, double* best_J, long long* best_idx, void* stream) {
+    Range roctx_range("gpmpc_argmin");
     if (!g || !J || B < 1 || first < 0) return bad(g, "bad argument");
     Handle* h = H_(g);
     GPMPC_HIP_CHECK(h, hipSetDevice(h->device));
@@ -250,6 +302,7 @@ int gpmpc_argmin(gpmpc_t* g, const double* J, int B, long long first, double* be
 
 int gpmpc_argmin_async(gpmpc_t* g, const double* J, int B, long long first, const double* actions, int HA, double* out_dev,
                        void* stream) {
+    Range roctx_range("gpmpc_argmin_async");
     if (!g || !J || !out_dev || B < 1 || first < 0 || HA < 0) return bad(g, "bad argument");
     Handle* h = H_(g);
     GPMPC_HIP_CHECK(h, hipSetDevice(h->device));

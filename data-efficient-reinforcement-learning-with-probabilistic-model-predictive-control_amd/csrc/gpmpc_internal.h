@@ -93,6 +93,7 @@ struct Handle {
     Buf xrange;   // (2, E) min / max of the inputs
     Buf gradws;   // gradient workspace: pair moments | mean sums | cost variances
     Buf mllws;    // marginal-likelihood workspace: tile partial sums | results
+    Buf cemws;    // cross-entropy search workspace: optimiser vectors | model actions | J | mean | std | warm start | mapper
     // incremental factorisation: what the cached factors were computed from, and border-update scratch
     Buf Xc, Yc;   // (N, E), (N, D) copies of the memory points of the last prepare
     Buf hyp;      // lengthscales (D*E) | outputscales (D) | noises (D) of the last prepare
@@ -166,6 +167,10 @@ int ensure_model_buffers(Handle* h, int N, int D, int E, bool need_factor_ws);
 int run_mll(Handle* h, const double* X, const double* Y, const double* ls, const double* os, const double* noise,
             int N, int D, int E, double* out_host, hipStream_t s);
 int grow(Handle* h, Buf& b, size_t need);
+// search.hip: cross-entropy search whose loop stays on the device (actions / J_out of `a` are set inside)
+int run_cem_search(Handle* h, RolloutArgs& a, int iterations, int n_elite, unsigned long long seed, const double* first_host,
+                   int mapper, const double* max_change_host, const double* a_prev_host, const double* noise_dev,
+                   double* best_out_dev, hipStream_t s);
 // prepare_small.hip: 1 = handled (N <= 256), 0 = not applicable, < 0 = error
 int run_prepare_small(Handle* h, const double* X, const double* Y, const double* ls, const double* os, const double* noise,
                       int N, int D, int E, hipStream_t s);

@@ -131,6 +131,7 @@ class HipEngine:
         target = _host(target, (D + A,))
         smin = _host(state_min, (D,)) if state_min is not None else None
         smax = _host(state_max, (D,)) if state_max is not None else None
+        self._cost_token = None        # whoever caches "my settings are loaded" (GpStateTransitionModel.set_cost) must re-key
         self._check(self.lib.gpmpc_set_cost(self._h, _hp(target), _hp(W), _hp(W_T), float(kappa), int(bool(clip_to_zero)),
                                             _hp(smin) if smin is not None else None,
                                             _hp(smax) if smax is not None else None, D, A))
@@ -212,6 +213,30 @@ class HipEngine:
                                                  int(bool(include_time)), float(time0), J.data_ptr(), int(reps),
                                                  C.byref(ms), self._stream()))
         return float(ms.value), J
+
+    def cem_search(self, mu0, S0, B, H, A, iterations, n_elite, seed=0, include_time=False, time0=0.0, first_candidate=None,
+                   max_change=None, action_prev=None, noise=None):
+        """Cross-entropy search over [0,1]^(H*A) with the whole loop on the device (gpmpc_cem_search): returns
+        (best optimiser vector (H*A,) numpy, best J).  `max_change` / `action_prev` given => DerivativeActionMapper,
+        else the identity mapper.  `noise` (iterations, B, H*A) device / host tensor replaces the Philox draws (tests).
+        ONE host synchronisation, at the end."""
+        D = self.D
+        mu0 = _host(mu0, (D,))
+        S0 = _host(S0, (D, D))
+        n = H * A
+        best = torch.empty(n + 1, dtype=torch.float64, device=self.device)
+        first = _host(first_candidate, (n,)) if first_candidate is not None else None
+        mapper = 0 if max_change is None else 1
+        mc = _host(max_change, (A,)) if mapper else None
+        ap = _host(action_prev, (A,)) if mapper else None
+        nz = None if noise is None else self._dev(noise, (iterations, B, n))
+        self._check(self.lib.gpmpc_cem_search(self._h, _hp(mu0), _hp(S0), B, H, A, int(bool(include_time)), float(time0),
+                                              int(iterations), int(n_elite), int(seed) & (2 ** 64 - 1),
+                                              _hp(first) if first is not None else None, mapper,
+                                              _hp(mc) if mapper else None, _hp(ap) if mapper else None,
+                                              nz.data_ptr() if nz is not None else None, best.data_ptr(), self._stream()))
+        host = best.cpu().numpy()                               # the one synchronisation
+        return host[:n].copy(), float(host[n])
 
     # -- a8 ----------------------------------------------------------------------------
     def argmin_async(self, J, first_global_index=0, actions=None, out=None):

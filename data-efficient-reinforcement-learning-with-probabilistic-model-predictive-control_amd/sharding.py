@@ -96,11 +96,18 @@ def _local_record(engine, J, actions_local, lo, out=None):
 
 def _gather_records(rec, group=None):
     """(world, flat (world * len(rec)) tensor): ONE all_gather over RCCL (gloo in the CPU tests) when a process
-    group is initialised, otherwise the record itself."""
+    group is initialised, otherwise the record itself.  Wrapped in a ROCTx range ("gpmpc_gather") on a GPU."""
     if dist.is_available() and dist.is_initialized():
         world = dist.get_world_size(group)
         flat = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)
-        dist.all_gather_into_tensor(flat, rec.contiguous(), group=group)
+        marked = rec.device.type == "cuda"
+        if marked:
+            torch.cuda.nvtx.range_push("gpmpc_gather")        # roctx on ROCm builds of torch
+        try:
+            dist.all_gather_into_tensor(flat, rec.contiguous(), group=group)
+        finally:
+            if marked:
+                torch.cuda.nvtx.range_pop()
         return world, flat
     return 1, rec
 

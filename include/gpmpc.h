@@ -174,6 +174,24 @@ int gpmpc_rollout_grad(gpmpc_t* h, const double* actions_dev, const double* mu0_
 int gpmpc_argmin_async(gpmpc_t* h, const double* J_dev, int B, long long first_global_index,
                        const double* actions_dev, int HA, double* out_dev, void* stream);
 
+/*
+ * Candidate optimisation whose loop stays on the device (replaces B sequential scipy restarts,
+ * gp_mpc_controller.py:125-141, by a cross-entropy search over the same box [0,1]^(H*A)): per iteration
+ * B optimiser vectors are drawn around the current mean / std (iteration 0: uniform; slot 0 = the incumbent, in
+ * iteration 0 `first_candidate_host` when given), mapped to model actions (mapper 0: identity reshape,
+ * normalization_action_mapper.py:21-23; 1: scaled deltas + cumulative sum + pass-through clamp,
+ * derivative_action_mapper.py:28-35, with max_change_host (A) and action_prev_host (A)), evaluated by one rollout
+ * launch, and the n_elite best refit mean and std.  All launches are enqueued on `stream`; NOTHING is read back
+ * between iterations.  best_out_dev (H*A + 1) = [best optimiser vector | its objective], valid after `stream`
+ * has been synchronised.  Draws come from Philox4x32-10 keyed by `seed`, or from noise_dev (iterations, B, H*A)
+ * when given (iteration 0: uniforms in [0,1); later: standard normals) -- the hook the parity test uses.
+ * 2 <= B <= 4096.
+ */
+int gpmpc_cem_search(gpmpc_t* h, const double* mu0_host, const double* S0_host, int B, int H, int A,
+                     int include_time, double time0, int iterations, int n_elite, unsigned long long seed,
+                     const double* first_candidate_host, int mapper, const double* max_change_host,
+                     const double* action_prev_host, const double* noise_dev, double* best_out_dev, void* stream);
+
 /* Kernel-only timing helper for bench.py: runs `reps` rollouts back to back on `stream`
  * bracketed by HIP events recorded on THAT stream and returns the average milliseconds
  * per launch in *ms_host (outputs as gpmpc_rollout; synchronises). */

@@ -148,6 +148,78 @@ def test_lbfgsb_path_improves_objective(engine):
     assert np.all(c.actions_mpc_previous_iter >= 0) and np.all(c.actions_mpc_previous_iter <= 1)
 
 
+@pytest.mark.parametrize("deriv", [False, True])
+def test_device_resident_search_matches_a_host_loop_on_the_same_draws(engine, deriv):
+    """gpmpc_cem_search keeps sampling, action mapper, elite selection and refit on the GPU.  Fed the SAME draws through
+    its noise hook, it must reproduce a plain numpy loop around gpmpc_rollout (same keep-the-incumbent, clip, stable
+    elite order, population std + 1e-3, NaN -> inf rules as GpMpcController._cross_entropy_search): same winner, same
+    objective; mean / std differ only by summation order."""
+    g = load("lcb_grad_deriv" if deriv else "lcb_grad_norm")
+    w = workload_of(g)
+    N, D, A, E, H, _ = w.dims
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    engine.set_cost(w.target, w.W, w.W_T, w.kappa)
+    B, iters, n_elite, n = 96, 4, 9, H * A
+    rng = np.random.default_rng(5)
+    noise = np.concatenate([rng.uniform(size=(1, B, n)), rng.standard_normal((iters - 1, B, n))])
+    first = rng.uniform(size=n)
+    mc, prev = (g["max_change"], g["action_prev"]) if deriv else (None, None)
+
+    def to_model(X):
+        a = X.reshape(-1, H, A)
+        if not deriv:
+            return a
+        d = a * 2.0 * mc - mc
+        d[:, 0] += prev
+        return np.clip(np.cumsum(d, axis=1), 0.0, 1.0)
+    mean = std = best_x = None
+    best_J = np.inf
+    for it in range(iters):
+        X = noise[it].copy() if it == 0 else np.clip(mean + std * noise[it], 0.0, 1.0)
+        X[0] = first if it == 0 else best_x
+        J = engine.rollout(to_model(X), w.mu0, w.S0, trajectories=False, stage_costs=False)["J"].cpu().numpy()
+        J = np.where(np.isnan(J), np.inf, J)
+        order = np.argsort(J, kind="stable")
+        if J[order[0]] < best_J:
+            best_J, best_x = float(J[order[0]]), X[order[0]].copy()
+        el = X[order[:n_elite]]
+        mean, std = el.mean(axis=0), el.std(axis=0) + 1e-3
+    kw = dict(max_change=mc, action_prev=prev) if deriv else {}
+    x_dev, J_dev = engine.cem_search(w.mu0, w.S0, B, H, A, iters, n_elite, first_candidate=first, noise=noise, **kw)
+    # (elite means are summed in a different order: the refitted draws differ in the last bits, and so does J)
+    assert abs(J_dev - best_J) <= 1e-9 * abs(best_J)
+    assert np.max(np.abs(x_dev - best_x)) < 1e-9
+    # and with its own Philox draws: reproducible for a seed, different for another, never worse than its warm start
+    x1, J1 = engine.cem_search(w.mu0, w.S0, B, H, A, iters, n_elite, seed=11, first_candidate=first, **kw)
+    x2, J2 = engine.cem_search(w.mu0, w.S0, B, H, A, iters, n_elite, seed=11, first_candidate=first, **kw)
+    x3, J3 = engine.cem_search(w.mu0, w.S0, B, H, A, iters, n_elite, seed=12, first_candidate=first, **kw)
+    assert J1 == J2 and np.array_equal(x1, x2) and not np.array_equal(x1, x3)
+    J_first = engine.rollout(to_model(first[None]), w.mu0, w.S0, trajectories=False, stage_costs=False)["J"].cpu().numpy()[0]
+    assert J1 <= J_first and J3 <= J_first and np.all((x1 >= 0) & (x1 <= 1))
+
+
+def test_device_resident_search_in_the_controller(engine):
+    """candidate_optimizer = "cem_device" behind get_action: same budget as 512 random sequences, ends at least as low;
+    the logging caches hold the winner's trajectory; the next step warm-starts from the shifted solution."""
+    g = load("lcb_grad_norm")
+    w = workload_of(g)
+    rs = make_controller(w, optimize=False, restarts=512, engine=engine)
+    np.random.seed(11)
+    rs._get_optimal_actions(torch.as_tensor(w.mu0), torch.as_tensor(w.S0))
+    c = make_controller(w, optimize=True, engine=engine)
+    c.config.controller.candidate_optimizer = "cem_device"
+    c.config.controller.cem_candidates = 128
+    c.config.controller.cem_iterations = 4
+    np.random.seed(11)
+    a = c.get_action(obs_mu=w.mu0)
+    assert a.shape == (1,) and c.num_rollouts == 512 + 1
+    assert c.best_candidate_J <= rs.best_candidate_J + 1e-12
+    assert abs(c.cost_traj_mean_lcb.item() + c.best_candidate_J) < 1e-12 * abs(c.best_candidate_J)
+    J_prev = c.best_candidate_J
+    c.get_action(obs_mu=w.mu0)
+    assert np.isfinite(c.best_candidate_J) and c.best_candidate_J < 2 * abs(J_prev) + 1.0
+
+
 def test_cross_entropy_search_beats_random_shooting(engine):
     """Same evaluation budget (4 launches x 128 candidates vs one launch of 512 random sequences): the
     refitted search must end at least as low, and never above its own first iteration."""
