@@ -202,8 +202,8 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(double* __restrict__ Ka
 
 // Trailing update A22 -= L21 L21^T on the lower triangle; 32x32 block per workgroup, one
 // 16x16 fp64 MFMA tile per wave.
-__global__ __launch_bounds__(256) void syrk_trailing_kernel(double* __restrict__ Kall, int N, int k0, int nb) {
-    const int ti = blockIdx.y, tj = blockIdx.x;
+__global__ __launch_bounds__(256) void syrk_trailing_kernel(double* __restrict__ Kall, int N, int k0, int nb, int cend) {
+    const int ti = blockIdx.y, tj = blockIdx.x;              // cend: columns >= cend are left to the outer (rank-128) update
     if (tj > ti) return;
     const int a = blockIdx.z;
     double* K = Kall + (size_t)a * N * N;
@@ -221,25 +221,25 @@ __global__ __launch_bounds__(256) void syrk_trailing_kernel(double* __restrict__
 #pragma unroll
     for (int r = 0; r < 4; ++r) {                            // the old values travel while the products are formed
         const int row = i0 + lk + 4 * r, col = j0 + li;
-        cold[r] = (row < N && col <= row) ? K[(size_t)row * N + col] : 0.0;
+        cold[r] = (row < N && col <= row && col < cend) ? K[(size_t)row * N + col] : 0.0;
     }
     mfma_kloop<8>(acc, 0, nb, lk, [&](int k) { return ri < N ? Ar[k] : 0.0; }, [&](int k) { return rj < N ? Br[k] : 0.0; });
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = i0 + lk + 4 * r, col = j0 + li;
-        if (row < N && col <= row) K[(size_t)row * N + col] = cold[r] - acc[r];
+        if (row < N && col <= row && col < cend) K[(size_t)row * N + col] = cold[r] - acc[r];
     }
 }
 
 // Row block k of Y = L^-1:  Y[k, c] = -Ykk * (sum_p L[k, p] Y[p, c]) for column tiles c < k0.
 __global__ __launch_bounds__(256) void trinv_row_kernel(const double* __restrict__ Kall, double* __restrict__ Yall,
-                                                        int N, int k0, int nb) {
+                                                        int N, int k0, int nb, int cbeg) {
     __shared__ double w[32][33];
     __shared__ double ykk[NB][NB + 1];
     const int a = blockIdx.y;
     const double* L = Kall + (size_t)a * N * N;
     double* Y = Yall + (size_t)a * N * N;
-    const int c0 = blockIdx.x * 32;
+    const int c0 = cbeg + blockIdx.x * 32;                   // cbeg > 0: only the columns of the current 128-row outer block
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
     const int li = lane & 15, lk = lane >> 4;
@@ -333,6 +333,216 @@ __global__ __launch_bounds__(256) void syrk_inverse_kernel(const double* __restr
             if (row != col) iK[(size_t)col * N + row] = v;
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// LDS-tiled symmetric rank-k products on the matrix cores (large N).  The round-1 kernels above give every wavefront one
+// 16 x 16 tile with operands straight from L2: 2 loads per lane per MFMA, the A operand as 16 scattered 32-byte pieces --
+// they ran at 7-21 TFLOP/s of the 78.6 TFLOP/s fp64 matrix peak.  Here a workgroup of 4 wavefronts owns a 64 x 64 tile of
+// the result; 32-deep slices of both operands are staged through LDS with coalesced loads (256-byte row segments) and
+// every wavefront forms a 32 x 32 sub-tile (2 x 2 MFMA tiles: 4 LDS reads per 4 MFMAs).  LDS layouts are chosen per
+// operand orientation so that the fragment reads are conflict-free: rows x k with a stride of 34 doubles when the
+// operand is stored row-major along k, k x columns with a stride of 80 doubles when it is stored along the columns.
+constexpr int TS = 64;            // tile edge
+constexpr int KC = 32;            // k-slice
+constexpr int SI = KC + 2;        // LDS stride, i-major tiles (rows x k)
+constexpr int SK = TS + 16;       // LDS stride, k-major tiles (k x columns)
+
+// Trailing update of the outer-blocked Cholesky: C[i][j] -= sum_{p < w} L[i][k0 + p] L[j][k0 + p] for the lower triangle of
+// rows / columns >= r0 (= k0 + w).  Both operands are rows of L: i-major staging.
+__global__ __launch_bounds__(256) void syrk_outer_kernel(double* __restrict__ Kall, int N, int k0, int w) {
+    __shared__ double As[TS * SI];
+    __shared__ double Bs[TS * SI];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    double* K = Kall + (size_t)blockIdx.z * N * N;
+    const int r0 = k0 + w;
+    const int i0 = r0 + ti * TS, j0 = r0 + tj * TS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    // staging: element e = 256 u + tid of the 64 x 32 slice, row e / 32, k = e % 32 -- a wavefront moves two 256-byte row
+    // segments per instruction and writes 64 consecutive doubles (+ one row skip) of LDS: coalesced and conflict-free
+    const int srow = tid >> 5, sk = tid & 31;
+    d4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = {0.0, 0.0, 0.0, 0.0};
+    double av[8], bv[8];
+    auto fetch = [&](int p0) {
+        const bool kin = (p0 + sk < w);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = 8 * u + srow;
+            const int ra = (i0 + row < N) ? i0 + row : N - 1, rb = (j0 + row < N) ? j0 + row : N - 1;
+            av[u] = kin ? K[(size_t)ra * N + k0 + p0 + sk] : 0.0;
+            bv[u] = kin ? K[(size_t)rb * N + k0 + p0 + sk] : 0.0;
+        }
+    };
+    fetch(0);
+    for (int p0 = 0; p0 < w; p0 += KC) {
+        __syncthreads();                                             // previous slice consumed
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { As[(8 * u + srow) * SI + sk] = av[u]; Bs[(8 * u + srow) * SI + sk] = bv[u]; }
+        __syncthreads();
+        if (p0 + KC < w) fetch(p0 + KC);                             // next slice travels while this one is multiplied
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            const double a0 = As[(wi + li) * SI + kk + lk], a1 = As[(wi + 16 + li) * SI + kk + lk];
+            const double b0 = Bs[(wj + li) * SI + kk + lk], b1 = Bs[(wj + 16 + li) * SI + kk + lk];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wi + 16 * x + lk + 4 * r, col = j0 + wj + 16 * y + li;
+                if (row < N && col <= row) K[(size_t)row * N + col] -= acc[x][y][r];
+            }
+}
+
+// iK = Y^T Y (Y = L^-1 lower triangular: Y[p][c] = 0 for p < c) on 64 x 64 tiles of the lower triangle, mirrored on store,
+// plus T = beta beta^T - iK (upper triangle, diagonal halved).  Both operands are columns of Y: k-major staging.
+__global__ __launch_bounds__(256) void syrk_inverse_tiled_kernel(const double* __restrict__ Yall, const double* __restrict__ beta,
+                                                                 int N, double* __restrict__ iKall, double* __restrict__ Tall) {
+    __shared__ double As[KC * SK];
+    __shared__ double Bs[KC * SK];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    const int a = blockIdx.z;
+    const double* Y = Yall + (size_t)a * N * N;
+    double* iK = iKall + (size_t)a * N * N;
+    double* T = Tall + (size_t)a * (N + kTPadRows) * N;
+    const double* be = beta + (size_t)a * N;
+    const int i0 = ti * TS, j0 = tj * TS;                            // j0 <= i0
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    // staging: element e = 256 u + tid of the 32 x 64 slice, k = e / 64, column e % 64 -- a wavefront moves one 512-byte
+    // row segment per instruction and writes 64 consecutive doubles of LDS
+    const int sp = tid >> 6, scol = tid & 63;
+    d4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = {0.0, 0.0, 0.0, 0.0};
+    double av[8], bv[8];
+    auto fetch = [&](int p0) {
+        const int ci = i0 + scol, cj = j0 + scol;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int p = p0 + 4 * u + sp;
+            av[u] = (p < N && ci < N) ? Y[(size_t)p * N + ci] : 0.0;
+            bv[u] = (p < N && cj < N) ? Y[(size_t)p * N + cj] : 0.0;
+        }
+    };
+    fetch(i0);
+    for (int p0 = i0; p0 < N; p0 += KC) {                            // rows p < i0 of the A columns are zero
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { As[(4 * u + sp) * SK + scol] = av[u]; Bs[(4 * u + sp) * SK + scol] = bv[u]; }
+        __syncthreads();
+        if (p0 + KC < N) fetch(p0 + KC);                             // next slice travels while this one is multiplied
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            const double a0 = As[(kk + lk) * SK + wi + li], a1 = As[(kk + lk) * SK + wi + 16 + li];
+            const double b0 = Bs[(kk + lk) * SK + wj + li], b1 = Bs[(kk + lk) * SK + wj + 16 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wi + 16 * x + lk + 4 * r, col = j0 + wj + 16 * y + li;
+                if (row < N && col < N && col <= row) {
+                    const double v = acc[x][y][r];
+                    double t = be[row] * be[col] - v;
+                    if (row == col) t *= 0.5;
+                    iK[(size_t)row * N + col] = v;
+                    T[(size_t)col * N + row] = t;                    // upper triangle only; the rest stays zero
+                    if (row != col) iK[(size_t)col * N + row] = v;
+                }
+            }
+}
+
+// C (M x NC) = alpha * A (M x Kd, row-major, lda) * B (Kd x NC, row-major, ldb) on 64 x 64 tiles, batched over blockIdx.z.
+// A rows are staged i-major, B rows k-major (see above).  kskip: B[p][c] = 0 for p < c (a lower-triangular right factor), so
+// the k range of column tile c0 starts at c0; ktri: A[i][p] = 0 for p > i (a lower-triangular left factor), so it ends at
+// i0 + 64.  Used for the triangular inverse by 128-row blocks: W = L[K, c:K] Y[c:K, c], then Y[K, c] = -Y_KK W.
+__global__ __launch_bounds__(256) void gemm_nn_tiled_kernel(const double* __restrict__ Aall, int lda, size_t sa,
+                                                            const double* __restrict__ Ball, int ldb, size_t sb,
+                                                            double* __restrict__ Call, int ldc, size_t sc, int M, int NC, int Kd,
+                                                            double alpha, int kskip, int ktri) {
+    __shared__ double As[TS * SI];
+    __shared__ double Bs[KC * SK];
+    const double* A = Aall + (size_t)blockIdx.z * sa;
+    const double* B = Ball + (size_t)blockIdx.z * sb;
+    double* C = Call + (size_t)blockIdx.z * sc;
+    const int i0 = blockIdx.y * TS, c0 = blockIdx.x * TS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    const int srow = tid >> 5, sk = tid & 31;                        // A slice 64 x 32: element 256 u + tid -> row 8 u + srow, k = sk
+    const int sp = tid >> 6, scol = tid & 63;                        // B slice 32 x 64: element 256 u + tid -> k = 4 u + sp, column scol
+    int kbeg = kskip ? (c0 & ~(KC - 1)) : 0;
+    int kend = Kd;
+    if (ktri && i0 + TS < kend) kend = i0 + TS;
+    d4 acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = {0.0, 0.0, 0.0, 0.0};
+    double av[8], bv[8];
+    auto fetch = [&](int p0) {
+        const int pa = p0 + sk, cb = c0 + scol;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = 8 * u + srow;
+            const int ra = (i0 + row < M) ? i0 + row : M - 1;
+            av[u] = (pa < kend) ? A[(size_t)ra * lda + pa] : 0.0;
+            const int pb = p0 + 4 * u + sp;
+            bv[u] = (pb < kend && cb < NC) ? B[(size_t)pb * ldb + cb] : 0.0;
+        }
+    };
+    if (kbeg < kend) fetch(kbeg);
+    for (int p0 = kbeg; p0 < kend; p0 += KC) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { As[(8 * u + srow) * SI + sk] = av[u]; Bs[(4 * u + sp) * SK + scol] = bv[u]; }
+        __syncthreads();
+        if (p0 + KC < kend) fetch(p0 + KC);
+#pragma unroll
+        for (int kk = 0; kk < KC; kk += 4) {
+            const double a0 = As[(wi + li) * SI + kk + lk], a1 = As[(wi + 16 + li) * SI + kk + lk];
+            const double b0 = Bs[(kk + lk) * SK + wj + li], b1 = Bs[(kk + lk) * SK + wj + 16 + li];
+            acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wi + 16 * x + lk + 4 * r, col = c0 + wj + 16 * y + li;
+                if (row < M && col < NC) C[(size_t)row * ldc + col] = alpha * acc[x][y][r];
+            }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -742,6 +952,10 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
         else hipLaunchKernelGGL(gram_kernel<24>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
         GPMPC_HIP_CHECK(h, hipGetLastError());
     }
+    // Outer blocking (large N): the rank-32 trailing update touches the whole trailing matrix per panel -- 32 multiply-adds
+    // per 16 bytes read and written, HBM-bound at N = 4096.  With outer panels of 128 columns the 32-wide steps only update
+    // the strip inside the outer panel and one LDS-tiled rank-128 product per outer panel does the rest.
+    const int OW = (N >= 1024 && h->opt_outer_block != 0) ? 128 : 0;
     for (int k0 = 0; k0 < N; k0 += NB) {
         const int nb = (N - k0 < NB) ? (N - k0) : NB;
         if (!factored) {
@@ -749,19 +963,51 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
             const int M = N - k0 - nb;
             if (M > 0) {
                 hipLaunchKernelGGL(trsm_panel_kernel, dim3((M + 255) / 256, D), dim3(256), 0, s, h->gram.p, N, k0, nb);
+                int cend = N;
+                if (OW) { cend = (k0 / OW + 1) * OW; if (cend > N) cend = N; }
                 const int nt = (M + 31) / 32;
-                hipLaunchKernelGGL(syrk_trailing_kernel, dim3(nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb);
+                const int ntx = (cend - (k0 + nb) + 31) / 32;
+                if (ntx > 0)
+                    hipLaunchKernelGGL(syrk_trailing_kernel, dim3(ntx < nt ? ntx : nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb, cend);
+                if (OW && k0 + nb == cend && cend < N) {             // outer panel [cend - OW, cend) complete: rank-OW update of the rest
+                    const int nto = (N - cend + TS - 1) / TS;
+                    hipLaunchKernelGGL(syrk_outer_kernel, dim3(nto, nto, D), dim3(256), 0, s, h->gram.p, N, cend - OW, OW);
+                }
             }
         }
-        if (k0 > 0) {
-            hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb);
+        if (k0 > 0 && !OW) {
+            hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb, 0);
+        }
+    }
+    if (OW) {
+        // Y = L^-1 by 128-row blocks: inside a block the 32-row recursion (columns of the block only) gives Y_KK; the part left
+        // of the block is two tiled products, W = L[K, c:K] Y[c:K, c] (scratch: the iK buffer, written later) and Y[K, c] = -Y_KK W
+        const size_t NN = (size_t)N * N;
+        for (int K0 = 0; K0 < N; K0 += OW) {
+            const int mb = (N - K0 < OW) ? (N - K0) : OW;
+            for (int k0 = K0 + NB; k0 < K0 + mb; k0 += NB) {
+                const int nb = (N - k0 < NB) ? (N - k0) : NB;
+                hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 - K0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb, K0);
+            }
+            if (K0 > 0) {
+                const dim3 grid((K0 + TS - 1) / TS, (mb + TS - 1) / TS, D);
+                hipLaunchKernelGGL(gemm_nn_tiled_kernel, grid, dim3(256), 0, s, h->gram.p + (size_t)K0 * N, N, NN, h->linv.p, N, NN,
+                                   h->iK.p + (size_t)K0 * N, N, NN, mb, K0, K0, 1.0, 1, 0);
+                hipLaunchKernelGGL(gemm_nn_tiled_kernel, grid, dim3(256), 0, s, h->linv.p + (size_t)K0 * N + K0, N, NN,
+                                   h->iK.p + (size_t)K0 * N, N, NN, h->linv.p + (size_t)K0 * N, N, NN, mb, K0, mb, -1.0, 0, 1);
+            }
         }
     }
     GPMPC_HIP_CHECK(h, hipGetLastError());
     hipLaunchKernelGGL(zvec_kernel, dim3((N + 3) / 4, D), dim3(256), 0, s, h->linv.p, Y, N, D, h->zvec.p);
     hipLaunchKernelGGL(beta_kernel, dim3((N + 255) / 256, D), dim3(256), 0, s, h->linv.p, h->zvec.p, N, h->beta.p);
-    const int nt = (N + 31) / 32;
-    hipLaunchKernelGGL(syrk_inverse_kernel, dim3(nt, nt, D), dim3(256), 0, s, h->linv.p, h->beta.p, N, h->iK.p, h->Tm.p);
+    if (N >= 512 && h->opt_outer_block != 0) {
+        const int nt = (N + TS - 1) / TS;
+        hipLaunchKernelGGL(syrk_inverse_tiled_kernel, dim3(nt, nt, D), dim3(256), 0, s, h->linv.p, h->beta.p, N, h->iK.p, h->Tm.p);
+    } else {
+        const int nt = (N + 31) / 32;
+        hipLaunchKernelGGL(syrk_inverse_kernel, dim3(nt, nt, D), dim3(256), 0, s, h->linv.p, h->beta.p, N, h->iK.p, h->Tm.p);
+    }
     GPMPC_HIP_CHECK(h, hipGetLastError());
     if ((rc = check_info(h, D, s))) return rc;
     if (factored) h->have_state = true;           // recorded by the factorisation kernel
