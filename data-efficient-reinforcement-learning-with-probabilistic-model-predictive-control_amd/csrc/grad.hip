@@ -1,5 +1,5 @@
 // grad.hip -- host-side dispatch of the analytic-gradient kernels (grad_kernels.h).
-#include "grad_kernels.h"
+#include "grad_stream_kernel.h"
 #include <cstring>
 
 namespace gpmpc_hip {
@@ -36,6 +36,22 @@ int launch_sweep(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s) 
     hipLaunchKernelGGL(kern, dim3(g.B), dim3(NT), lds_bytes, s, g);
     GPMPC_HIP_CHECK(h, hipGetLastError());
     return GPMPC_OK;
+}
+
+template <int DP, int NXP>
+int launch_moments_stream(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s) {
+    auto kern = pair_moments_stream_kernel<DP, NXP>;
+    int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(g.H, g.B, g.gz), dim3(kGsThreads), lds_bytes, s, g);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    return GPMPC_OK;
+}
+
+template <int DP>
+int launch_moments_stream_dp(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s) {
+    if (g.NXP == 1) return launch_moments_stream<DP, 1>(h, g, lds_bytes, s);
+    return g.NXP == 2 ? launch_moments_stream<DP, 2>(h, g, lds_bytes, s) : launch_moments_stream<DP, 6>(h, g, lds_bytes, s);
 }
 
 template <int DP>
@@ -76,7 +92,7 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     const int sweep_nt = DP <= 4 ? 64 : 256;
     // a small batch leaves most CUs idle: spread the pair groups of each (candidate, step) over up to P workgroups
     int gz = 1;
-    if ((long long)B * H * 2 <= h->num_cu) {
+    if (G > 0 && (long long)B * H * 2 <= h->num_cu) {
         int zmax = h->num_cu / (B * H);
         if (zmax > P) zmax = P;
         const int Gs = (P + zmax - 1) / zmax;            // pairs per workgroup
@@ -89,10 +105,17 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
         if ((size_t)Lp.total * 8 <= 96 * 1024) pre_steps = H;
     }
     const SweepLayout SL = make_sweep_layout(D, A, E, H, NSP, sweep_nt / 64, DP <= 4 ? 0 : kSweepAug, pre_steps);
-    if (G == 0 || (size_t)SL.total * 8 > (size_t)h->lds_limit) {
-        h->err = "gradient: N too large for the LDS-resident gradient kernels"; return GPMPC_ERR_LIMIT;
-    }
-    if ((unsigned long long)RC * NCU * NCU >= 0x100000000ULL || (unsigned long long)G * wpp * wpp >= 0x100000000ULL) {
+    if ((size_t)SL.total * 8 > (size_t)h->lds_limit) { h->err = "gradient: horizon too long for the reverse sweep's LDS"; return GPMPC_ERR_LIMIT; }
+    // memories whose per-point arrays do not fit the LDS (or on request) take the streaming moment pass
+    bool stream = (G == 0) || h->opt_grad_stream == 1;
+    size_t gs_lds = 0;
+    if (stream) {
+        const GsLayout GL = make_gs_layout(N, D, E, DP, NXP, RS, NSP);
+        gs_lds = (size_t)GL.total * 8;
+        if (gs_lds > (size_t)h->lds_limit) { h->err = "gradient: N too large for the column-factor array of the streaming moment pass"; return GPMPC_ERR_LIMIT; }
+        gz = 1;
+        if ((long long)B * H * 2 <= h->num_cu) { gz = h->num_cu / (B * H); if (gz > P) gz = P; }
+    } else if ((unsigned long long)RC * NCU * NCU >= 0x100000000ULL || (unsigned long long)G * wpp * wpp >= 0x100000000ULL) {
         h->err = "gradient: index range too large for the multiply-high division"; return GPMPC_ERR_LIMIT;
     }
     auto magic = [](unsigned d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + d - 1) / d); };
@@ -119,6 +142,15 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     g.magic_N = magic((unsigned)NCU); g.magic_wpp = magic((unsigned)wpp);
 
     g.xrange = h->xrange.p; g.force_path = h->opt_force_path;
+    if (stream) {
+        switch (DP) {
+            case 2:  rc = launch_moments_stream_dp<2>(h, g, gs_lds, s); break;
+            case 3:  rc = launch_moments_stream_dp<3>(h, g, gs_lds, s); break;
+            case 4:  rc = launch_moments_stream_dp<4>(h, g, gs_lds, s); break;
+            case 6:  rc = launch_moments_stream_dp<6>(h, g, gs_lds, s); break;
+            default: rc = launch_moments_stream_dp<8>(h, g, gs_lds, s); break;
+        }
+    } else
     switch (DP) {
         case 2:  rc = launch_moments_dp<2>(h, g, mom_lds, s); break;
         case 3:  rc = launch_moments_dp<3>(h, g, mom_lds, s); break;

@@ -159,8 +159,10 @@ int gpmpc_argmin(gpmpc_t* h, const double* J_dev, int B, long long first_global_
  * scipy as `jac` (:132-139, :285).  Three launches on `stream`: the forward rollout (as gpmpc_rollout),
  * the pairwise moment pass (one workgroup per candidate and horizon step) and the reverse sweep.
  * clip_lower_bound_cost_to_0 clips the value only (the reference's clamp passes the gradient through).
- * mu_out_dev / Sig_out_dev / cost_mu_out_dev / cost_var_out_dev as in gpmpc_rollout (nullable).  Supported for D <= 8, A (+1 with time) <= 6 and N
- * within the LDS-resident kernels; otherwise GPMPC_ERR_LIMIT (callers then difference gpmpc_rollout).
+ * mu_out_dev / Sig_out_dev / cost_mu_out_dev / cost_var_out_dev as in gpmpc_rollout (nullable).  Supported for D <= 8 and A (+1 with
+ * time) <= 6; memories whose per-point arrays exceed the LDS take a streaming moment pass (N up to ~15 000 at D = 4,
+ * ~2 000 at D = 8: the column-factor array and the point chunks must fit); otherwise GPMPC_ERR_LIMIT (callers then
+ * difference gpmpc_rollout).
  */
 int gpmpc_rollout_grad(gpmpc_t* h, const double* actions_dev, const double* mu0_host, const double* S0_host,
                        int B, int H, int A, int include_time, double time0, double* J_out_dev, double* grad_out_dev,

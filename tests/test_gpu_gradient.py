@@ -163,6 +163,63 @@ def test_two_columns_per_lane_variant_agrees(engine):
     assert rel_err(two.cpu().numpy(), one.cpu().numpy()) < 1e-9
 
 
+@pytest.mark.parametrize("N,D,A,H,B,tm,path", [(30, 3, 1, 5, 3, False, 0), (25, 2, 2, 4, 2, True, 0), (70, 4, 2, 3, 2, False, 0),
+                                               (1, 2, 1, 3, 2, False, 0), (65, 1, 1, 4, 2, False, 0), (90, 6, 2, 4, 2, True, 0),
+                                               (40, 8, 3, 3, 2, False, 0), (130, 3, 5, 3, 2, True, 0), (200, 3, 1, 6, 3, False, 0),
+                                               (700, 3, 1, 3, 2, False, 0), (90, 3, 1, 4, 2, False, 1), (45, 6, 2, 3, 2, False, 1),
+                                               (1100, 4, 2, 2, 1, False, 0)])
+def test_streaming_moment_pass_matches_numpy_adjoint(engine, N, D, A, H, B, tm, path):
+    """The moment pass for memories beyond the LDS (grad_stream_kernel.h: points in chunks, row records through a
+    double-buffered stage, per-column accumulators in registers across all row chunks), forced at small N with option
+    grad_stream = 1: ragged N (not a multiple of 64 / 512), N = 1, several passes over the column blocks (N = 1100 at
+    D = 4: 18 column blocks, 16 per pass), padded D, time input, Taylor and direct-exp forms -- vs the numpy adjoint and
+    vs the LDS-resident kernels."""
+    w = synth.make_workload(N, D, A, H, B, include_time=tm, seed=N + D)
+    f = _load_model(engine, w)
+    engine.set_option("grad_stream", 1)
+    engine.set_option("force_path", path)
+    try:
+        out = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+        again = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+    finally:
+        engine.set_option("grad_stream", 0)
+        engine.set_option("force_path", 0)
+    grad = out["grad"].cpu().numpy()
+    assert torch.equal(out["grad"], again["grad"])                    # fixed summation order
+    J, gr, *_ = adjoint.lcb_and_gradient(f, w.actions[0], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
+    assert abs(float(out["J"][0]) - J) < 1e-7 * abs(J)
+    assert rel_err(grad[0], gr) < 1e-7
+    if N <= 700:                                                       # shapes the LDS-resident kernels cover
+        engine.set_option("force_path", path)
+        try:
+            ref = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)["grad"].cpu().numpy()
+        finally:
+            engine.set_option("force_path", 0)
+        assert rel_err(grad, ref) < 2e-7                              # two summation orders of sums with cancellation (N = 700: 8e-8)
+
+
+def test_config4_size_has_an_analytic_gradient(engine):
+    """BASELINE configs[3] (N = 1000, D = 4, A = 2): too large for the LDS-resident moment pass, handled by the streaming
+    one without any option; against 4th-order differences of the forward kernel (H = 4 keeps the difference batch small)."""
+    w = synth.make_workload(1000, 4, 2, 4, 2, seed=3)
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    engine.set_cost(w.target, w.W, w.W_T, w.kappa)
+    out = engine.rollout_grad(w.actions, w.mu0, w.S0)
+    h, n = 1e-3, 4 * 2
+    base = w.actions[0]
+    cand = np.repeat(base[None], 4 * n + 1, axis=0)
+    flat = cand.reshape(4 * n + 1, n)
+    k = np.arange(n)
+    flat[1 + k, k] += h
+    flat[1 + n + k, k] -= h
+    flat[1 + 2 * n + k, k] += 2 * h
+    flat[1 + 3 * n + k, k] -= 2 * h
+    J = engine.rollout(cand, w.mu0, w.S0)["J"].cpu().numpy()
+    fd = (8.0 * (J[1:1 + n] - J[1 + n:1 + 2 * n]) - (J[1 + 2 * n:1 + 3 * n] - J[1 + 3 * n:])) / (12.0 * h)
+    assert abs(float(out["J"][0]) - J[0]) < 1e-12 * abs(J[0])
+    assert rel_err(out["grad"][0].cpu().numpy().reshape(-1), fd) < 1e-4
+
+
 def test_unsupported_shape_is_reported_not_approximated(engine):
     import gp_mpc_amd
     w = synth.make_workload(40, 12, 2, 2, 2, seed=2)
