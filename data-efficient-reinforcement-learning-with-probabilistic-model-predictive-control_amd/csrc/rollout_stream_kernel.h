@@ -144,6 +144,61 @@ __device__ inline double block_mfma_taylor(const double* st, int ntiles, const d
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
 
+// Mid-range form of the same item (|g.w| beyond the Taylor range, up to kTableMaxArg): exp(ka' + kb' + c) =
+// e^ka' e^kb' e^c with the per-point factors already in the row record / column factor (exactly as in the Taylor form),
+// and e^c = T[n] P_6(r), n = round(64 c), r = c - n / 64 (exact), |r| <= 1/128, T[n] = exp(n / 64) tabulated in LDS
+// (1025 entries), truncation r^7 / 5040 <= 3.5e-19: 12 VALU instructions per element where the general fast_exp of the
+// direct form needs 16 plus the two additions that form its argument -- on this part the fp64 vector and matrix
+// instructions share one pipe, so every instruction saved per element is time.  Config 5 spends most of its horizon
+// here (predicted variances ~1e-2 give |g.w| ~ 0.5 .. 4).
+constexpr double kTableMaxArg = 7.99;
+constexpr int kTableHalf = 512;                  // T[kTableHalf + n] = exp(n / 64), |n| <= 512
+
+__device__ inline double table_exp(double c, const double* tab /* centre of the table */) {
+    const double n = __builtin_rint(c * 64.0);
+    const double r = fma(n, -0.015625, c);
+    const double t = tab[(int)n];
+    double q = fma(r, 1.0 / 720, 1.0 / 120);
+    q = fma(q, r, 1.0 / 24);
+    q = fma(q, r, 1.0 / 6);
+    q = fma(q, r, 0.5);
+    q = fma(q, r, 1.0);
+    q = fma(q, r, 1.0);
+    return t * q;
+}
+
+template <int DP, bool DIAG>
+__device__ inline double block_mfma_table(const double* st, int ntiles, const double (&bw)[DP / 4], const double* Tp, int N, int lane,
+                                          const double* tab) {
+    constexpr int RS = DP + 2;
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const double* wrow = st + (size_t)(lane >> 4) * RS;
+    for (int t = 0; t < ntiles; t += 2) {
+        double wt[8];
+        if (DIAG) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                wt[r] = Tp[(size_t)(16 * t + 4 * r) * N];
+                wt[4 + r] = Tp[(size_t)(16 * t + 16 + 4 * r) * N];
+            }
+        }
+        mfma_d4 c0, c1;
+        mfma_c_tiles<DP>(st, t, bw, lane, c0, c1);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double* w0 = wrow + (size_t)(16 * t + 4 * r) * RS;
+            const double* w1 = w0 + 16 * RS;
+            if (DIAG) { wt[r] *= w0[0]; wt[4 + r] *= w1[0]; } else { wt[r] = w0[1]; wt[4 + r] = w1[1]; }
+        }
+        double ev[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { ev[r] = table_exp(c0[r], tab); ev[4 + r] = table_exp(c1[r], tab); }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e & 3] = fma(ev[e], wt[e], acc[e & 3]);
+    }
+    return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
 // Direct form exp(ka'_i + kb'_j + c_ij) of the same item (record [0] = ka'_i, [1] = beta_ai).
 template <int DP, bool DIAG>
 __device__ inline double block_mfma_exp(const double* st, int ntiles, const double (&bw)[DP / 4], double kbj, const double* Tp, int N,
@@ -179,7 +234,7 @@ __device__ inline double block_mfma_exp(const double* st, int ntiles, const doub
 
 struct StreamLayout {
     int mu, Sig, m, M, cc, s1, Vs, Sp, aug, red, kb, stage, ints;
-    int c_ils2, c_logvar, c_var, c_xr, c_act, c_exptab;
+    int c_ils2, c_logvar, c_var, c_xr, c_act, c_exptab, c_etab, ush;
     int total;     // doubles
 };
 
@@ -206,6 +261,8 @@ __host__ __device__ inline StreamLayout make_stream_layout(int N, int D, int A, 
     L.c_xr = o;     o += rnd2(2 * E);
     L.c_act = o;    o += rnd2(HA);
     L.c_exptab = o; o += 64;
+    L.c_etab = o;   o += (DP % 4 == 0 && DP >= 8) ? 2 * kTableHalf + 2 : 0;     // exp(n / 64), |n| <= 512 (matrix-core pair pass only)
+    L.ush = o;      o += (DP == 16) ? 16 * 64 : 0;                                  // per-wavefront hand-off slot of the D = 16 stage fill
     L.total = o;
     return L;
 }
@@ -257,6 +314,11 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
     for (int i = tid0; i < 2 * E; i += NT) c_xr[i] = p.xrange[i];
     for (int i = tid0; i < H * A; i += NT) c_act[i] = act[i];
     for (int i = tid0; i < 64; i += NT) c_exptab[i] = kExp2Tab[i];
+    double* c_etab = smem + L.c_etab + kTableHalf;                     // centre of the table
+    double* s_ush = smem + L.ush;
+    if constexpr (kMfma) {
+        for (int i = tid0; i <= 2 * kTableHalf; i += NT) c_etab[i - kTableHalf] = exp((double)(i - kTableHalf) * 0.015625);
+    }
     __syncthreads();
     for (int i = tid0; i < D; i += NT) p.mu_out[((size_t)c * (H + 1)) * D + i] = s_mu[i];
     for (int i = tid0; i < D * D; i += NT) p.Sig_out[((size_t)c * (H + 1)) * D * D + i] = s_Sig2[i];
@@ -371,10 +433,12 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
                     const double cmax = wave_sum(cpart);
                     if (lane == 0) {
                         s_rdet[0] = 1.0 / sqrt(detR);
-                        int K = 0;
-                        if (p.force_path != 1 && cmax <= kTaylorMaxArg[kMaxTaylor]) {
-                            K = 1;
-                            for (int k = 1; k < kMaxTaylor; ++k) K += (cmax > kTaylorMaxArg[k]) ? 1 : 0;
+                        int K = 0;                                       // 0: direct exp; 1..14: Taylor degree; 15: table form
+                        if (p.force_path != 1) {
+                            if (cmax <= kTaylorMaxArg[kMaxTaylor] && p.force_path != 4) {
+                                K = 1;
+                                for (int k = 1; k < kMaxTaylor; ++k) K += (cmax > kTaylorMaxArg[k]) ? 1 : 0;
+                            } else if (kMfma && cmax <= kTableMaxArg) K = kMaxTaylor + 1;
                         }
                         s_int[0] = K;
                     }
@@ -423,7 +487,57 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
                 }
 
                 // row records of one chunk -> LDS stage; DPC lanes share a row (lane group = one record)
-                auto fill_stage = [&](int r, double* stage) {
+                // D = 16: the 16 lanes of a row share the work -- lane `comp` loads ONE state coordinate (the old form had
+                // every lane load all 20 and spend ~70 instructions on their addresses), u goes through a 64-double LDS
+                // slot per wavefront, g_comp = sum_d Z[d][comp] u_d, and ka' is one DPP row reduction of the per-lane
+                // pieces -1/2 nu u + 1/2 u g
+                auto fill_stage16 = [&](int r, double* stage) {
+                    const int comp = tid & 15;
+                    double* ush = s_ush + wave * 64;
+                    for (int trow = tid >> 4; trow < CH; trow += NT / 16) {
+                        const int i = r * CH + trow;
+                        const bool in = i < N;
+                        const int ic = in ? i : N - 1;
+                        double u = 0.0, piece = 0.0;
+                        if (comp < D) {
+                            const double nu = p.Xt[(size_t)comp * N + ic] - s_m[comp];
+                            u = nu * c_ils2[a * E + comp];
+                            piece = -0.5 * nu * u;
+                        }
+                        if (comp < E - D) {
+                            const double v = p.Xt[(size_t)(D + comp) * N + ic] - s_m[D + comp];
+                            piece = fma(-0.5 * v * v, c_ils2[a * E + D + comp], piece);
+                        }
+                        ush[lane] = u;
+                        wave_lds_sync();
+                        const double* ug = ush + (lane & 48);
+                        double gcomp = 0.0;
+                        if (comp < D) {
+#pragma unroll
+                            for (int d = 0; d < 16; ++d)
+                                if (d < D) gcomp = fma(Z[d * LD + comp], ug[d], gcomp);                  // g = Z^T u
+                        }
+                        wave_lds_sync();                                                               // slot free for the next row group
+                        piece = fma(0.5 * u, gcomp, piece);
+                        piece += dpp_shifted<0x111, 0xf>(piece);                                       // row_shr 1, 2, 4, 8: lane 15 of the
+                        piece += dpp_shifted<0x112, 0xf>(piece);                                       // row holds the sum of its 16 lanes
+                        piece += dpp_shifted<0x114, 0xf>(piece);
+                        piece += dpp_shifted<0x118, 0xf>(piece);
+                        double* rec = stage + (size_t)trow * RS;
+                        rec[2 + comp] = in ? gcomp : 0.0;
+                        if (comp == 15) {
+                            double r0 = 0.0, r1 = 0.0;
+                            if (in) {
+                                const double ka = c_logvar[a] + piece;
+                                const double ba = p.beta[(size_t)a * N + i];
+                                if (K > 0) { r0 = exp(ka); r1 = r0 * ba; } else { r0 = ka; r1 = ba; }
+                            }
+                            rec[0] = r0;
+                            rec[1] = r1;
+                        }
+                    }
+                };
+                auto fill_stage_gen = [&](int r, double* stage) {
                   const int comp = tid % DPC;
                   for (int trow = tid / DPC; trow < CH; trow += NT / DPC) {
                     {
@@ -473,6 +587,9 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
                         }
                     }
                   }
+                };
+                auto fill_stage = [&](int r, double* stage) {
+                    if constexpr (DP == 16) fill_stage16(r, stage); else fill_stage_gen(r, stage);
                 };
                 fill_stage(0, s_stage);
                 __syncthreads();
@@ -528,7 +645,9 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
                                 else if (K <= 8) v = GPMPC_TAYLOR_BLOCK(8);
                                 else if (K <= 10) v = GPMPC_TAYLOR_BLOCK(10);
                                 else if (K <= 12) v = GPMPC_TAYLOR_BLOCK(12);
-                                else v = GPMPC_TAYLOR_BLOCK(14);
+                                else if (K <= 14) v = GPMPC_TAYLOR_BLOCK(14);
+                                else v = diag ? block_mfma_table<DP, true>(rec, ntiles, bw, Tp, N, lane, c_etab)
+                                              : block_mfma_table<DP, false>(rec, ntiles, bw, Tp, N, lane, c_etab);
 #undef GPMPC_TAYLOR_BLOCK
                                 v *= diag ? 2.0 * kbj : kbj;
                             }

@@ -101,7 +101,7 @@ int gpmpc_get_factors(gpmpc_t* h, const double** iK_dev, const double** beta_dev
 int gpmpc_read_factors(gpmpc_t* h, double* iK_dst_dev, double* beta_dst_dev, void* stream);
 
 /* Options (measurement / test hooks): "threads" (rollout workgroup size: 0 = auto, 256/512/1024),
- * "rows_per_chunk", "force_path" (0 auto / 1 direct exp / 2 element-wise Taylor), "force_separable",
+ * "rows_per_chunk", "force_path" (0 auto / 1 direct exp / 2 element-wise Taylor / 4 tabulated mid-range exp in the matrix-core pair pass), "force_separable",
  * "force_global_scratch" (0/1, the large-N streaming kernel at any N), "cols_per_lane" (0 auto, 1, 2: columns per
  * lane in the pairwise pass of the rollout kernel), "grad_cols_per_lane" (same for the gradient's moment pass),
  * "exact_dim" (2: never the compile-time-D kernel instantiation),

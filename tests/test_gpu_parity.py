@@ -399,7 +399,8 @@ def test_padded_and_odd_shapes_against_oracle(engine, N, D, A, H, B, tm):
 def test_matrix_core_pair_pass_against_oracle(engine, N, D, A, H, B, tm, s0):
     """The streaming kernel's pairwise pass on the fp64 matrix cores (padded state dimension 8 or 16; config 5's path),
     forced at small N: ragged N (not a multiple of 16 / 64, N < 16), D below the padded size, time input, input
-    variances that select low and high Taylor degrees and the direct-exp form, each in all three evaluation modes."""
+    variances that select low and high Taylor degrees and the direct-exp form, each in all evaluation modes (0 automatic,
+    1 direct exp, 2 Taylor, 4 the tabulated mid-range form exp(c) = T[round(64 c)] P6(r) forced from |g.w| = 0 up)."""
     w = synth.make_workload(N, D, A, H, B, include_time=tm, seed=300 + N, s0=s0, noise_var=1e-4, time0=float(N) if tm else 0.0)
     f = factors_of(w)
     ref = orc.evaluate_candidates(f, w)
@@ -407,7 +408,7 @@ def test_matrix_core_pair_pass_against_oracle(engine, N, D, A, H, B, tm, s0):
     try:
         engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
         _set_cost(engine, w)
-        for force_path in (0, 1, 2):
+        for force_path in (0, 1, 2, 4):
             engine.set_option("force_path", force_path)
             out = engine.rollout(w.actions, w.mu0, w.S0, w.include_time, w.time0)
             tag = (N, D, force_path)
