@@ -943,7 +943,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
         GPMPC_HIP_CHECK(h, hipMemsetAsync(h->info, 0, kMaxD * sizeof(int), s));
         GPMPC_HIP_CHECK(h, hipMemsetAsync(h->linv.p, 0, (size_t)D * N * N * sizeof(double), s));
     }
-    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->Tm.p, 0, (size_t)D * (N + kTPadRows) * N * sizeof(double), s));
+    if (!factored) GPMPC_HIP_CHECK(h, hipMemsetAsync(h->Tm.p, 0, (size_t)D * (N + kTPadRows) * N * sizeof(double), s));
     if (!factored) {
         const dim3 grid((N + 63) / 64, (N + 63) / 64, D);
         if (E <= 4) hipLaunchKernelGGL(gram_kernel<4>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
@@ -975,7 +975,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
                 }
             }
         }
-        if (k0 > 0 && !OW) {
+        if (k0 > 0 && !OW && !factored) {
             hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb, 0);
         }
     }

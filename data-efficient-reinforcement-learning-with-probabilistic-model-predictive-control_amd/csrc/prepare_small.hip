@@ -273,7 +273,11 @@ __global__ __launch_bounds__(1024) void prepare_small_kernel(const SmallPrepArgs
     }
 
     SMALL_STAMP();
-    if (p.cholesky_only) return;
+    if (p.cholesky_only) {
+        // T_a := 0 (its upper triangle is filled by the Y^T Y launch that follows): saves the memset launch
+        for (int idx = tid; idx < (N + kSTPad) * N; idx += 1024) T[idx] = 0.0;
+        return;
+    }
     // ---- P3: Y = L^-1 by row blocks: Y[k, c] = -Ykk (L[k, :k] Y[:k, c]) for c < k ------------------------------------------
     for (int k0 = kSB; k0 < N; k0 += kSB) {
         const int nb = (N - k0 < kSB) ? (N - k0) : kSB;
@@ -388,8 +392,48 @@ __global__ __launch_bounds__(1024) void prepare_small_kernel(const SmallPrepArgs
 #endif
 }
 
-// Host side: returns 1 when the fused path handled the whole call (N <= 256), 2 when it did the factorisation and the caller
-// has to run the products (run_prepare's tail), 0 to fall through, < 0 on error.
+// Y = L^-1 below the diagonal blocks, ONE launch: workgroup (cb, a) owns the 32-column block cb of Y_a and walks down its
+// row blocks, Y[k, cb] = -Y_kk (L[k, cb:k] Y[cb:k, cb]) -- each step only needs rows of its own column block, which it
+// wrote itself, so there is no dependence between workgroups (the row-block form of prepare.hip needs one launch per
+// row block: 6 dependent launches at N = 200).  4 wavefronts = the 2 x 2 tiles of a 32 x 32 block.
+__global__ __launch_bounds__(256) void trinv_cols_small_kernel(const double* __restrict__ Lall, double* __restrict__ Yall, int N) {
+    __shared__ double Ws[kSB * 33];
+    const int a = blockIdx.y, c0 = blockIdx.x * kSB;
+    const double* L = Lall + (size_t)a * N * N;
+    double* Y = Yall + (size_t)a * N * N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
+    for (int k0 = c0 + kSB; k0 < N; k0 += kSB) {
+        const int nb = (N - k0 < kSB) ? (N - k0) : kSB;
+        sd4 acc = {0.0, 0.0, 0.0, 0.0};
+        const bool rowin = (wi + li < nb);
+        const double* Ar = L + (size_t)(k0 + (rowin ? wi + li : 0)) * N;
+        const double* Bc = Y + c0 + wj + li;                          // c0 + 31 < k0 <= N: always inside
+        mfma_kloop<16>(acc, c0, k0, lk, [&](int pk) { return rowin ? Ar[pk] : 0.0; }, [&](int pk) { return Bc[(size_t)pk * N]; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Ws[(wi + lk + 4 * r) * 33 + wj + li] = acc[r];
+        __syncthreads();
+        sd4 acc2 = {0.0, 0.0, 0.0, 0.0};
+        const double* Yk = Y + (size_t)(k0 + (rowin ? wi + li : 0)) * N + k0;
+#pragma unroll
+        for (int kk = 0; kk < kSB; kk += 4) {
+            const int m = kk + lk;
+            const double av = (rowin && m < nb) ? Yk[m] : 0.0;
+            acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Ws[m * 33 + wj + li], acc2, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = wi + lk + 4 * r;
+            if (row < nb) Y[(size_t)(k0 + row) * N + c0 + wj + li] = -acc2[r];
+        }
+        __syncthreads();                                             // rows k0.. of this column block are read by the next step
+    }
+}
+
+// Host side: returns 1 when the fused path handled the whole call (N <= 256), 2 when it did the factorisation, the
+// triangular inverse and the zero fill of T, and the caller has to run beta and Y^T Y (run_prepare's tail), 0 to fall
+// through, < 0 on error.
 int run_prepare_small(Handle* h, const double* X, const double* Y, const double* ls, const double* os, const double* noise,
                       int N, int D, int E, hipStream_t s) {
     if (N > kSmallMaxN || N < 1 || h->opt_fused_prepare == 0) return 0;
@@ -414,6 +458,8 @@ int run_prepare_small(Handle* h, const double* X, const double* Y, const double*
         if (rc) return rc;
     }
     hipLaunchKernelGGL(prepare_small_kernel, dim3(D), dim3(1024), lds, s, p);
+    if (p.cholesky_only && N > kSB)
+        hipLaunchKernelGGL(trinv_cols_small_kernel, dim3((N + kSB - 1) / kSB - 1, D), dim3(256), 0, s, h->gram.p, h->linv.p, N);
     GPMPC_HIP_CHECK(h, hipGetLastError());
     return p.cholesky_only ? 2 : 1;
 }

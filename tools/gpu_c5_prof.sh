@@ -16,3 +16,5 @@ done
 cd $REPO
 python tools/rocpd_summary.py pmc $DBS > $OUT/c5_pmc.txt
 grep stream $OUT/c5_pmc.txt | cut -c1-30,70-140
+# the sqlite outputs are tens of MB each: only the text summaries travel back (gpurun merges at most 64 MiB)
+(cd $OUT && rm -rf c5_pmc_SQ_WAVES c5_pmc_SQ_WAIT_INST_LDS)

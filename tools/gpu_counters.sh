@@ -25,3 +25,5 @@ python tools/rocpd_summary.py pmc $DBS > $OUT/${TAG}_pmc.txt
 python tools/rocpd_summary.py json $KEY $KSUB $DBS | cut -c1-300
 cp profiles/pmc_counters.json profiles/pmc_traffic.json $OUT/
 head -6 $OUT/${TAG}_kernel_trace_stats.txt | cut -c1-150
+# the sqlite outputs are tens of MB each: only the text summaries travel back (gpurun merges at most 64 MiB)
+(cd $OUT && rm -rf ${TAG}_trace ${TAG}_pmc_*)

@@ -9,3 +9,5 @@ cd $REPO
 python tools/rocpd_summary.py trace $OUT/prep_trace/prep_results.db > $OUT/prep_kernel_trace_stats.txt
 python tools/rocpd_summary.py pmc $OUT/prep_pmc_mfma/prep_results.db $OUT/prep_pmc_write/prep_results.db $OUT/prep_pmc_fetch/prep_results.db > $OUT/prep_pmc.txt
 cut -c1-150 $OUT/prep_kernel_trace_stats.txt | head -16; grep -E "gram_kernel|syrk|trinv" $OUT/prep_pmc.txt | cut -c1-40,70-140
+# the sqlite outputs are tens of MB each: only the text summaries travel back (gpurun merges at most 64 MiB)
+(cd $OUT && rm -rf prep_trace prep_pmc_mfma prep_pmc_write prep_pmc_fetch)
