@@ -200,6 +200,103 @@ __global__ __launch_bounds__(256) void trsm_panel_kernel(double* __restrict__ Ka
         if (c < nb) rp[c] = x[c];
 }
 
+// Diagonal block of a panel, round 2: the same arrangement as prepare_small.hip's pivot loop.  Thread (row rr, column c)
+// owns element (rr, c) of the 32 x 32 block and of the 32 x 32 identity under it; 1 / sqrt(pivot) from an fp32 v_rsq seed +
+// two Newton steps (6 dependent fp64 operations instead of ~35 for sqrt + divide -- a dependent v_fma_f64 issues only every
+// ~40 cycles on this part), computed by the owner of the NEXT pivot right after its own update: one barrier per pivot;
+// columns are never divided, L is scaled on the way out; the identity comes out as L11^-T, i.e. the block's inverse that
+// the panel solve and the triangular inverse use.  25 -> ~9 us per panel.
+__device__ inline double inv_sqrt_pos_p(double d) {
+    double y = (double)__builtin_amdgcn_rsqf((float)d);
+    const double h = 0.5 * d;
+    y = y * fma(-h * y, y, 1.5);
+    y = y * fma(-h * y, y, 1.5);
+    return y;
+}
+
+__global__ __launch_bounds__(NB * NB) void potrf_diag_fast_kernel(double* __restrict__ Kall, double* __restrict__ Yall,
+                                                                 int N, int k0, int nb, int* __restrict__ info) {
+    __shared__ double colb[2][2 * NB];
+    __shared__ double sinv[NB];
+    const int a = blockIdx.x;
+    double* K = Kall + (size_t)a * N * N;
+    double* Y = Yall + (size_t)a * N * N;
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const int c = tid >> 5, r = tid & 31;                    // column-major over the wavefronts: wave w <-> columns 2w, 2w + 1
+    double a0 = (r < nb && c < nb && c <= r) ? K[(size_t)(k0 + r) * N + (k0 + c)] : 0.0;
+    double a1 = (r == c) ? 1.0 : 0.0;
+    if (c == 0) { colb[0][r] = a0; colb[0][NB + r] = a1; }
+    if (tid == 0) {
+        if (!(a0 > 0.0) && info[a] == 0) info[a] = k0 + 1;
+        sinv[0] = inv_sqrt_pos_p(a0);
+    }
+    if (tid >= nb && tid < NB) sinv[tid] = 0.0;
+    __syncthreads();
+    for (int k = 0; k + 1 < nb; ++k) {
+        if (2 * wave + 1 > k) {                              // wave-uniform: both columns of a finished wave are final
+            const double* cb = colb[k & 1];
+            double* cn = colb[(k + 1) & 1];
+            const double inv = sinv[k];
+            if (c > k && c < nb) {
+                const double lc = cb[c] * inv;
+                a0 = fma(-(cb[r] * inv), lc, a0);
+                a1 = fma(-(cb[NB + r] * inv), lc, a1);
+                if (c == k + 1) {
+                    cn[r] = a0;
+                    cn[NB + r] = a1;
+                    if (r == k + 1) {
+                        if (!(a0 > 0.0) && info[a] == 0) info[a] = k0 + k + 2;
+                        sinv[k + 1] = inv_sqrt_pos_p(a0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const double sc = sinv[c];                               // 0 for c >= nb
+    if (r < nb && c <= r) K[(size_t)(k0 + r) * N + k0 + c] = a0 * sc;
+    if (r < nb && c < nb) Y[(size_t)(k0 + c) * N + k0 + r] = (r <= c) ? a1 * sc : 0.0;       // row r of the identity -> column r of Y11
+}
+
+// Panel solve on the matrix cores: L21 = A21 Y11^T (Y11 = the block's inverse written by potrf_diag_fast_kernel).
+// One workgroup = 64 rows (a 16-row tile per wavefront, both 16-column halves); memory-bound: M x 32 in, M x 32 out.
+__global__ __launch_bounds__(256) void trsm_panel_mfma_kernel(double* __restrict__ Kall, const double* __restrict__ Yall,
+                                                              int N, int k0, int nb) {
+    __shared__ double yt[NB][NB + 1];                        // yt[k][j] = Y11[j][k]
+    const int a = blockIdx.y;
+    double* K = Kall + (size_t)a * N * N;
+    const double* Y = Yall + (size_t)a * N * N;
+    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+        const int j = idx / NB, k = idx % NB;
+        yt[k][j] = (j < nb && k <= j) ? Y[(size_t)(k0 + j) * N + k0 + k] : 0.0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int i0 = k0 + nb + blockIdx.x * 64 + wave * 16;
+    if (i0 >= N) return;
+    const int ri = i0 + li;
+    const double* Ar = K + (size_t)(ri < N ? ri : N - 1) * N + k0;
+    double av[NB / 4];
+#pragma unroll
+    for (int q = 0; q < NB / 4; ++q) av[q] = (ri < N && 4 * q + lk < nb) ? Ar[4 * q + lk] : 0.0;
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < NB / 4; ++q) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], yt[4 * q + lk][li], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], yt[4 * q + lk][16 + li], acc1, 0, 0, 0);
+    }
+    // every lane of the wavefront has read its A values before any lane stores (same wavefront: program order)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = i0 + lk + 4 * r;
+        if (row < N) {
+            if (li < nb) K[(size_t)row * N + k0 + li] = acc0[r];
+            if (16 + li < nb) K[(size_t)row * N + k0 + 16 + li] = acc1[r];
+        }
+    }
+}
+
 // Trailing update A22 -= L21 L21^T on the lower triangle; 32x32 block per workgroup, one
 // 16x16 fp64 MFMA tile per wave.
 __global__ __launch_bounds__(256) void syrk_trailing_kernel(double* __restrict__ Kall, int N, int k0, int nb, int cend) {
@@ -959,10 +1056,13 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     for (int k0 = 0; k0 < N; k0 += NB) {
         const int nb = (N - k0 < NB) ? (N - k0) : NB;
         if (!factored) {
-            hipLaunchKernelGGL(potrf_diag_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
+            const bool fast = h->opt_outer_block != 0;           // round-2 panel kernels (option "outer_block" = 0: the round-1 ones)
+            if (fast) hipLaunchKernelGGL(potrf_diag_fast_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
+            else hipLaunchKernelGGL(potrf_diag_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
             const int M = N - k0 - nb;
             if (M > 0) {
-                hipLaunchKernelGGL(trsm_panel_kernel, dim3((M + 255) / 256, D), dim3(256), 0, s, h->gram.p, N, k0, nb);
+                if (fast) hipLaunchKernelGGL(trsm_panel_mfma_kernel, dim3((M + 63) / 64, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb);
+                else hipLaunchKernelGGL(trsm_panel_kernel, dim3((M + 255) / 256, D), dim3(256), 0, s, h->gram.p, N, k0, nb);
                 int cend = N;
                 if (OW) { cend = (k0 / OW + 1) * OW; if (cend > N) cend = N; }
                 const int nt = (M + 31) / 32;

@@ -242,8 +242,10 @@ def test_cross_entropy_search_beats_random_shooting(engine):
     assert a.shape == (1,) and 0.0 <= a[0] <= 1.0
 
 
-def test_closed_loop_pendulum_with_training_process(engine):
-    """run_env on an own pendulum: random warm-up, memory admission, one spawned GP training, MPC steps."""
+@pytest.mark.parametrize("search", ["shooting", "cem_device"])
+def test_closed_loop_pendulum_with_training_process(engine, search):
+    """run_env on an own pendulum: random warm-up, memory admission, one spawned GP training, MPC steps -- with the
+    reference-style random shooting and with the device-resident search behind the action-change mapper."""
     import gp_mpc_amd  # noqa: F401
     from gp_mpc_amd.config_classes import (Config, ControllerConfig, ActionsConfig, RewardConfig, ObservationConfig,
                                            MemoryConfig, ModelConfig, TrainingConfig)
@@ -254,18 +256,20 @@ def test_closed_loop_pendulum_with_training_process(engine):
         reward_config=RewardConfig(target_state_norm=[1, 0.5, 0.5], weight_state=[1, 0.1, 0.1],
                                    weight_state_terminal=[5, 2, 2], target_action_norm=[0.5], weight_action=[1e-3],
                                    exploration_factor=1),
-        actions_config=ActionsConfig(False, [0.3]),
+        actions_config=ActionsConfig(search == "cem_device", [0.3]),
         model_config=ModelConfig(gp_init={"noise_covar.noise": [1e-5] * 3, "base_kernel.lengthscale": [0.5] * 3,
                                           "outputscale": [5e-2] * 3}, min_std_noise=1e-3, max_std_noise=1e-2,
                                  min_outputscale=1e-2, max_lengthscale=10.0),
         memory_config=MemoryConfig(True, [3e-4] * 3, [3e-3] * 3, points_batch_memory=64),
         training_config=TrainingConfig(lr_train=7e-3, iter_train=3, training_frequency=8),
-        controller_config=ControllerConfig(len_horizon=8, restarts_optim=128, optimize=False))
+        controller_config=ControllerConfig(len_horizon=8, restarts_optim=128, optimize=(search != "shooting"),
+                                           candidate_optimizer=None if search == "shooting" else search,
+                                           cem_candidates=64, cem_iterations=3))
     np.random.seed(0)
     costs, ctrl = run_env(PendulumEnv(seed=0), cfg, None, random_actions_init=5, num_steps=22, verbose=False, engine=engine)
     assert costs.shape == (22,) and np.isfinite(costs).all()
     assert ctrl.memory.len_mem == 22 and ctrl.memory.len_mem_model >= 5
-    assert ctrl.num_rollouts >= 5 + 17 * 128
+    assert ctrl.num_rollouts >= 5 + 17 * (128 if search == "shooting" else 64 * 3 + 1)
     assert len(ctrl.info_iters["cost"]) == 22
     ls = ctrl.transition_model.lengthscales
     assert ls.shape == (3, 4) and torch.isfinite(ls).all()
