@@ -92,6 +92,12 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
+    # Exactly ONE line goes to stdout: native libraries (RCCL prints a version banner to fd 1 when its communicator comes up)
+    # are pointed at stderr for the duration of the run; the JSON line is printed after stdout has been restored.
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -379,10 +385,22 @@ def main():
                     except Exception as e:   # the checker must not take the bench line down
                         result["gradient"]["cpu_baseline"] = {"error": repr(e)}
             result["speedup_vs_cpu_baseline"] = result["value"] / result["cpu_baseline"]["value"]
-        print(json.dumps(result))
+        line = json.dumps(result)
+    else:
+        line = None
     eng.close()
     if dist.is_initialized():
         dist.destroy_process_group()
+    sys.stdout.flush()
+    try:                                    # C stdio buffers too (RCCL's banner sits in one until exit when fd 1 is a pipe)
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    os.dup2(stdout_fd, 1)
+    os.close(stdout_fd)
+    if line is not None:
+        print(line, flush=True)
 
 
 if __name__ == "__main__":

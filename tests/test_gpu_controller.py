@@ -322,3 +322,23 @@ def test_training_on_the_gpu_follows_the_cpu_expression():
     for a in range(2):
         for k in res["cpu"][a]:
             assert rel_err(np.asarray(res["hip"][a][k]), np.asarray(res["cpu"][a][k])) < 1e-4, (a, k)
+
+
+@pytest.mark.parametrize("args,scaling", [(["--steps", "3", "--warmup", "1"], "weak"),
+                                          (["--workload", "c4", "--candidates-total", "256", "--steps", "2", "--warmup", "1"], "strong")])
+def test_bench_line_with_the_process_group_initialised(args, scaling):
+    """bench.py through its N > 1 code path on one rank (`--force-dist`: RCCL initialised, the per-rank record goes through
+    all_gather_into_tensor and the ROCTx-marked gather): the contract fields, the scaling mode and the parity spot check."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--no-cpu-baseline"] + args,
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(out.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 1 and d["scaling"] == scaling and d["value"] > 0 and d["unit"] == "rollouts/s"
+    assert abs(d["value"] - d["config"]["B_total"] / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-9
+    assert d["roofline"]["frac"] > 0 and d["parity"]["max_rel_cov"] < 1e-5 and d["parity"]["max_abs_dmean"] < 1e-8
