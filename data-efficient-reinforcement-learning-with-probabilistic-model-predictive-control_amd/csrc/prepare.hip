@@ -75,6 +75,63 @@ __global__ __launch_bounds__(256) void xrange_kernel(const double* __restrict__ 
     }
 }
 
+// pack_inputs + xrange + the record of (X, Y, hyper-parameters) the factors are computed from, in ONE launch (they were
+// 2 kernels + 5 device-to-device copies: at small N every launch is ~5 us of a 0.1-0.2 ms call).  Blocks e < E also reduce
+// the data range of input dimension e.
+__global__ __launch_bounds__(256) void pack_record_kernel(const double* __restrict__ X, const double* __restrict__ Y,
+                                                          const double* __restrict__ ls, const double* __restrict__ os,
+                                                          const double* __restrict__ noise, int N, int D, int E,
+                                                          double* __restrict__ Xt, double* __restrict__ ils2, double* __restrict__ var,
+                                                          double* __restrict__ logvar, double* __restrict__ xr,
+                                                          double* __restrict__ Xc, double* __restrict__ Yc, double* __restrict__ hyp) {
+    const int stride = gridDim.x * 256;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < N * E; idx += stride) {
+        const int e = idx / N, pt = idx - e * N;
+        Xt[idx] = X[(size_t)pt * E + e];
+        Xc[idx] = X[idx];
+    }
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < N * D; idx += stride) Yc[idx] = Y[idx];
+    if (blockIdx.x == 0) {
+        for (int idx = threadIdx.x; idx < D * E; idx += 256) { const double l = ls[idx]; ils2[idx] = 1.0 / (l * l); hyp[idx] = l; }
+        if (threadIdx.x < D) {
+            var[threadIdx.x] = os[threadIdx.x]; logvar[threadIdx.x] = log(os[threadIdx.x]);
+            hyp[(size_t)D * E + threadIdx.x] = os[threadIdx.x];
+            hyp[(size_t)D * E + kMaxD + threadIdx.x] = noise[threadIdx.x];
+        }
+    }
+    if ((int)blockIdx.x < E) {
+        __shared__ double smin[4], smax[4];
+        const int e = blockIdx.x;
+        double lo = INFINITY, hi = -INFINITY;
+        for (int pt = threadIdx.x; pt < N; pt += 256) { const double v = X[(size_t)pt * E + e]; lo = fmin(lo, v); hi = fmax(hi, v); }
+        for (int off = 32; off >= 1; off >>= 1) { lo = fmin(lo, __shfl_xor(lo, off, 64)); hi = fmax(hi, __shfl_xor(hi, off, 64)); }
+        if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            xr[e] = fmin(fmin(smin[0], smin[1]), fmin(smin[2], smin[3]));
+            xr[E + e] = fmax(fmax(smax[0], smax[1]), fmax(smax[2], smax[3]));
+        }
+    }
+}
+
+// Is the cached (X, Y, hyper-parameters) a prefix of the new one?  One launch over the five arrays; `flag` is zero when
+// idle (the host clears it again after a mismatch).
+__global__ __launch_bounds__(256) void prefix_mismatch_all_kernel(const double* __restrict__ X, const double* __restrict__ Xc, size_t nX,
+                                                                  const double* __restrict__ Y, const double* __restrict__ Yc, size_t nY,
+                                                                  const double* __restrict__ ls, const double* __restrict__ os,
+                                                                  const double* __restrict__ noise, const double* __restrict__ hyp,
+                                                                  int D, int E, int* __restrict__ flag) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nX; i += stride) bad |= (X[i] != Xc[i]);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nY; i += stride) bad |= (Y[i] != Yc[i]);
+    if (blockIdx.x == 0) {
+        for (int i = threadIdx.x; i < D * E; i += 256) bad |= (ls[i] != hyp[i]);
+        if ((int)threadIdx.x < D) bad |= (os[threadIdx.x] != hyp[(size_t)D * E + threadIdx.x]) || (noise[threadIdx.x] != hyp[(size_t)D * E + kMaxD + threadIdx.x]);
+    }
+    if (bad) *flag = 1;
+}
+
 // K_a = outputscale_a exp(-1/2 sum_e ((x_ie - x_je)/l_ae)^2) + noise_a I, 64 x 64 tiles of the upper block
 // triangle (tj >= ti); the mirror tile is written through an LDS transpose, so every store is a coalesced
 // 512-byte row segment and every element is computed once.  Lane = column j (its x_j / l_a in registers),
@@ -329,10 +386,18 @@ __global__ __launch_bounds__(256) void syrk_trailing_kernel(double* __restrict__
 }
 
 // Row block k of Y = L^-1:  Y[k, c] = -Ykk * (sum_p L[k, p] Y[p, c]) for column tiles c < k0.
+// blocks > 0: one launch for ALL outer blocks of `blocks` rows (blockIdx.z = outer block K): row block k0 = K + koff of
+// each, columns [K, k0) only -- the diagonal blocks Y_KK of the recursive-doubling inverse below.
 __global__ __launch_bounds__(256) void trinv_row_kernel(const double* __restrict__ Kall, double* __restrict__ Yall,
-                                                        int N, int k0, int nb, int cbeg) {
+                                                        int N, int k0, int nb, int cbeg, int blocks, int koff) {
     __shared__ double w[32][33];
     __shared__ double ykk[NB][NB + 1];
+    if (blocks > 0) {
+        cbeg = blockIdx.z * blocks;
+        k0 = cbeg + koff;
+        nb = (N - k0 < NB) ? (N - k0) : NB;
+        if (nb <= 0) return;
+    }
     const int a = blockIdx.y;
     const double* L = Kall + (size_t)a * N * N;
     double* Y = Yall + (size_t)a * N * N;
@@ -575,6 +640,283 @@ __global__ __launch_bounds__(256) void syrk_inverse_tiled_kernel(const double* _
             }
 }
 
+// ---- 128 x 128 tiles, 8 wavefronts -------------------------------------------------------------------------------------
+// A 64 x 64 tile moves 16 bytes per 16 multiply-adds through the L2: at N = 4096, D = 16 the three products above pull
+// ~3.7 TB/s and sit at 37-40 % of the matrix peak with the matrix pipe idle 60 % of the time.  128 x 128 tiles halve the
+// bytes per flop: 8 wavefronts, each a 32 x 64 sub-tile (2 x 4 MFMA tiles: 6 LDS reads per 8 MFMAs), 32-deep slices, the
+// next slice travelling in registers while the current one is multiplied (64 MFMAs = 4096 matrix-pipe cycles per wavefront
+// and slice against one pair of barriers).  Addresses: one uniform base pointer per operand advanced by scalar adds plus
+// per-thread 32-bit offsets computed once; full slices are loaded unmasked, only the last one compares.
+constexpr int T2 = 128;
+constexpr int SI2 = KC + 2;        // i-major slice: 128 rows x 32 k, stride 34
+constexpr int SK2 = T2 + 16;       // k-major slice: 32 k x 128 columns, stride 144 (144 mod 32 = 16: see SK)
+
+// lower-triangle tile (ti >= tj) number t -> (ti, tj), row by row
+__device__ inline void tri_tile(int t, int& ti, int& tj) {
+    int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((r + 1) * (r + 2) / 2 <= t) ++r;
+    while (r * (r + 1) / 2 > t) --r;
+    ti = r; tj = t - r * (r + 1) / 2;
+}
+
+// 8 k-steps of one slice: As / Bs fragment base pointers already include the wavefront and lane offsets
+template <int ASTEP, int AROW, int BSTEP, int BROW>
+__device__ inline void slice_mfma_2x4(d4 (&acc)[2][4], const double* __restrict__ Af, const double* __restrict__ Bf) {
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 4) {
+        const double a0 = Af[kk * ASTEP], a1 = Af[kk * ASTEP + 16 * AROW];
+        const double b0 = Bf[kk * BSTEP], b1 = Bf[kk * BSTEP + 16 * BROW], b2 = Bf[kk * BSTEP + 32 * BROW], b3 = Bf[kk * BSTEP + 48 * BROW];
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b1, acc[0][1], 0, 0, 0);
+        acc[0][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b2, acc[0][2], 0, 0, 0);
+        acc[0][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b3, acc[0][3], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
+        acc[1][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b2, acc[1][2], 0, 0, 0);
+        acc[1][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b3, acc[1][3], 0, 0, 0);
+    }
+}
+
+// iK = Y^T Y and T = beta beta^T - iK as in syrk_inverse_tiled_kernel, 128 x 128 tiles of the lower triangle.  1-D grid:
+// workgroup id -> XCD id & 7 (round-robin dispatch); every XCD works through whole GPs (a, a + 8, ...) tile row by tile row,
+// so that the workgroups sharing its L2 read the same column blocks of the same Y.
+__global__ __launch_bounds__(512) void syrk_inverse_t128_kernel(const double* __restrict__ Yall, const double* __restrict__ beta,
+                                                                int N, int D, int ntile, double* __restrict__ iKall,
+                                                                double* __restrict__ Tall) {
+    __shared__ double As[KC * SK2];
+    __shared__ double Bs[KC * SK2];
+    int a, t;
+    {
+        const int id = blockIdx.x, x = id & 7, l = id >> 3;
+        // GPs a = x, x + 8, ... on XCD x (D need not be a multiple of 8: ids past the end fall out below)
+        a = x + 8 * (l / ntile);
+        t = l - (l / ntile) * ntile;
+        if (a >= D) return;
+    }
+    int ti, tj;
+    tri_tile(t, ti, tj);
+    const double* Y = Yall + (size_t)a * N * N;
+    double* iK = iKall + (size_t)a * N * N;
+    double* T = Tall + (size_t)a * (N + kTPadRows) * N;
+    const double* be = beta + (size_t)a * N;
+    const int i0 = ti * T2, j0 = tj * T2;                            // j0 <= i0
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 64;
+    // staging: element e = 512 u + tid of the 32 x 128 slice, k = e / 128 = 4 u + sp, column e % 128
+    const int sp = tid >> 7, scol = tid & 127;
+    const unsigned ca = (unsigned)((i0 + scol < N) ? i0 + scol : N - 1), cb = (unsigned)((j0 + scol < N) ? j0 + scol : N - 1);
+    const unsigned offa = (unsigned)sp * (unsigned)N + ca, offb = (unsigned)sp * (unsigned)N + cb;
+    d4 acc[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = {0.0, 0.0, 0.0, 0.0};
+    double av[8], bv[8];
+    const int nfull = i0 + ((N - i0) / KC) * KC;                     // slices [i0, nfull) are complete
+    auto fetch = [&](int p0) {
+        const double* Yp = Y + (size_t)p0 * N;
+        if (p0 < nfull) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { av[u] = Yp[(size_t)(4 * u) * N + offa]; bv[u] = Yp[(size_t)(4 * u) * N + offb]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool in = p0 + 4 * u + sp < N;
+                av[u] = in ? Yp[(size_t)(4 * u) * N + offa] : 0.0;
+                bv[u] = in ? Yp[(size_t)(4 * u) * N + offb] : 0.0;
+            }
+        }
+    };
+    const double* Af = As + lk * SK2 + wi + li;
+    const double* Bf = Bs + lk * SK2 + wj + li;
+    double* Aw = As + sp * SK2 + scol;
+    double* Bw = Bs + sp * SK2 + scol;
+    fetch(i0);
+    for (int p0 = i0; p0 < N; p0 += KC) {                            // rows p < i0 of the A columns are zero
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { Aw[4 * u * SK2] = av[u]; Bw[4 * u * SK2] = bv[u]; }
+        __syncthreads();
+        if (p0 + KC < N) fetch(p0 + KC);
+        slice_mfma_2x4<SK2, 1, SK2, 1>(acc, Af, Bf);
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wi + 16 * x + lk + 4 * r, col = j0 + wj + 16 * y + li;
+                if (row < N && col < N && col <= row) {
+                    const double v = acc[x][y][r];
+                    double tt = be[row] * be[col] - v;
+                    if (row == col) tt *= 0.5;
+                    iK[(size_t)row * N + col] = v;
+                    T[(size_t)col * N + row] = tt;                   // upper triangle only; the rest stays zero
+                    if (row != col) iK[(size_t)col * N + row] = v;
+                }
+            }
+}
+
+// Trailing update of the outer-blocked Cholesky as in syrk_outer_kernel, 128 x 128 tiles of the lower triangle (w is a
+// multiple of 32).  Same 1-D grid / XCD mapping as syrk_inverse_t128_kernel.
+__global__ __launch_bounds__(512) void syrk_outer_t128_kernel(double* __restrict__ Kall, int N, int D, int ntile, int k0, int w) {
+    __shared__ double As[T2 * SI2];
+    __shared__ double Bs[T2 * SI2];
+    int a, t;
+    {
+        const int id = blockIdx.x, x = id & 7, l = id >> 3;
+        a = x + 8 * (l / ntile);
+        t = l - (l / ntile) * ntile;
+        if (a >= D) return;
+    }
+    int ti, tj;
+    tri_tile(t, ti, tj);
+    double* K = Kall + (size_t)a * N * N;
+    const int r0 = k0 + w;
+    const int i0 = r0 + ti * T2, j0 = r0 + tj * T2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 64;
+    // staging: element e = 512 u + tid of the 128 x 32 slice, row e / 32 = 16 u + srow, k = e % 32
+    const int srow = tid >> 5, sk = tid & 31;
+    unsigned offa[8], offb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int row = 16 * u + srow;
+        const int ra = (i0 + row < N) ? i0 + row : N - 1, rb = (j0 + row < N) ? j0 + row : N - 1;
+        offa[u] = (unsigned)ra * (unsigned)N + (unsigned)sk;
+        offb[u] = (unsigned)rb * (unsigned)N + (unsigned)sk;
+    }
+    d4 acc[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = {0.0, 0.0, 0.0, 0.0};
+    double av[8], bv[8];
+    auto fetch = [&](int p0) {
+        const double* Kp = K + k0 + p0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { av[u] = Kp[offa[u]]; bv[u] = Kp[offb[u]]; }
+    };
+    const double* Af = As + (wi + li) * SI2 + lk;
+    const double* Bf = Bs + (wj + li) * SI2 + lk;
+    double* Aw = As + srow * SI2 + sk;
+    double* Bw = Bs + srow * SI2 + sk;
+    fetch(0);
+    for (int p0 = 0; p0 < w; p0 += KC) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { Aw[16 * u * SI2] = av[u]; Bw[16 * u * SI2] = bv[u]; }
+        __syncthreads();
+        if (p0 + KC < w) fetch(p0 + KC);
+        slice_mfma_2x4<1, SI2, 1, SI2>(acc, Af, Bf);
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wi + 16 * x + lk + 4 * r, col = j0 + wj + 16 * y + li;
+                if (row < N && col <= row) K[(size_t)row * N + col] -= acc[x][y][r];
+            }
+}
+
+// Batched C = alpha A B on 128 x 128 tiles: A (M x Kd) row-major (i-major staging), B (Kd x NC) row-major (k-major staging).
+// Batch z = a * nq + q: operand blocks at base + a * s? + q * q?; the last q has M_last (> 0) rows, the others M rows.
+// kskip: B is lower triangular (k starts at the column tile); ktri: A is lower triangular (k ends with the row tile).
+// 1-D grid with the XCD mapping of the kernels above (batches are dealt to the XCDs).
+struct GemmBatch {
+    const double* A; int lda; size_t sa, qa;
+    const double* B; int ldb; size_t sb, qb;
+    double* C; int ldc; size_t sc, qc;
+    int nq, nbatch, M, M_last, NC, Kd, kd_is_m, tiles_x, tiles;
+    double alpha; int kskip, ktri;
+};
+
+__global__ __launch_bounds__(512) void gemm_nn_t128_kernel(GemmBatch g) {
+    __shared__ double As[T2 * SI2];
+    __shared__ double Bs[KC * SK2];
+    int z, t;
+    {
+        const int id = blockIdx.x, x = id & 7, l = id >> 3;
+        z = x + 8 * (l / g.tiles);
+        t = l - (l / g.tiles) * g.tiles;
+        if (z >= g.nbatch) return;
+    }
+    const int a = z / g.nq, q = z - a * g.nq;
+    const int M = (q == g.nq - 1) ? g.M_last : g.M;
+    const int NC = g.NC;
+    const int Kd = g.kd_is_m ? M : g.Kd;
+    const int i0 = (t / g.tiles_x) * T2, c0 = (t % g.tiles_x) * T2;
+    if (i0 >= M) return;
+    const double* A = g.A + (size_t)a * g.sa + (size_t)q * g.qa;
+    const double* B = g.B + (size_t)a * g.sb + (size_t)q * g.qb;
+    double* C = g.C + (size_t)a * g.sc + (size_t)q * g.qc;
+    const int lda = g.lda, ldb = g.ldb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 64;
+    const int srow = tid >> 5, sk = tid & 31;                        // A slice 128 x 32
+    const int sp = tid >> 7, scol = tid & 127;                       // B slice 32 x 128
+    const int kbeg = g.kskip ? c0 : 0;
+    int kend = Kd;
+    if (g.ktri && i0 + T2 < kend) kend = i0 + T2;
+    unsigned offa[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int row = i0 + 16 * u + srow;
+        offa[u] = (unsigned)(row < M ? row : M - 1) * (unsigned)lda + (unsigned)sk;
+    }
+    const unsigned offb = (unsigned)sp * (unsigned)ldb + (unsigned)(c0 + scol < NC ? c0 + scol : NC - 1);
+    d4 acc[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = {0.0, 0.0, 0.0, 0.0};
+    double av[8], bv[8];
+    const int nfull = kbeg + ((kend - kbeg) / KC) * KC;
+    auto fetch = [&](int p0) {
+        const double* Ap = A + p0;
+        const double* Bp = B + (size_t)p0 * ldb;
+        if (p0 < nfull) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { av[u] = Ap[offa[u]]; bv[u] = Bp[(size_t)(4 * u) * ldb + offb]; }
+        } else {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                av[u] = (p0 + sk < kend) ? Ap[offa[u]] : 0.0;
+                bv[u] = (p0 + 4 * u + sp < kend) ? Bp[(size_t)(4 * u) * ldb + offb] : 0.0;
+            }
+        }
+    };
+    const double* Af = As + (wi + li) * SI2 + lk;
+    const double* Bf = Bs + lk * SK2 + wj + li;
+    double* Aw = As + srow * SI2 + sk;
+    double* Bw = Bs + sp * SK2 + scol;
+    if (kbeg < kend) fetch(kbeg);
+    for (int p0 = kbeg; p0 < kend; p0 += KC) {
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { Aw[16 * u * SI2] = av[u]; Bw[4 * u * SK2] = bv[u]; }
+        __syncthreads();
+        if (p0 + KC < kend) fetch(p0 + KC);
+        slice_mfma_2x4<1, SI2, SK2, 1>(acc, Af, Bf);
+    }
+    const double alpha = g.alpha;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wi + 16 * x + lk + 4 * r, col = c0 + wj + 16 * y + li;
+                if (row < M && col < NC) C[(size_t)row * g.ldc + col] = alpha * acc[x][y][r];
+            }
+}
+
 // C (M x NC) = alpha * A (M x Kd, row-major, lda) * B (Kd x NC, row-major, ldb) on 64 x 64 tiles, batched over blockIdx.z.
 // A rows are staged i-major, B rows k-major (see above).  kskip: B[p][c] = 0 for p < c (a lower-triangular right factor), so
 // the k range of column tile c0 starts at c0; ktri: A[i][p] = 0 for p > i (a lower-triangular left factor), so it ends at
@@ -755,11 +1097,13 @@ __global__ __launch_bounds__(256) void tm_kernel(const double* __restrict__ iK, 
     const int a = blockIdx.z;
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (i >= N || j >= N) return;
-    const size_t o = ((size_t)a * N + i) * N + j;
-    double t = beta[(size_t)a * N + i] * beta[(size_t)a * N + j] - iK[o];
-    if (i == j) t *= 0.5;
-    T[((size_t)a * (N + kTPadRows) + i) * N + j] = (i <= j) ? t : 0.0;       // upper triangle only
+    if (i >= N + kTPadRows || j >= N) return;                // the launch covers the zero rows after T_a too (no memset)
+    double t = 0.0;
+    if (i <= j) {
+        t = beta[(size_t)a * N + i] * beta[(size_t)a * N + j] - iK[((size_t)a * N + i) * N + j];
+        if (i == j) t *= 0.5;
+    }
+    T[((size_t)a * (N + kTPadRows) + i) * N + j] = t;        // upper triangle only
 }
 
 // ------------------------------------------------------------------------------------------
@@ -802,8 +1146,8 @@ int ensure_model_buffers(Handle* h, int N, int D, int E, bool need_factor_ws) {
     if ((rc = grow(h, h->kv, DN))) return rc;
     if ((rc = grow(h, h->vv, DN))) return rc;
     if ((rc = grow(h, h->sc, 2 * (size_t)kMaxD))) return rc;
-    if (!h->info) GPMPC_HIP_CHECK(h, hipMalloc(&h->info, kMaxD * sizeof(int)));
-    if (!h->mismatch) GPMPC_HIP_CHECK(h, hipMalloc(&h->mismatch, sizeof(int)));
+    if (!h->info) { GPMPC_HIP_CHECK(h, hipMalloc(&h->info, kMaxD * sizeof(int))); GPMPC_HIP_CHECK(h, hipMemset(h->info, 0, kMaxD * sizeof(int))); }
+    if (!h->mismatch) { GPMPC_HIP_CHECK(h, hipMalloc(&h->mismatch, sizeof(int))); GPMPC_HIP_CHECK(h, hipMemset(h->mismatch, 0, sizeof(int))); }
     return GPMPC_OK;
 }
 
@@ -816,6 +1160,20 @@ static int pack(Handle* h, const double* X, const double* ls, const double* os, 
     return GPMPC_OK;
 }
 
+static int pack_and_record(Handle* h, const double* X, const double* Y, const double* ls, const double* os, const double* noise,
+                           int N, int D, int E, hipStream_t s) {
+    int nb = (N * (E > D ? E : D) + 255) / 256;
+    if (nb < E) nb = E;
+    if (nb > 64) nb = 64;
+    if (nb < 1) nb = 1;
+    if (nb < E) nb = E;
+    hipLaunchKernelGGL(pack_record_kernel, dim3(nb), dim3(256), 0, s, X, Y, ls, os, noise, N, D, E, h->Xt.p, h->ils2.p, h->var.p,
+                       h->logvar.p, h->xrange.p, h->Xc.p, h->Yc.p, h->hyp.p);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    h->have_state = true;
+    return GPMPC_OK;
+}
+
 int run_set_factors(Handle* h, const double* X, const double* iK, const double* beta, const double* ls,
                     const double* os, int N, int D, int E, hipStream_t s) {
     int rc = ensure_model_buffers(h, N, D, E, false);
@@ -823,8 +1181,7 @@ int run_set_factors(Handle* h, const double* X, const double* iK, const double* 
     if ((rc = pack(h, X, ls, os, N, D, E, s))) return rc;
     GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->iK.p, iK, (size_t)D * N * N * sizeof(double), hipMemcpyDeviceToDevice, s));
     GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->beta.p, beta, (size_t)D * N * sizeof(double), hipMemcpyDeviceToDevice, s));
-    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->Tm.p, 0, (size_t)D * (N + kTPadRows) * N * sizeof(double), s));
-    hipLaunchKernelGGL(tm_kernel, dim3((N + 63) / 64, (N + 3) / 4, D), dim3(256), 0, s, h->iK.p, h->beta.p, N, h->Tm.p);
+    hipLaunchKernelGGL(tm_kernel, dim3((N + 63) / 64, (N + kTPadRows + 3) / 4, D), dim3(256), 0, s, h->iK.p, h->beta.p, N, h->Tm.p);
     GPMPC_HIP_CHECK(h, hipGetLastError());
     h->N = N; h->D = D; h->E = E; h->ready = true;
     h->have_state = false;                      // no (X, Y, hyper-parameters) record for these factors
@@ -931,17 +1288,6 @@ __global__ __launch_bounds__(256) void mll_finish_kernel(const double* __restric
 }
 
 // remember what the cached factors were computed from
-static int record_state(Handle* h, const double* X, const double* Y, const double* ls, const double* os,
-                        const double* noise, int N, int D, int E, hipStream_t s) {
-    GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->Xc.p, X, (size_t)N * E * sizeof(double), hipMemcpyDeviceToDevice, s));
-    GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->Yc.p, Y, (size_t)N * D * sizeof(double), hipMemcpyDeviceToDevice, s));
-    GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->hyp.p, ls, (size_t)D * E * sizeof(double), hipMemcpyDeviceToDevice, s));
-    GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->hyp.p + (size_t)D * E, os, D * sizeof(double), hipMemcpyDeviceToDevice, s));
-    GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->hyp.p + (size_t)D * E + kMaxD, noise, D * sizeof(double), hipMemcpyDeviceToDevice, s));
-    h->have_state = true;
-    return GPMPC_OK;
-}
-
 static int check_info(Handle* h, int D, hipStream_t s) {
     int info[kMaxD];
     GPMPC_HIP_CHECK(h, hipMemcpyAsync(info, h->info, kMaxD * sizeof(int), hipMemcpyDeviceToHost, s));
@@ -954,6 +1300,7 @@ static int check_info(Handle* h, int D, hipStream_t s) {
             h->err = buf;
             h->ready = false;
             h->have_state = false;
+            (void)hipMemsetAsync(h->info, 0, kMaxD * sizeof(int), s);          // zero when idle
             return GPMPC_ERR_NOT_PD;
         }
     }
@@ -973,23 +1320,21 @@ static int try_incremental(Handle* h, const double* X, const double* Y, const do
         !fits(h->Tm, TN) || !fits(h->Xt, (size_t)E * N) || !fits(h->Xc, (size_t)N * E) ||
         !fits(h->Yc, (size_t)N * D) || !fits(h->kv, DN) || !fits(h->vv, DN))
         return 0;
-    // is the cached (X, Y, hyper-parameters) a prefix of the new one?
-    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->mismatch, 0, sizeof(int), s));
-    auto cmp = [&](const double* a, const double* b, size_t n) {
-        hipLaunchKernelGGL(prefix_mismatch_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, b, n, h->mismatch);
-    };
-    cmp(X, h->Xc.p, (size_t)n0 * E);
-    cmp(Y, h->Yc.p, (size_t)n0 * D);
-    cmp(ls, h->hyp.p, (size_t)D * E);
-    cmp(os, h->hyp.p + (size_t)D * E, D);
-    cmp(noise, h->hyp.p + (size_t)D * E + kMaxD, D);
+    // is the cached (X, Y, hyper-parameters) a prefix of the new one?  (flag is zero when idle)
+    {
+        const size_t nX = (size_t)n0 * E, nY = (size_t)n0 * D;
+        int nb = (int)((nX + 255) / 256);
+        if (nb > 64) nb = 64;
+        if (nb < 1) nb = 1;
+        hipLaunchKernelGGL(prefix_mismatch_all_kernel, dim3(nb), dim3(256), 0, s, X, h->Xc.p, nX, Y, h->Yc.p, nY, ls, os, noise,
+                           h->hyp.p, D, E, h->mismatch);
+    }
     int flag = 1;
     GPMPC_HIP_CHECK(h, hipMemcpyAsync(&flag, h->mismatch, sizeof(int), hipMemcpyDeviceToHost, s));
     GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
-    if (flag) return 0;
+    if (flag) { GPMPC_HIP_CHECK(h, hipMemsetAsync(h->mismatch, 0, sizeof(int), s)); return 0; }
     if (k == 0) { h->last_prepare_mode = 2; return 1; }           // nothing changed: the factors are current
-    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->info, 0, kMaxD * sizeof(int), s));
-    for (int n = n0; n < N; ++n) {
+    for (int n = n0; n < N; ++n) {                                  // (info is zero when idle: check_info clears it after a failure)
         hipLaunchKernelGGL(kvec_kernel, dim3((n + 255) / 256, D), dim3(256), 0, s, X, n, E, h->ils2.p, h->var.p, N, h->kv.p);
         hipLaunchKernelGGL(border_lvec_kernel, dim3((n + 3) / 4, D), dim3(256), 0, s, h->linv.p, h->kv.p, n, N, h->vv.p);
         hipLaunchKernelGGL(border_u_kernel, dim3((n + 64) / 64, D), dim3(1024), 0, s, h->linv.p, h->vv.p, n, N, h->var.p, noise,
@@ -1002,13 +1347,11 @@ static int try_incremental(Handle* h, const double* X, const double* Y, const do
         t = h->beta; h->beta = h->zvec; h->zvec = t;
     }
     GPMPC_HIP_CHECK(h, hipGetLastError());
-    int rc = pack(h, X, ls, os, N, D, E, s);
-    if (rc) return rc;
-    GPMPC_HIP_CHECK(h, hipMemsetAsync(h->Tm.p, 0, (size_t)D * (N + kTPadRows) * N * sizeof(double), s));
-    hipLaunchKernelGGL(tm_kernel, dim3((N + 63) / 64, (N + 3) / 4, D), dim3(256), 0, s, h->iK.p, h->beta.p, N, h->Tm.p);
+    hipLaunchKernelGGL(tm_kernel, dim3((N + 63) / 64, (N + kTPadRows + 3) / 4, D), dim3(256), 0, s, h->iK.p, h->beta.p, N, h->Tm.p);
     GPMPC_HIP_CHECK(h, hipGetLastError());
-    if ((rc = check_info(h, D, s))) return rc;
-    if ((rc = record_state(h, X, Y, ls, os, noise, N, D, E, s))) return rc;
+    int rc = check_info(h, D, s);
+    if (rc) return rc;
+    if ((rc = pack_and_record(h, X, Y, ls, os, noise, N, D, E, s))) return rc;
     h->N = N;
     h->inc_updates += k;
     h->last_prepare_mode = 1;
@@ -1036,8 +1379,8 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     }
     const bool factored = (rc == 2);
     if (!factored) {
-        if ((rc = pack(h, X, ls, os, N, D, E, s))) return rc;
-        GPMPC_HIP_CHECK(h, hipMemsetAsync(h->info, 0, kMaxD * sizeof(int), s));
+        if ((rc = pack_and_record(h, X, Y, ls, os, noise, N, D, E, s))) return rc;
+        h->have_state = false;                   // valid only once the factorisation has succeeded
         GPMPC_HIP_CHECK(h, hipMemsetAsync(h->linv.p, 0, (size_t)D * N * N * sizeof(double), s));
     }
     if (!factored) GPMPC_HIP_CHECK(h, hipMemsetAsync(h->Tm.p, 0, (size_t)D * (N + kTPadRows) * N * sizeof(double), s));
@@ -1070,16 +1413,55 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
                 if (ntx > 0)
                     hipLaunchKernelGGL(syrk_trailing_kernel, dim3(ntx < nt ? ntx : nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb, cend);
                 if (OW && k0 + nb == cend && cend < N) {             // outer panel [cend - OW, cend) complete: rank-OW update of the rest
-                    const int nto = (N - cend + TS - 1) / TS;
-                    hipLaunchKernelGGL(syrk_outer_kernel, dim3(nto, nto, D), dim3(256), 0, s, h->gram.p, N, cend - OW, OW);
+                    if (h->opt_tile128 != 0) {
+                        const int nto = (N - cend + T2 - 1) / T2, ntile = nto * (nto + 1) / 2;
+                        hipLaunchKernelGGL(syrk_outer_t128_kernel, dim3(8 * ntile * ((D + 7) / 8)), dim3(512), 0, s, h->gram.p, N, D, ntile,
+                                           cend - OW, OW);
+                    } else {
+                        const int nto = (N - cend + TS - 1) / TS;
+                        hipLaunchKernelGGL(syrk_outer_kernel, dim3(nto, nto, D), dim3(256), 0, s, h->gram.p, N, cend - OW, OW);
+                    }
                 }
             }
         }
         if (k0 > 0 && !OW && !factored) {
-            hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb, 0);
+            hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb, 0, 0, 0);
         }
     }
-    if (OW) {
+    if (OW && h->opt_tile128 != 0) {
+        // Y = L^-1 by recursive doubling.  All diagonal 128-blocks Y_KK at once (the 32-row recursion restricted to the columns
+        // of the block: 3 launches), then for b = 128, 256, ...: every pair of adjacent b-blocks [[Y11, 0], [Y21, Y22]] gets
+        // Y21 = -Y22 (L21 Y11) from two batched tiled products (scratch W = L21 Y11: the iK buffer, written later).  5 levels
+        // at N = 4096, every launch >= 256 workgroups, instead of 31 dependent steps whose first ones fill a few CUs.
+        const size_t NN = (size_t)N * N;
+        const int nblk = (N + OW - 1) / OW;
+        for (int koff = NB; koff < OW; koff += NB)
+            hipLaunchKernelGGL(trinv_row_kernel, dim3((koff + 31) / 32, D, nblk), dim3(256), 0, s, h->gram.p, h->linv.p, N, 0, 0, 0, OW, koff);
+        for (int b = OW; b < N; b *= 2) {
+            const int nq = (N - b + 2 * b - 1) / (2 * b);              // pairs q with (2q + 1) b < N
+            const int lastrows = N - (2 * (nq - 1) + 1) * b;
+            GemmBatch g;
+            g.lda = g.ldb = g.ldc = N;
+            g.sa = g.sb = g.sc = NN;
+            g.qa = g.qb = g.qc = (size_t)2 * b * ((size_t)N + 1);
+            g.nq = nq; g.nbatch = nq * D;
+            g.M = b; g.M_last = lastrows < b ? lastrows : b;
+            g.NC = b; g.Kd = b;
+            g.tiles_x = (b + T2 - 1) / T2;
+            g.tiles = g.tiles_x * ((b + T2 - 1) / T2);
+            const size_t off21 = (size_t)b * N;                        // block (1, 0) of a pair relative to its block (0, 0)
+            const size_t off22 = (size_t)b * N + b;
+            const dim3 grid(8 * g.tiles * ((g.nbatch + 7) / 8));
+            // W = L21 Y11
+            g.A = h->gram.p + off21; g.B = h->linv.p; g.C = h->iK.p + off21;
+            g.alpha = 1.0; g.kskip = 1; g.ktri = 0; g.kd_is_m = 0;
+            hipLaunchKernelGGL(gemm_nn_t128_kernel, grid, dim3(512), 0, s, g);
+            // Y21 = -Y22 W
+            g.A = h->linv.p + off22; g.B = h->iK.p + off21; g.C = h->linv.p + off21;
+            g.alpha = -1.0; g.kskip = 0; g.ktri = 1; g.kd_is_m = 1;
+            hipLaunchKernelGGL(gemm_nn_t128_kernel, grid, dim3(512), 0, s, g);
+        }
+    } else if (OW) {
         // Y = L^-1 by 128-row blocks: inside a block the 32-row recursion (columns of the block only) gives Y_KK; the part left
         // of the block is two tiled products, W = L[K, c:K] Y[c:K, c] (scratch: the iK buffer, written later) and Y[K, c] = -Y_KK W
         const size_t NN = (size_t)N * N;
@@ -1087,7 +1469,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
             const int mb = (N - K0 < OW) ? (N - K0) : OW;
             for (int k0 = K0 + NB; k0 < K0 + mb; k0 += NB) {
                 const int nb = (N - k0 < NB) ? (N - k0) : NB;
-                hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 - K0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb, K0);
+                hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 - K0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb, K0, 0, 0);
             }
             if (K0 > 0) {
                 const dim3 grid((K0 + TS - 1) / TS, (mb + TS - 1) / TS, D);
@@ -1101,7 +1483,11 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     GPMPC_HIP_CHECK(h, hipGetLastError());
     hipLaunchKernelGGL(zvec_kernel, dim3((N + 3) / 4, D), dim3(256), 0, s, h->linv.p, Y, N, D, h->zvec.p);
     hipLaunchKernelGGL(beta_kernel, dim3((N + 255) / 256, D), dim3(256), 0, s, h->linv.p, h->zvec.p, N, h->beta.p);
-    if (N >= 512 && h->opt_outer_block != 0) {
+    if (N >= 1024 && h->opt_outer_block != 0 && h->opt_tile128 != 0) {
+        const int nt = (N + T2 - 1) / T2, ntile = nt * (nt + 1) / 2;
+        hipLaunchKernelGGL(syrk_inverse_t128_kernel, dim3(8 * ntile * ((D + 7) / 8)), dim3(512), 0, s, h->linv.p, h->beta.p, N, D, ntile,
+                           h->iK.p, h->Tm.p);
+    } else if (N >= 512 && h->opt_outer_block != 0) {
         const int nt = (N + TS - 1) / TS;
         hipLaunchKernelGGL(syrk_inverse_tiled_kernel, dim3(nt, nt, D), dim3(256), 0, s, h->linv.p, h->beta.p, N, h->iK.p, h->Tm.p);
     } else {
@@ -1110,8 +1496,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     }
     GPMPC_HIP_CHECK(h, hipGetLastError());
     if ((rc = check_info(h, D, s))) return rc;
-    if (factored) h->have_state = true;           // recorded by the factorisation kernel
-    else if ((rc = record_state(h, X, Y, ls, os, noise, N, D, E, s))) return rc;
+    h->have_state = true;                         // (X, Y, hyper-parameters) were recorded by the first launch
     h->inc_updates = 0;
     h->N = N; h->D = D; h->E = E; h->ready = true;
     return GPMPC_OK;
