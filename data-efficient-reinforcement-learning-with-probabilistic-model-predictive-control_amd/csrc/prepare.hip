@@ -659,8 +659,18 @@ __device__ inline void tri_tile(int t, int& ti, int& tj) {
     ti = r; tj = t - r * (r + 1) / 2;
 }
 
+// Operand slices are fetched with raw buffer loads: one 32-bit byte offset per thread and operand, everything uniform
+// (slice row, slice advance) in the scalar offset, and the range check of the descriptor returns zero past `bytes` -- rows
+// past the end of a matrix need neither clamping nor masking.
+__device__ inline __amdgpu_buffer_rsrc_t operand_rsrc(const double* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, (int)(unsigned)(bytes < 0xFFFFFFFFull ? bytes : 0xFFFFFFFFull), 0x00020000);
+}
+__device__ inline double operand_load(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, (int)soff, 0));
+}
+
 // 8 k-steps of one slice: As / Bs fragment base pointers already include the wavefront and lane offsets
-template <int ASTEP, int AROW, int BSTEP, int BROW>
+template <int ASTEP, int AROW, int BSTEP, int BROW, bool FENCE = false>
 __device__ inline void slice_mfma_2x4(d4 (&acc)[2][4], const double* __restrict__ Af, const double* __restrict__ Bf) {
 #pragma unroll
     for (int kk = 0; kk < KC; kk += 4) {
@@ -674,13 +684,16 @@ __device__ inline void slice_mfma_2x4(d4 (&acc)[2][4], const double* __restrict_
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc[1][1], 0, 0, 0);
         acc[1][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b2, acc[1][2], 0, 0, 0);
         acc[1][3] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b3, acc[1][3], 0, 0, 0);
+        // FENCE: keep the fragment reads of the next k-step behind these MFMAs (12 fragment registers instead of 24; with
+        // four wavefronts per SIMD the others cover the LDS latency)
+        if (FENCE) __builtin_amdgcn_sched_barrier(0);
     }
 }
 
 // iK = Y^T Y and T = beta beta^T - iK as in syrk_inverse_tiled_kernel, 128 x 128 tiles of the lower triangle.  1-D grid:
 // workgroup id -> XCD id & 7 (round-robin dispatch); every XCD works through whole GPs (a, a + 8, ...) tile row by tile row,
 // so that the workgroups sharing its L2 read the same column blocks of the same Y.
-__global__ __launch_bounds__(512) void syrk_inverse_t128_kernel(const double* __restrict__ Yall, const double* __restrict__ beta,
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void syrk_inverse_t128_kernel(const double* __restrict__ Yall, const double* __restrict__ beta,
                                                                 int N, int D, int ntile, double* __restrict__ iKall,
                                                                 double* __restrict__ Tall) {
     __shared__ double As[KC * SK2];
@@ -706,26 +719,20 @@ __global__ __launch_bounds__(512) void syrk_inverse_t128_kernel(const double* __
     // staging: element e = 512 u + tid of the 32 x 128 slice, k = e / 128 = 4 u + sp, column e % 128
     const int sp = tid >> 7, scol = tid & 127;
     const unsigned ca = (unsigned)((i0 + scol < N) ? i0 + scol : N - 1), cb = (unsigned)((j0 + scol < N) ? j0 + scol : N - 1);
-    const unsigned offa = (unsigned)sp * (unsigned)N + ca, offb = (unsigned)sp * (unsigned)N + cb;
+    const unsigned offa = ((unsigned)sp * (unsigned)N + ca) * 8u, offb = ((unsigned)sp * (unsigned)N + cb) * 8u;
+    const __amdgpu_buffer_rsrc_t rs = operand_rsrc(Y, (size_t)N * N * 8);      // rows p >= N read as zero
     d4 acc[2][4];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) acc[x][y] = {0.0, 0.0, 0.0, 0.0};
     double av[8], bv[8];
-    const int nfull = i0 + ((N - i0) / KC) * KC;                     // slices [i0, nfull) are complete
     auto fetch = [&](int p0) {
-        const double* Yp = Y + (size_t)p0 * N;
-        if (p0 < nfull) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { av[u] = Yp[(size_t)(4 * u) * N + offa]; bv[u] = Yp[(size_t)(4 * u) * N + offb]; }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const bool in = p0 + 4 * u + sp < N;
-                av[u] = in ? Yp[(size_t)(4 * u) * N + offa] : 0.0;
-                bv[u] = in ? Yp[(size_t)(4 * u) * N + offb] : 0.0;
-            }
+        for (int u = 0; u < 8; ++u) {
+            const unsigned so = (unsigned)(p0 + 4 * u) * (unsigned)N * 8u;
+            av[u] = operand_load(rs, offa, so);
+            bv[u] = operand_load(rs, offb, so);
         }
     };
     const double* Af = As + lk * SK2 + wi + li;
@@ -761,9 +768,10 @@ __global__ __launch_bounds__(512) void syrk_inverse_t128_kernel(const double* __
 
 // Trailing update of the outer-blocked Cholesky as in syrk_outer_kernel, 128 x 128 tiles of the lower triangle (w is a
 // multiple of 32).  Same 1-D grid / XCD mapping as syrk_inverse_t128_kernel.
-__global__ __launch_bounds__(512) void syrk_outer_t128_kernel(double* __restrict__ Kall, int N, int D, int ntile, int k0, int w) {
-    __shared__ double As[T2 * SI2];
-    __shared__ double Bs[T2 * SI2];
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void syrk_outer_t128_kernel(double* __restrict__ Kall, int N, int D, int ntile, int k0, int w) {
+    __shared__ double S[2 * T2 * SI2];                               // A slice | B slice: one base register, constant offsets
+    double* const As = S;
+    double* const Bs = S + T2 * SI2;
     int a, t;
     {
         const int id = blockIdx.x, x = id & 7, l = id >> 3;
@@ -781,14 +789,9 @@ __global__ __launch_bounds__(512) void syrk_outer_t128_kernel(double* __restrict
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 64;
     // staging: element e = 512 u + tid of the 128 x 32 slice, row e / 32 = 16 u + srow, k = e % 32
     const int srow = tid >> 5, sk = tid & 31;
-    unsigned offa[8], offb[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int row = 16 * u + srow;
-        const int ra = (i0 + row < N) ? i0 + row : N - 1, rb = (j0 + row < N) ? j0 + row : N - 1;
-        offa[u] = (unsigned)ra * (unsigned)N + (unsigned)sk;
-        offb[u] = (unsigned)rb * (unsigned)N + (unsigned)sk;
-    }
+    const unsigned offa = ((unsigned)(i0 + srow) * (unsigned)N + (unsigned)sk) * 8u;
+    const unsigned offb = ((unsigned)(j0 + srow) * (unsigned)N + (unsigned)sk) * 8u;
+    const __amdgpu_buffer_rsrc_t rs = operand_rsrc(K, (size_t)N * N * 8);      // rows >= N read as zero
     d4 acc[2][4];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -796,22 +799,24 @@ __global__ __launch_bounds__(512) void syrk_outer_t128_kernel(double* __restrict
         for (int y = 0; y < 4; ++y) acc[x][y] = {0.0, 0.0, 0.0, 0.0};
     double av[8], bv[8];
     auto fetch = [&](int p0) {
-        const double* Kp = K + k0 + p0;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { av[u] = Kp[offa[u]]; bv[u] = Kp[offb[u]]; }
+        for (int u = 0; u < 8; ++u) {
+            const unsigned so = ((unsigned)(16 * u) * (unsigned)N + (unsigned)(k0 + p0)) * 8u;
+            av[u] = operand_load(rs, offa, so);
+            bv[u] = operand_load(rs, offb, so);
+        }
     };
     const double* Af = As + (wi + li) * SI2 + lk;
     const double* Bf = Bs + (wj + li) * SI2 + lk;
     double* Aw = As + srow * SI2 + sk;
-    double* Bw = Bs + srow * SI2 + sk;
     fetch(0);
     for (int p0 = 0; p0 < w; p0 += KC) {
         __syncthreads();
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { Aw[16 * u * SI2] = av[u]; Bw[16 * u * SI2] = bv[u]; }
+        for (int u = 0; u < 8; ++u) { Aw[16 * u * SI2] = av[u]; Aw[T2 * SI2 + 16 * u * SI2] = bv[u]; }
         __syncthreads();
         if (p0 + KC < w) fetch(p0 + KC);
-        slice_mfma_2x4<1, SI2, 1, SI2>(acc, Af, Bf);
+        slice_mfma_2x4<1, SI2, 1, SI2, true>(acc, Af, Bf);
     }
 #pragma unroll
     for (int x = 0; x < 2; ++x)
@@ -832,11 +837,12 @@ struct GemmBatch {
     const double* A; int lda; size_t sa, qa;
     const double* B; int ldb; size_t sb, qb;
     double* C; int ldc; size_t sc, qc;
+    size_t a_rem;                     // elements from A (batch q = 0) to the end of its matrix
     int nq, nbatch, M, M_last, NC, Kd, kd_is_m, tiles_x, tiles;
     double alpha; int kskip, ktri;
 };
 
-__global__ __launch_bounds__(512) void gemm_nn_t128_kernel(GemmBatch g) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_nn_t128_kernel(GemmBatch g) {
     __shared__ double As[T2 * SI2];
     __shared__ double Bs[KC * SK2];
     int z, t;
@@ -864,32 +870,23 @@ __global__ __launch_bounds__(512) void gemm_nn_t128_kernel(GemmBatch g) {
     const int kbeg = g.kskip ? c0 : 0;
     int kend = Kd;
     if (g.ktri && i0 + T2 < kend) kend = i0 + T2;
-    unsigned offa[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        const int row = i0 + 16 * u + srow;
-        offa[u] = (unsigned)(row < M ? row : M - 1) * (unsigned)lda + (unsigned)sk;
-    }
-    const unsigned offb = (unsigned)sp * (unsigned)ldb + (unsigned)(c0 + scol < NC ? c0 + scol : NC - 1);
+    const unsigned offa = ((unsigned)(i0 + srow) * (unsigned)lda + (unsigned)sk) * 8u;
+    const unsigned offb = ((unsigned)sp * (unsigned)ldb + (unsigned)(c0 + scol < NC ? c0 + scol : NC - 1)) * 8u;
+    // A: rows past M are rows of the enclosing matrix (finite; their products are not stored) or, past its end, zero;
+    // B: rows p >= kend read as zero, which also covers the k tail of A (whatever finite values it reads there)
+    const __amdgpu_buffer_rsrc_t ra = operand_rsrc(A, (g.a_rem - (size_t)q * g.qa) * 8);
+    const __amdgpu_buffer_rsrc_t rb = operand_rsrc(B, (size_t)kend * ldb * 8);
     d4 acc[2][4];
 #pragma unroll
     for (int x = 0; x < 2; ++x)
 #pragma unroll
         for (int y = 0; y < 4; ++y) acc[x][y] = {0.0, 0.0, 0.0, 0.0};
     double av[8], bv[8];
-    const int nfull = kbeg + ((kend - kbeg) / KC) * KC;
     auto fetch = [&](int p0) {
-        const double* Ap = A + p0;
-        const double* Bp = B + (size_t)p0 * ldb;
-        if (p0 < nfull) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { av[u] = Ap[offa[u]]; bv[u] = Bp[(size_t)(4 * u) * ldb + offb]; }
-        } else {
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                av[u] = (p0 + sk < kend) ? Ap[offa[u]] : 0.0;
-                bv[u] = (p0 + 4 * u + sp < kend) ? Bp[(size_t)(4 * u) * ldb + offb] : 0.0;
-            }
+        for (int u = 0; u < 8; ++u) {
+            av[u] = operand_load(ra, offa, ((unsigned)(16 * u) * (unsigned)lda + (unsigned)p0) * 8u);
+            bv[u] = operand_load(rb, offb, (unsigned)(p0 + 4 * u) * (unsigned)ldb * 8u);
         }
     };
     const double* Af = As + (wi + li) * SI2 + lk;
@@ -1454,10 +1451,12 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
             const dim3 grid(8 * g.tiles * ((g.nbatch + 7) / 8));
             // W = L21 Y11
             g.A = h->gram.p + off21; g.B = h->linv.p; g.C = h->iK.p + off21;
+            g.a_rem = NN - off21;
             g.alpha = 1.0; g.kskip = 1; g.ktri = 0; g.kd_is_m = 0;
             hipLaunchKernelGGL(gemm_nn_t128_kernel, grid, dim3(512), 0, s, g);
             // Y21 = -Y22 W
             g.A = h->linv.p + off22; g.B = h->iK.p + off21; g.C = h->linv.p + off21;
+            g.a_rem = NN - off22;
             g.alpha = -1.0; g.kskip = 0; g.ktri = 1; g.kd_is_m = 1;
             hipLaunchKernelGGL(gemm_nn_t128_kernel, grid, dim3(512), 0, s, g);
         }
