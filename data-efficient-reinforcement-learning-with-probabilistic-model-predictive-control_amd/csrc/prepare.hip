@@ -768,7 +768,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 
 // Trailing update of the outer-blocked Cholesky as in syrk_outer_kernel, 128 x 128 tiles of the lower triangle (w is a
 // multiple of 32).  Same 1-D grid / XCD mapping as syrk_inverse_t128_kernel.
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void syrk_outer_t128_kernel(double* __restrict__ Kall, int N, int D, int ntile, int k0, int w) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) void syrk_outer_t128_kernel(double* __restrict__ Kall, int N, int D, int ntile, int k0, int w, int nto) {
     __shared__ double S[2 * T2 * SI2];                               // A slice | B slice: one base register, constant offsets
     double* const As = S;
     double* const Bs = S + T2 * SI2;
@@ -780,7 +780,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if (a >= D) return;
     }
     int ti, tj;
-    tri_tile(t, ti, tj);
+    // tiles of the first columns of the trailing matrix, column by column: column tj has rows tj .. nto - 1
+    tj = 0;
+    while (t >= nto - tj) { t -= nto - tj; ++tj; }
+    ti = tj + t;
     double* K = Kall + (size_t)a * N * N;
     const int r0 = k0 + w;
     const int i0 = r0 + ti * T2, j0 = r0 + tj * T2;
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + wi + 16 * x + lk + 4 * r, col = j0 + wj + 16 * y + li;
-                if (row < N && col <= row) K[(size_t)row * N + col] -= acc[x][y][r];
+                if (row < N && col <= row) unsafeAtomicAdd(&K[(size_t)row * N + col], -acc[x][y][r]);   // one add per element and launch: no read latency to wait for
             }
 }
 
@@ -1411,9 +1414,24 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
                     hipLaunchKernelGGL(syrk_trailing_kernel, dim3(ntx < nt ? ntx : nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb, cend);
                 if (OW && k0 + nb == cend && cend < N) {             // outer panel [cend - OW, cend) complete: rank-OW update of the rest
                     if (h->opt_tile128 != 0) {
-                        const int nto = (N - cend + T2 - 1) / T2, ntile = nto * (nto + 1) / 2;
+                        // two outer levels: after the first 128 columns of a 256-column block only the next 128 columns are
+                        // updated (one strip of tiles, k = 128); after the second, everything to the right with k = 256 --
+                        // the trailing matrix is read and written once per 256 columns
+                        // Binary outer levels: after m = cend / 128 outer panels, with 2^t the largest power of two dividing m
+                        // (t <= tmax), the last 2^t panels update the next 2^t tile columns in one product (k = 128 * 2^t) -- or,
+                        // at t = tmax, everything to the right.  Every element of the trailing matrix is then read and written
+                        // once per 128 * 2^tmax columns instead of once per 128 (the update is bound by that traffic).
+                        const int nto = (N - cend + T2 - 1) / T2;
+                        const int tmax = h->opt_outer2 < 0 ? 0 : (h->opt_outer2 > 4 ? 4 : h->opt_outer2);
+                        const int m = cend / OW;
+                        int t = 0;
+                        while (t < tmax && (m & ((2 << t) - 1)) == 0) ++t;
+                        int nct = (t == tmax) ? nto : (1 << t);
+                        if (nct > nto) nct = nto;
+                        const int ntile = nct * nto - nct * (nct - 1) / 2;
+                        const int wk = OW << t;
                         hipLaunchKernelGGL(syrk_outer_t128_kernel, dim3(8 * ntile * ((D + 7) / 8)), dim3(512), 0, s, h->gram.p, N, D, ntile,
-                                           cend - OW, OW);
+                                           cend - wk, wk, nto);
                     } else {
                         const int nto = (N - cend + TS - 1) / TS;
                         hipLaunchKernelGGL(syrk_outer_kernel, dim3(nto, nto, D), dim3(256), 0, s, h->gram.p, N, cend - OW, OW);
