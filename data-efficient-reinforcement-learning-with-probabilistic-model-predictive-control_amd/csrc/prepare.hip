@@ -271,16 +271,35 @@ __device__ inline double inv_sqrt_pos_p(double d) {
     return y;
 }
 
+// left > 0 (outer-blocked path): the block first receives the update of the `left` columns before it inside the current
+// outer panel, A_kk -= L[k, J:k0] L[k, J:k0]^T -- the panels of an outer panel are factorised left-looking, so no
+// trailing update is launched (and no trailing strip re-read and re-written) per 32 columns.
 __global__ __launch_bounds__(NB * NB) void potrf_diag_fast_kernel(double* __restrict__ Kall, double* __restrict__ Yall,
-                                                                 int N, int k0, int nb, int* __restrict__ info) {
+                                                                 int N, int k0, int nb, int* __restrict__ info, int left) {
     __shared__ double colb[2][2 * NB];
     __shared__ double sinv[NB];
+    __shared__ double lb[NB][3 * NB + 1];
     const int a = blockIdx.x;
     double* K = Kall + (size_t)a * N * N;
     double* Y = Yall + (size_t)a * N * N;
     const int tid = threadIdx.x, wave = tid >> 6;
     const int c = tid >> 5, r = tid & 31;                    // column-major over the wavefronts: wave w <-> columns 2w, 2w + 1
     double a0 = (r < nb && c < nb && c <= r) ? K[(size_t)(k0 + r) * N + (k0 + c)] : 0.0;
+    if (left > 0) {
+        for (int idx = tid; idx < NB * left; idx += NB * NB) {
+            const int rr = idx / left, p = idx - rr * left;
+            lb[rr][p] = (rr < nb) ? K[(size_t)(k0 + rr) * N + (k0 - left + p)] : 0.0;
+        }
+        __syncthreads();
+        double u0 = 0.0, u1 = 0.0, u2 = 0.0, u3 = 0.0;
+        for (int p = 0; p < left; p += 4) {
+            u0 = fma(lb[r][p], lb[c][p], u0);
+            u1 = fma(lb[r][p + 1], lb[c][p + 1], u1);
+            u2 = fma(lb[r][p + 2], lb[c][p + 2], u2);
+            u3 = fma(lb[r][p + 3], lb[c][p + 3], u3);
+        }
+        if (r < nb && c < nb && c <= r) a0 -= (u0 + u1) + (u2 + u3);
+    }
     double a1 = (r == c) ? 1.0 : 0.0;
     if (c == 0) { colb[0][r] = a0; colb[0][NB + r] = a1; }
     if (tid == 0) {
@@ -344,6 +363,75 @@ __global__ __launch_bounds__(256) void trsm_panel_mfma_kernel(double* __restrict
         acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], yt[4 * q + lk][16 + li], acc1, 0, 0, 0);
     }
     // every lane of the wavefront has read its A values before any lane stores (same wavefront: program order)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = i0 + lk + 4 * r;
+        if (row < N) {
+            if (li < nb) K[(size_t)row * N + k0 + li] = acc0[r];
+            if (16 + li < nb) K[(size_t)row * N + k0 + 16 + li] = acc1[r];
+        }
+    }
+}
+
+// Panel solve of the left-looking inner level: rows below the diagonal block first receive the update of the `left`
+// columns before the panel inside the current outer panel, X = A[rows, k0:k0+32] - L[rows, J:k0] L[k0:k0+32, J:k0]^T, then
+// L21 = X Y11^T.  One workgroup = 64 rows; the update leaves the accumulators in the C layout, the solve wants X as the
+// A operand: one trip through LDS per wavefront.
+__global__ __launch_bounds__(256) void trsm_panel_ll_kernel(double* __restrict__ Kall, const double* __restrict__ Yall,
+                                                            int N, int k0, int nb, int left) {
+    __shared__ double yt[NB][NB + 1];                        // yt[k][j] = Y11[j][k]
+    __shared__ double lbt[3 * NB][NB + 1];                   // lbt[p][j] = L[k0 + j][k0 - left + p]
+    __shared__ double xs[4][16][NB + 1];
+    const int a = blockIdx.y;
+    double* K = Kall + (size_t)a * N * N;
+    const double* Y = Yall + (size_t)a * N * N;
+    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
+        const int j = idx / NB, k = idx % NB;
+        yt[k][j] = (j < nb && k <= j) ? Y[(size_t)(k0 + j) * N + k0 + k] : 0.0;
+    }
+    for (int idx = threadIdx.x; idx < NB * left; idx += 256) {
+        const int j = idx / left, p = idx - j * left;
+        lbt[p][j] = (j < nb) ? K[(size_t)(k0 + j) * N + (k0 - left + p)] : 0.0;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int i0 = k0 + nb + blockIdx.x * 64 + wave * 16;    // wavefronts past the last row run along (loads masked, no stores)
+    const int ri = i0 + li;
+    const double* Ar = K + (size_t)(ri < N ? ri : N - 1) * N + (k0 - left);
+    d4 u0 = {0.0, 0.0, 0.0, 0.0}, u1 = {0.0, 0.0, 0.0, 0.0};
+    double cold0[4], cold1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {                            // the old values travel while the update is formed
+        const int row = i0 + lk + 4 * r;
+        cold0[r] = (row < N && li < nb) ? K[(size_t)row * N + k0 + li] : 0.0;
+        cold1[r] = (row < N && 16 + li < nb) ? K[(size_t)row * N + k0 + 16 + li] : 0.0;
+    }
+    for (int p = 0; p < left; p += 16) {
+        double al[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) al[q] = (ri < N) ? Ar[p + 4 * q + lk] : 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(al[q], lbt[p + 4 * q + lk][li], u0, 0, 0, 0);
+            u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(al[q], lbt[p + 4 * q + lk][16 + li], u1, 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        xs[wave][lk + 4 * r][li] = cold0[r] - u0[r];
+        xs[wave][lk + 4 * r][16 + li] = cold1[r] - u1[r];
+    }
+    __syncthreads();                                         // lanes exchange through xs: needs the barrier's ordering
+    double av[NB / 4];
+#pragma unroll
+    for (int q = 0; q < NB / 4; ++q) av[q] = xs[wave][li][4 * q + lk];
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < NB / 4; ++q) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], yt[4 * q + lk][li], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], yt[4 * q + lk][16 + li], acc1, 0, 0, 0);
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = i0 + lk + 4 * r;
@@ -438,8 +526,17 @@ __global__ __launch_bounds__(256) void zvec_kernel(const double* __restrict__ Ya
     const int lane = threadIdx.x & 63;
     if (row >= N) return;
     const double* Y = Yall + (size_t)a * N * N + (size_t)row * N;
-    double s = 0.0;
-    for (int p = lane; p <= row; p += 64) s = fma(Y[p], Ymem[(size_t)p * D + a], s);
+    // four independent partial sums keep four loads per lane in flight (fixed order: reproducible)
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int p = lane;
+    for (; p + 192 <= row; p += 256) {
+        s0 = fma(Y[p], Ymem[(size_t)p * D + a], s0);
+        s1 = fma(Y[p + 64], Ymem[(size_t)(p + 64) * D + a], s1);
+        s2 = fma(Y[p + 128], Ymem[(size_t)(p + 128) * D + a], s2);
+        s3 = fma(Y[p + 192], Ymem[(size_t)(p + 192) * D + a], s3);
+    }
+    for (; p <= row; p += 64) s0 = fma(Y[p], Ymem[(size_t)p * D + a], s0);
+    double s = (s0 + s1) + (s2 + s3);
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) z[(size_t)a * N + row] = s;
 }
@@ -461,6 +558,48 @@ __global__ __launch_bounds__(256) void beta_kernel(const double* __restrict__ Ya
     }
     for (; p < N; ++p) s0 = fma(Y[(size_t)p * N + i], z[(size_t)a * N + p], s0);
     beta[(size_t)a * N + i] = (s0 + s1) + (s2 + s3);
+}
+
+// Large N: beta in two deterministic stages.  One thread per column leaves 1 wavefront per SIMD, each walking up to N rows
+// (0.82 ms at N = 4096, D = 16); here a workgroup sums 256 rows of 64 columns (rows above the diagonal block skipped) and
+// a second launch adds the row-chunk partials in order.
+__global__ __launch_bounds__(256) void beta_partial_kernel(const double* __restrict__ Yall, const double* __restrict__ z, int N,
+                                                           double* __restrict__ partial) {
+    __shared__ double red[4][64];
+    const int a = blockIdx.z, ch = blockIdx.y, cb = blockIdx.x;
+    const int nch = gridDim.y;
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = cb * 64 + cl;
+    const int pbeg = ch * 256, pend = (pbeg + 256 < N) ? pbeg + 256 : N;
+    if (pend <= cb * 64) {                                    // all rows above the columns' diagonal: Y is zero there
+        if (rg == 0 && c < N) partial[((size_t)a * nch + ch) * N + c] = 0.0;
+        return;
+    }
+    const double* Y = Yall + (size_t)a * N * N;
+    const double* za = z + (size_t)a * N;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (c < N) {
+        int p = pbeg + rg;
+        for (; p + 12 < pend; p += 16) {
+            s0 = fma(Y[(size_t)p * N + c], za[p], s0);
+            s1 = fma(Y[(size_t)(p + 4) * N + c], za[p + 4], s1);
+            s2 = fma(Y[(size_t)(p + 8) * N + c], za[p + 8], s2);
+            s3 = fma(Y[(size_t)(p + 12) * N + c], za[p + 12], s3);
+        }
+        for (; p < pend; p += 4) s0 = fma(Y[(size_t)p * N + c], za[p], s0);
+    }
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && c < N) partial[((size_t)a * nch + ch) * N + c] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+}
+
+__global__ __launch_bounds__(256) void beta_reduce_kernel(const double* __restrict__ partial, int N, int nch, double* __restrict__ beta) {
+    const int a = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N) return;
+    double s = 0.0;
+    for (int ch = 0; ch < nch; ++ch) s += partial[((size_t)a * nch + ch) * N + i];
+    beta[(size_t)a * N + i] = s;
 }
 
 // iK = Y^T Y on lower-triangular 32x32 blocks (mirrored on store), plus T = beta beta^T - iK
@@ -1400,17 +1539,22 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
         const int nb = (N - k0 < NB) ? (N - k0) : NB;
         if (!factored) {
             const bool fast = h->opt_outer_block != 0;           // round-2 panel kernels (option "outer_block" = 0: the round-1 ones)
-            if (fast) hipLaunchKernelGGL(potrf_diag_fast_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
+            // inside an outer panel the 32-column panels are factorised left-looking (option "inner_left" = 0: right-looking
+            // with a rank-32 update of the rest of the outer panel per step)
+            const bool ll = OW && h->opt_inner_left != 0;
+            const int left = ll ? k0 % OW : 0;
+            if (fast) hipLaunchKernelGGL(potrf_diag_fast_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info, left);
             else hipLaunchKernelGGL(potrf_diag_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
             const int M = N - k0 - nb;
             if (M > 0) {
-                if (fast) hipLaunchKernelGGL(trsm_panel_mfma_kernel, dim3((M + 63) / 64, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb);
+                if (fast && left > 0) hipLaunchKernelGGL(trsm_panel_ll_kernel, dim3((M + 63) / 64, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb, left);
+                else if (fast) hipLaunchKernelGGL(trsm_panel_mfma_kernel, dim3((M + 63) / 64, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb);
                 else hipLaunchKernelGGL(trsm_panel_kernel, dim3((M + 255) / 256, D), dim3(256), 0, s, h->gram.p, N, k0, nb);
                 int cend = N;
                 if (OW) { cend = (k0 / OW + 1) * OW; if (cend > N) cend = N; }
                 const int nt = (M + 31) / 32;
                 const int ntx = (cend - (k0 + nb) + 31) / 32;
-                if (ntx > 0)
+                if (ntx > 0 && !ll)
                     hipLaunchKernelGGL(syrk_trailing_kernel, dim3(ntx < nt ? ntx : nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb, cend);
                 if (OW && k0 + nb == cend && cend < N) {             // outer panel [cend - OW, cend) complete: rank-OW update of the rest
                     if (h->opt_tile128 != 0) {
@@ -1499,7 +1643,14 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     }
     GPMPC_HIP_CHECK(h, hipGetLastError());
     hipLaunchKernelGGL(zvec_kernel, dim3((N + 3) / 4, D), dim3(256), 0, s, h->linv.p, Y, N, D, h->zvec.p);
-    hipLaunchKernelGGL(beta_kernel, dim3((N + 255) / 256, D), dim3(256), 0, s, h->linv.p, h->zvec.p, N, h->beta.p);
+    if (N >= 1024 && h->opt_tile128 != 0) {
+        // partials in the iK buffer (written by the product that follows)
+        const int nch = (N + 255) / 256;
+        hipLaunchKernelGGL(beta_partial_kernel, dim3((N + 63) / 64, nch, D), dim3(256), 0, s, h->linv.p, h->zvec.p, N, h->iK.p);
+        hipLaunchKernelGGL(beta_reduce_kernel, dim3((N + 255) / 256, D), dim3(256), 0, s, h->iK.p, N, nch, h->beta.p);
+    } else {
+        hipLaunchKernelGGL(beta_kernel, dim3((N + 255) / 256, D), dim3(256), 0, s, h->linv.p, h->zvec.p, N, h->beta.p);
+    }
     if (N >= 1024 && h->opt_outer_block != 0 && h->opt_tile128 != 0) {
         const int nt = (N + T2 - 1) / T2, ntile = nt * (nt + 1) / 2;
         hipLaunchKernelGGL(syrk_inverse_t128_kernel, dim3(8 * ntile * ((D + 7) / 8)), dim3(512), 0, s, h->linv.p, h->beta.p, N, D, ntile,
