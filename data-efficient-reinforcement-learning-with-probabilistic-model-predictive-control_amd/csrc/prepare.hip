@@ -541,23 +541,31 @@ __global__ __launch_bounds__(256) void zvec_kernel(const double* __restrict__ Ya
     if (lane == 0) z[(size_t)a * N + row] = s;
 }
 
+// beta = Y^T z: a workgroup owns 64 columns, four wavefronts share the rows (p = c + g, c + g + 4, ... in units of the
+// column block's first row), four partial sums each, combined in a fixed order.  (One thread per column walked all N rows
+// alone: 20 us at N = 200.)
 __global__ __launch_bounds__(256) void beta_kernel(const double* __restrict__ Yall, const double* __restrict__ z,
                                                    int N, double* __restrict__ beta) {
+    __shared__ double red[4][64];
     const int a = blockIdx.y;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N) return;
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c0 = blockIdx.x * 64, i = c0 + cl;
     const double* Y = Yall + (size_t)a * N * N;
-    // four independent partial sums keep several loads in flight (fixed order: reproducible)
+    const double* za = z + (size_t)a * N;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int p = i;
-    for (; p + 3 < N; p += 4) {
-        s0 = fma(Y[(size_t)p * N + i], z[(size_t)a * N + p], s0);
-        s1 = fma(Y[(size_t)(p + 1) * N + i], z[(size_t)a * N + p + 1], s1);
-        s2 = fma(Y[(size_t)(p + 2) * N + i], z[(size_t)a * N + p + 2], s2);
-        s3 = fma(Y[(size_t)(p + 3) * N + i], z[(size_t)a * N + p + 3], s3);
+    if (i < N) {
+        int p = c0 + rg;                                     // rows above the diagonal hold zeros
+        for (; p + 12 < N; p += 16) {
+            s0 = fma(Y[(size_t)p * N + i], za[p], s0);
+            s1 = fma(Y[(size_t)(p + 4) * N + i], za[p + 4], s1);
+            s2 = fma(Y[(size_t)(p + 8) * N + i], za[p + 8], s2);
+            s3 = fma(Y[(size_t)(p + 12) * N + i], za[p + 12], s3);
+        }
+        for (; p < N; p += 4) s0 = fma(Y[(size_t)p * N + i], za[p], s0);
     }
-    for (; p < N; ++p) s0 = fma(Y[(size_t)p * N + i], z[(size_t)a * N + p], s0);
-    beta[(size_t)a * N + i] = (s0 + s1) + (s2 + s3);
+    red[rg][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rg == 0 && i < N) beta[(size_t)a * N + i] = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
 }
 
 // Large N: beta in two deterministic stages.  One thread per column leaves 1 wavefront per SIMD, each walking up to N rows
@@ -998,7 +1006,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int M = (q == g.nq - 1) ? g.M_last : g.M;
     const int NC = g.NC;
     const int Kd = g.kd_is_m ? M : g.Kd;
-    const int i0 = (t / g.tiles_x) * T2, c0 = (t % g.tiles_x) * T2;
+    // long tiles first: with a triangular left factor the k range grows with the row tile
+    const int trow = g.ktri ? (g.tiles / g.tiles_x - 1 - t / g.tiles_x) : t / g.tiles_x;
+    const int i0 = trow * T2, c0 = (t % g.tiles_x) * T2;
     if (i0 >= M) return;
     const double* A = g.A + (size_t)a * g.sa + (size_t)q * g.qa;
     const double* B = g.B + (size_t)a * g.sb + (size_t)q * g.qb;
@@ -1649,7 +1659,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
         hipLaunchKernelGGL(beta_partial_kernel, dim3((N + 63) / 64, nch, D), dim3(256), 0, s, h->linv.p, h->zvec.p, N, h->iK.p);
         hipLaunchKernelGGL(beta_reduce_kernel, dim3((N + 255) / 256, D), dim3(256), 0, s, h->iK.p, N, nch, h->beta.p);
     } else {
-        hipLaunchKernelGGL(beta_kernel, dim3((N + 255) / 256, D), dim3(256), 0, s, h->linv.p, h->zvec.p, N, h->beta.p);
+        hipLaunchKernelGGL(beta_kernel, dim3((N + 63) / 64, D), dim3(256), 0, s, h->linv.p, h->zvec.p, N, h->beta.p);
     }
     if (N >= 1024 && h->opt_outer_block != 0 && h->opt_tile128 != 0) {
         const int nt = (N + T2 - 1) / T2, ntile = nt * (nt + 1) / 2;

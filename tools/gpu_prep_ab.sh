@@ -7,4 +7,5 @@ timeout 200 rocprofv3 --kernel-trace --stats -d $OUT/prep_trace_$TAG -o prep -- 
 cd $REPO
 python tools/rocpd_summary.py trace $OUT/prep_trace_$TAG/prep_results.db > $OUT/prep_kernel_trace_stats_$TAG.txt
 cut -c1-150 $OUT/prep_kernel_trace_stats_$TAG.txt | head -14
+python tools/rocpd_summary.py list $OUT/prep_trace_$TAG/prep_results.db t128 > $OUT/prep_dispatches_$TAG.txt
 rm -rf $OUT/prep_trace_$TAG

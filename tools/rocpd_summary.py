@@ -23,6 +23,23 @@ def trace(path):
         print(f"#   {r[0][:80]}: min {r[1]/1e3:.1f} us max {r[2]/1e3:.1f} us n={r[3]}")
 
 
+def dispatches(path, substr):
+    """Every dispatch of the kernels whose name contains `substr`, in launch order: duration and grid."""
+    cur = sqlite3.connect(path).cursor()
+    cols = [d[0] for d in cur.execute("select * from kernels limit 1").description]
+    name = "kernel_name" if "kernel_name" in cols else "name"
+    grid = [c for c in ("grid_x", "grid_size_x", "grid_size") if c in cols]
+    q = f"select {name}, start, end" + (f", {grid[0]}" if grid else "") + " from kernels order by start"
+    t0 = None
+    print(f"# dispatches matching '{substr}'  ({path})")
+    for row in cur.execute(q):
+        if t0 is None:
+            t0 = row[1]
+        if substr in row[0]:
+            g = f" grid {row[3]}" if grid else ""
+            print(f"{(row[1] - t0) / 1e3:10.1f} us  +{(row[2] - row[1]) / 1e3:9.1f} us{g}  {row[0][:60]}")
+
+
 def _has(cur, table, col):
     try:
         cols = [d[0] for d in cur.execute(f"select * from {table} limit 1").description]
@@ -85,6 +102,8 @@ def merge_json(key, kernel_substr, paths):
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
         trace(sys.argv[2])
+    elif sys.argv[1] == "list":
+        dispatches(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "json":
         merge_json(sys.argv[2], sys.argv[3], sys.argv[4:])
     else:
