@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void prefix_mismatch_all_kernel(const double* 
 template <int EP>
 __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xt, const double* __restrict__ ils2,
                                                    const double* __restrict__ var, const double* __restrict__ noise,
-                                                   int N, int E, double* __restrict__ K) {
+                                                   int N, int E, double* __restrict__ K, int lower_only) {
     __shared__ double xi[64][EP + 1];          // rows of the tile, pre-scaled by 1 / l_a
     __shared__ double tile[64][65];
     const int a = blockIdx.z;
@@ -173,7 +173,9 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xt
         const int i = i0 + r;
         if (i == j) v += nz;
         tile[r][lane] = v;
-        if (i < N && j < N) Ka[(size_t)i * N + j] = v;
+        // lower_only: the factorisation reads the lower triangle only -- the upper off-diagonal tiles are not stored
+        // (half of the kernel's HBM writes at large N)
+        if (i < N && j < N && (tj == ti || !lower_only)) Ka[(size_t)i * N + j] = v;
     }
     if (tj != ti) {                                  // mirror tile: K[j0 + r][i0 + lane] = tile[lane][r]
         __syncthreads();
@@ -519,23 +521,33 @@ __global__ __launch_bounds__(256) void trinv_row_kernel(const double* __restrict
 }
 
 // z = Y y  (wave per row), beta = Y^T z  (thread per column)
-__global__ __launch_bounds__(256) void zvec_kernel(const double* __restrict__ Yall, const double* __restrict__ Ymem,
-                                                   int N, int D, double* __restrict__ z) {
+// targets (N, D) -> (D, N): the rows of Y are multiplied with ONE column of the targets; read in place, the 64 lanes of a load
+// touch 64 cache lines (stride D doubles)
+__global__ __launch_bounds__(256) void targets_by_gp_kernel(const double* __restrict__ Ymem, int N, int D, double* __restrict__ yt) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= N * D) return;
+    const int a = idx / N, p = idx - a * N;
+    yt[idx] = Ymem[(size_t)p * D + a];
+}
+
+__global__ __launch_bounds__(256) void zvec_kernel(const double* __restrict__ Yall, const double* __restrict__ yt,
+                                                   int N, double* __restrict__ z) {
     const int a = blockIdx.y;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= N) return;
     const double* Y = Yall + (size_t)a * N * N + (size_t)row * N;
+    const double* y = yt + (size_t)a * N;
     // four independent partial sums keep four loads per lane in flight (fixed order: reproducible)
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int p = lane;
     for (; p + 192 <= row; p += 256) {
-        s0 = fma(Y[p], Ymem[(size_t)p * D + a], s0);
-        s1 = fma(Y[p + 64], Ymem[(size_t)(p + 64) * D + a], s1);
-        s2 = fma(Y[p + 128], Ymem[(size_t)(p + 128) * D + a], s2);
-        s3 = fma(Y[p + 192], Ymem[(size_t)(p + 192) * D + a], s3);
+        s0 = fma(Y[p], y[p], s0);
+        s1 = fma(Y[p + 64], y[p + 64], s1);
+        s2 = fma(Y[p + 128], y[p + 128], s2);
+        s3 = fma(Y[p + 192], y[p + 192], s3);
     }
-    for (; p <= row; p += 64) s0 = fma(Y[p], Ymem[(size_t)p * D + a], s0);
+    for (; p <= row; p += 64) s0 = fma(Y[p], y[p], s0);
     double s = (s0 + s1) + (s2 + s3);
     for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
     if (lane == 0) z[(size_t)a * N + row] = s;
@@ -976,6 +988,217 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             for (int r = 0; r < 4; ++r) {
                 const int row = i0 + wi + 16 * x + lk + 4 * r, col = j0 + wj + 16 * y + li;
                 if (row < N && col <= row) unsafeAtomicAdd(&K[(size_t)row * N + col], -acc[x][y][r]);   // one add per element and launch: no read latency to wait for
+            }
+}
+
+// ---- whole outer panel in two launches ---------------------------------------------------------------------------------
+// The 32-column panel chain (block factorisation + panel solve, 8 dependent launches per 128 columns) is ~150 us of
+// critical path per outer panel at N = 4096 -- 18 % of the factorisation.  potrf_block128_kernel factorises the whole
+// 128 x 128 diagonal block of an outer panel in ONE workgroup per GP with the block resident in LDS (stride 130: the
+// MFMA operand reads of 16 rows x 2 k-values fall on 32 distinct banks): per 32 columns a left-looking update on the matrix
+// cores, the register pivot loop of potrf_diag_fast_kernel, the solve of the rows below with L11^-T; the diagonal blocks
+// are replaced by their inverses on the way and a row-block recursion turns the LDS copy into Y_KK = L_KK^-1 (scratch W in
+// the unused upper blocks).  trsm_outer_t128_kernel then solves all rows below the block with one tiled product,
+// L[rows, K] = A[rows, K] Y_KK^T.
+constexpr int kPS = 130;
+
+__global__ __launch_bounds__(1024) void potrf_block128_kernel(double* __restrict__ Kall, double* __restrict__ Yall, int N, int J0,
+                                                              int* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Bk = smem;                                       // (128, 130) the block; diagonal 32-blocks become their inverses
+    double* Yt = Bk + T2 * kPS;                              // (32, 33) L11^-T of the current panel
+    double* colb = Yt + NB * 33;                             // 2 x 64 current / next pivot column (+ identity column)
+    double* sinv = colb + 4 * NB;                            // (32) 1 / L_kk
+    const int a = blockIdx.x;
+    double* K = Kall + (size_t)a * N * N;
+    double* Y = Yall + (size_t)a * N * N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int c32 = tid >> 5, r32 = tid & 31;
+    const int nr = (N - J0 < T2) ? (N - J0) : T2;
+    for (int idx = tid; idx < T2 * T2; idx += 1024) {
+        const int r = idx >> 7, c = idx & 127;
+        Bk[r * kPS + c] = (r < nr && c <= r) ? K[(size_t)(J0 + r) * N + J0 + c] : 0.0;
+    }
+    __syncthreads();
+    for (int k0 = 0; k0 < nr; k0 += NB) {
+        const int nb = (nr - k0 < NB) ? (nr - k0) : NB;
+        // (a) panel -= L[k0:, 0:k0] L[k0:k0+32, 0:k0]^T
+        if (k0 > 0) {
+            const int nrt = (nr - k0 + 15) >> 4;
+            for (int t = wave; t < 2 * nrt; t += 16) {
+                const int i0 = k0 + (t >> 1) * 16, j0 = (t & 1) * 16;
+                d4 acc = {0.0, 0.0, 0.0, 0.0};
+                const double* Ar = Bk + (i0 + li) * kPS + lk;
+                const double* Br = Bk + (k0 + j0 + li) * kPS + lk;
+                for (int pp = 0; pp < k0; pp += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[pp], Br[pp], acc, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) Bk[(i0 + lk + 4 * r) * kPS + k0 + j0 + li] -= acc[r];
+            }
+            __syncthreads();
+        }
+        // (b) 32 x 32 diagonal block: thread (row r32, column c32), identity under it (see potrf_diag_fast_kernel)
+        double a0 = (r32 < nb && c32 < nb && c32 <= r32) ? Bk[(k0 + r32) * kPS + k0 + c32] : 0.0;
+        double a1 = (r32 == c32) ? 1.0 : 0.0;
+        if (c32 == 0) { colb[r32] = a0; colb[NB + r32] = a1; }
+        if (tid == 0) {
+            if (!(a0 > 0.0) && info[a] == 0) info[a] = J0 + k0 + 1;
+            sinv[0] = inv_sqrt_pos_p(a0);
+        }
+        if (tid >= nb && tid < NB) sinv[tid] = 0.0;
+        __syncthreads();
+        for (int k = 0; k + 1 < nb; ++k) {
+            if (2 * wave + 1 > k) {
+                const double* cb = colb + (k & 1) * 2 * NB;
+                double* cn = colb + ((k + 1) & 1) * 2 * NB;
+                const double inv = sinv[k];
+                if (c32 > k && c32 < nb) {
+                    const double lc = cb[c32] * inv;
+                    a0 = fma(-(cb[r32] * inv), lc, a0);
+                    a1 = fma(-(cb[NB + r32] * inv), lc, a1);
+                    if (c32 == k + 1) {
+                        cn[r32] = a0;
+                        cn[NB + r32] = a1;
+                        if (r32 == k + 1) {
+                            if (!(a0 > 0.0) && info[a] == 0) info[a] = J0 + k0 + k + 2;
+                            sinv[k + 1] = inv_sqrt_pos_p(a0);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+        }
+        {
+            const double sc = sinv[c32];                     // 0 for c >= nb
+            const double l = (c32 <= r32) ? a0 * sc : 0.0, y = (r32 <= c32) ? a1 * sc : 0.0;   // y = Y11[c32][r32]
+            Yt[r32 * 33 + c32] = y;
+            Bk[(k0 + c32) * kPS + k0 + r32] = y;             // the diagonal block now holds Y11 (row c32, column r32)
+            if (r32 < nb && c32 <= r32) K[(size_t)(J0 + k0 + r32) * N + J0 + k0 + c32] = l;
+            if (r32 < nb && c32 < nb) Y[(size_t)(J0 + k0 + c32) * N + J0 + k0 + r32] = y;
+        }
+        __syncthreads();
+        // (c) rows below: L21 = A21 L11^-T (a wavefront owns 16 rows and both column halves: it reads before it writes)
+        {
+            const int M = nr - k0 - nb;
+            const int nrt = (M + 15) >> 4;
+            for (int t = wave; t < nrt; t += 16) {
+                const int i0 = k0 + nb + t * 16;
+                d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+                const double* Ar = Bk + (i0 + li) * kPS + k0 + lk;
+#pragma unroll
+                for (int kk = 0; kk < NB; kk += 4) {
+                    const double av = Ar[kk];
+                    acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Yt[(kk + lk) * 33 + li], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Yt[(kk + lk) * 33 + 16 + li], acc1, 0, 0, 0);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the lanes exchange rows through Bk
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = i0 + lk + 4 * r;
+                    Bk[row * kPS + k0 + li] = acc0[r];
+                    Bk[row * kPS + k0 + 16 + li] = acc1[r];
+                    if (row < nr) {
+                        K[(size_t)(J0 + row) * N + J0 + k0 + li] = acc0[r];
+                        K[(size_t)(J0 + row) * N + J0 + k0 + 16 + li] = acc1[r];
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // Y_KK by row blocks, in place: Y[k, c] = -Y_kk (L[k, c:k] Y[c:k, c]); W (32 x k0) in rows 0..31, columns 32.. of Bk
+    for (int k0 = NB; k0 < nr; k0 += NB) {
+        const int nb = (nr - k0 < NB) ? (nr - k0) : NB;
+        const int nct = k0 >> 4;
+        for (int t = wave; t < 2 * nct; t += 16) {
+            const int i0 = (t & 1) * 16, c0 = (t >> 1) * 16;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const double* Ar = Bk + (k0 + i0 + li) * kPS + lk;
+            const double* Bc = Bk + lk * kPS + c0 + li;
+            for (int pp = c0 & ~3; pp < k0; pp += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[pp], Bc[pp * kPS], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Bk[(i0 + lk + 4 * r) * kPS + NB + c0 + li] = acc[r];
+        }
+        __syncthreads();
+        for (int t = wave; t < 2 * nct; t += 16) {
+            const int i0 = (t & 1) * 16, c0 = (t >> 1) * 16;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const double* Ar = Bk + (k0 + i0 + li) * kPS + k0 + lk;
+            const double* Bc = Bk + lk * kPS + NB + c0 + li;
+#pragma unroll
+            for (int m = 0; m < NB; m += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Ar[m], Bc[m * kPS], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + lk + 4 * r;
+                Bk[(k0 + row) * kPS + c0 + li] = -acc[r];
+                if (row < nb) Y[(size_t)(J0 + k0 + row) * N + J0 + c0 + li] = -acc[r];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// L[rows >= J0 + 128, J0 : J0 + 128] = A[rows, J0 : J0 + 128] Y_KK^T on 128-row tiles (k = 128), in place: a workgroup has
+// read all of its rows (the last slice is in LDS behind a barrier) before any wavefront stores.
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void trsm_outer_t128_kernel(double* __restrict__ Kall, const double* __restrict__ Yall, int N, int D, int ntile, int J0, int nk) {
+    __shared__ double S[2 * T2 * SI2];
+    double* const As = S;
+    double* const Bs = S + T2 * SI2;
+    int a, t;
+    {
+        const int id = blockIdx.x, x = id & 7, l = id >> 3;
+        a = x + 8 * (l / ntile);
+        t = l - (l / ntile) * ntile;
+        if (a >= D) return;
+    }
+    double* K = Kall + (size_t)a * N * N;
+    const double* Y = Yall + (size_t)a * N * N;
+    const int i0 = J0 + T2 + t * T2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lk = lane >> 4;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 64;
+    const int srow = tid >> 5, sk = tid & 31;
+    const unsigned offa = ((unsigned)(i0 + srow) * (unsigned)N + (unsigned)sk) * 8u;
+    const unsigned offb = ((unsigned)(J0 + srow) * (unsigned)N + (unsigned)sk) * 8u;
+    const __amdgpu_buffer_rsrc_t ra = operand_rsrc(K, (size_t)N * N * 8);
+    const __amdgpu_buffer_rsrc_t rb = operand_rsrc(Y, (size_t)N * N * 8);
+    d4 acc[2][4];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y) acc[x][y] = {0.0, 0.0, 0.0, 0.0};
+    double av[8], bv[8];
+    auto fetch = [&](int p0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const unsigned so = ((unsigned)(16 * u) * (unsigned)N + (unsigned)(J0 + p0)) * 8u;
+            av[u] = operand_load(ra, offa, so);
+            bv[u] = operand_load(rb, offb, so);
+        }
+    };
+    const double* Af = As + (wi + li) * SI2 + lk;
+    const double* Bf = Bs + (wj + li) * SI2 + lk;
+    double* Aw = As + srow * SI2 + sk;
+    fetch(0);
+    for (int p0 = 0; p0 < nk; p0 += KC) {                            // nk = 128 (a multiple of 32; rows of Y_KK past the block: zero)
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { Aw[16 * u * SI2] = av[u]; Aw[T2 * SI2 + 16 * u * SI2] = bv[u]; }
+        __syncthreads();
+        if (p0 + KC < nk) fetch(p0 + KC);
+        slice_mfma_2x4<1, SI2, 1, SI2, true>(acc, Af, Bf);
+    }
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + wi + 16 * x + lk + 4 * r, col = J0 + wj + 16 * y + li;
+                if (row < N && col < N) K[(size_t)row * N + col] = acc[x][y][r];
             }
 }
 
@@ -1535,19 +1758,56 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     if (!factored) GPMPC_HIP_CHECK(h, hipMemsetAsync(h->Tm.p, 0, (size_t)D * (N + kTPadRows) * N * sizeof(double), s));
     if (!factored) {
         const dim3 grid((N + 63) / 64, (N + 63) / 64, D);
-        if (E <= 4) hipLaunchKernelGGL(gram_kernel<4>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
-        else if (E <= 8) hipLaunchKernelGGL(gram_kernel<8>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
-        else if (E <= 16) hipLaunchKernelGGL(gram_kernel<16>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
-        else hipLaunchKernelGGL(gram_kernel<24>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p);
+        const int lower = (N >= 1024 && h->opt_outer_block != 0) ? 1 : 0;
+        if (E <= 4) hipLaunchKernelGGL(gram_kernel<4>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p, lower);
+        else if (E <= 8) hipLaunchKernelGGL(gram_kernel<8>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p, lower);
+        else if (E <= 16) hipLaunchKernelGGL(gram_kernel<16>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p, lower);
+        else hipLaunchKernelGGL(gram_kernel<24>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p, lower);
         GPMPC_HIP_CHECK(h, hipGetLastError());
     }
     // Outer blocking (large N): the rank-32 trailing update touches the whole trailing matrix per panel -- 32 multiply-adds
     // per 16 bytes read and written, HBM-bound at N = 4096.  With outer panels of 128 columns the 32-wide steps only update
     // the strip inside the outer panel and one LDS-tiled rank-128 product per outer panel does the rest.
     const int OW = (N >= 1024 && h->opt_outer_block != 0) ? 128 : 0;
+    // trailing update after the outer panel that ends at column cend (128 x 128 tiles, binary outer levels)
+    auto outer_update = [&](int cend) -> int {
+        // Binary outer levels: after m = cend / 128 outer panels, with 2^t the largest power of two dividing m
+        // (t <= tmax), the last 2^t panels update the next 2^t tile columns in one product (k = 128 * 2^t) -- or,
+        // at t = tmax, everything to the right.  Every element of the trailing matrix is then read and written
+        // once per 128 * 2^tmax columns instead of once per 128 (the update is bound by that traffic).
+        const int nto = (N - cend + T2 - 1) / T2;
+        const int tmax = h->opt_outer2 < 0 ? 0 : (h->opt_outer2 > 4 ? 4 : h->opt_outer2);
+        const int m = cend / OW;
+        int t = 0;
+        while (t < tmax && (m & ((2 << t) - 1)) == 0) ++t;
+        int nct = (t == tmax) ? nto : (1 << t);
+        if (nct > nto) nct = nto;
+        const int ntile = nct * nto - nct * (nct - 1) / 2;
+        const int wk = OW << t;
+        hipLaunchKernelGGL(syrk_outer_t128_kernel, dim3(8 * ntile * ((D + 7) / 8)), dim3(512), 0, s, h->gram.p, N, D, ntile,
+                           cend - wk, wk, nto);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+        return GPMPC_OK;
+    };
     for (int k0 = 0; k0 < N; k0 += NB) {
         const int nb = (N - k0 < NB) ? (N - k0) : NB;
-        if (!factored) {
+        const bool blk128 = OW && h->opt_tile128 != 0 && h->opt_block128 != 0;
+        if (!factored && blk128) {
+            // whole outer panel: block factorisation (+ its inverse) and the solve of the rows below, two launches
+            if (k0 % OW == 0) {
+                const void* kern = reinterpret_cast<const void*>(potrf_block128_kernel);
+                if ((rc = allow_full_lds(h, kern))) return rc;
+                const size_t lds = (size_t)(T2 * kPS + NB * 33 + 4 * NB + NB) * sizeof(double);
+                hipLaunchKernelGGL(potrf_block128_kernel, dim3(D), dim3(1024), lds, s, h->gram.p, h->linv.p, N, k0, h->info);
+                const int cend = k0 + OW;
+                if (cend < N) {
+                    const int nrow = (N - cend + T2 - 1) / T2;
+                    hipLaunchKernelGGL(trsm_outer_t128_kernel, dim3(8 * nrow * ((D + 7) / 8)), dim3(512), 0, s, h->gram.p, h->linv.p, N, D,
+                                       nrow, k0, OW);
+                    if ((rc = outer_update(cend))) return rc;
+                }
+            }
+        } else if (!factored) {
             const bool fast = h->opt_outer_block != 0;           // round-2 panel kernels (option "outer_block" = 0: the round-1 ones)
             // inside an outer panel the 32-column panels are factorised left-looking (option "inner_left" = 0: right-looking
             // with a rank-32 update of the rest of the outer panel per step)
@@ -1568,24 +1828,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
                     hipLaunchKernelGGL(syrk_trailing_kernel, dim3(ntx < nt ? ntx : nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb, cend);
                 if (OW && k0 + nb == cend && cend < N) {             // outer panel [cend - OW, cend) complete: rank-OW update of the rest
                     if (h->opt_tile128 != 0) {
-                        // two outer levels: after the first 128 columns of a 256-column block only the next 128 columns are
-                        // updated (one strip of tiles, k = 128); after the second, everything to the right with k = 256 --
-                        // the trailing matrix is read and written once per 256 columns
-                        // Binary outer levels: after m = cend / 128 outer panels, with 2^t the largest power of two dividing m
-                        // (t <= tmax), the last 2^t panels update the next 2^t tile columns in one product (k = 128 * 2^t) -- or,
-                        // at t = tmax, everything to the right.  Every element of the trailing matrix is then read and written
-                        // once per 128 * 2^tmax columns instead of once per 128 (the update is bound by that traffic).
-                        const int nto = (N - cend + T2 - 1) / T2;
-                        const int tmax = h->opt_outer2 < 0 ? 0 : (h->opt_outer2 > 4 ? 4 : h->opt_outer2);
-                        const int m = cend / OW;
-                        int t = 0;
-                        while (t < tmax && (m & ((2 << t) - 1)) == 0) ++t;
-                        int nct = (t == tmax) ? nto : (1 << t);
-                        if (nct > nto) nct = nto;
-                        const int ntile = nct * nto - nct * (nct - 1) / 2;
-                        const int wk = OW << t;
-                        hipLaunchKernelGGL(syrk_outer_t128_kernel, dim3(8 * ntile * ((D + 7) / 8)), dim3(512), 0, s, h->gram.p, N, D, ntile,
-                                           cend - wk, wk, nto);
+                        if ((rc = outer_update(cend))) return rc;
                     } else {
                         const int nto = (N - cend + TS - 1) / TS;
                         hipLaunchKernelGGL(syrk_outer_kernel, dim3(nto, nto, D), dim3(256), 0, s, h->gram.p, N, cend - OW, OW);
@@ -1604,7 +1847,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
         // at N = 4096, every launch >= 256 workgroups, instead of 31 dependent steps whose first ones fill a few CUs.
         const size_t NN = (size_t)N * N;
         const int nblk = (N + OW - 1) / OW;
-        for (int koff = NB; koff < OW; koff += NB)
+        for (int koff = NB; koff < OW && h->opt_block128 == 0; koff += NB)      // (potrf_block128_kernel leaves Y_KK behind)
             hipLaunchKernelGGL(trinv_row_kernel, dim3((koff + 31) / 32, D, nblk), dim3(256), 0, s, h->gram.p, h->linv.p, N, 0, 0, 0, OW, koff);
         for (int b = OW; b < N; b *= 2) {
             const int nq = (N - b + 2 * b - 1) / (2 * b);              // pairs q with (2q + 1) b < N
@@ -1652,7 +1895,8 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
         }
     }
     GPMPC_HIP_CHECK(h, hipGetLastError());
-    hipLaunchKernelGGL(zvec_kernel, dim3((N + 3) / 4, D), dim3(256), 0, s, h->linv.p, Y, N, D, h->zvec.p);
+    hipLaunchKernelGGL(targets_by_gp_kernel, dim3((N * D + 255) / 256), dim3(256), 0, s, Y, N, D, h->vv.p);      // vv: border-update scratch, free here
+    hipLaunchKernelGGL(zvec_kernel, dim3((N + 3) / 4, D), dim3(256), 0, s, h->linv.p, h->vv.p, N, h->zvec.p);
     if (N >= 1024 && h->opt_tile128 != 0) {
         // partials in the iK buffer (written by the product that follows)
         const int nch = (N + 255) / 256;
