@@ -154,6 +154,64 @@ def test_factorisation_ragged_sizes(engine, N, D, A):
     assert rel_err(beta.cpu().numpy(), beta0) < 1e-8
 
 
+LARGE = [(1024, 2, {}), (1025, 1, {}), (1151, 9, {}), (1300, 2, {}), (1300, 2, {"block128": 0}),
+         (1300, 2, {"block128": 0, "inner_left": 0}), (1300, 2, {"tile128": 0}), (1300, 2, {"outer2": 0}),
+         (1300, 2, {"outer2": 3}), (1300, 2, {"outer_block": 0}), (1700, 3, {"outer2": 1})]
+
+
+@pytest.mark.parametrize("N,D,opts", LARGE, ids=[f"N{n}-D{d}-" + ("default" if not o else "-".join(f"{k}{v}" for k, v in o.items()))
+                                                  for n, d, o in LARGE])
+def test_large_memory_factorisation_paths(N, D, opts):
+    """N >= 1024: outer panels of 128 columns (LDS-resident block factorisation, 128 x 128 tiled products, binary outer
+    levels, triangular inverse by recursive doubling) -- sizes at and across the 128 / 256 / 512 boundaries, more GPs than
+    XCDs, and every A/B option of the path, all against the CPU oracle's factorisation."""
+    import gp_mpc_amd
+    eng = gp_mpc_amd.HipEngine(0)
+    try:
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        w = synth.make_workload(N, D, 1, 2, 2, seed=N + D)
+        eng.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+        iK, beta = eng.factors()
+        iK0, beta0 = orc.factorize(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+        e_iK, e_beta = rel_err(iK.cpu().numpy(), iK0), rel_err(beta.cpu().numpy(), beta0)
+        record(f"large_factorisation[N{N},D{D},{opts}]", iK=e_iK, beta=e_beta)
+        assert e_iK < 1e-8
+        assert e_beta < 1e-8
+        iKn = iK.cpu().numpy()
+        assert np.array_equal(iKn, iKn.transpose(0, 2, 1))
+        if not opts and D <= 2:
+            # T_a (upper triangle, halved diagonal, zero rows after it) is only visible through a rollout
+            _set_cost(eng, w)
+            out = eng.rollout(w.actions[:1, :1], w.mu0, w.S0)
+            f = orc.Factors(w.X, w.Y, w.lengthscales, w.outputscales, w.noises, iK0, beta0)
+            mu, Sig = orc.predict_trajectory(f, w.actions[:1, :1], w.mu0, w.S0)
+            assert rel_err(out["mu"].cpu().numpy(), mu) < 1e-8
+            assert rel_err(out["Sig"].cpu().numpy(), Sig) < 5e-6
+    finally:
+        eng.close()
+
+
+def test_large_memory_not_positive_definite_then_recovers():
+    """The block factorisation reports the first non-positive pivot (global index) and the handle stays usable."""
+    import gp_mpc_amd
+    eng = gp_mpc_amd.HipEngine(0)
+    try:
+        w = synth.make_workload(1100, 2, 1, 2, 2, seed=5)
+        X = w.X.copy()
+        X[900] = X[300]                      # duplicated point and negative noise => not positive-definite at pivot <= 901
+        with pytest.raises(gp_mpc_amd.NotPositiveDefiniteError) as ei:
+            eng.prepare(X, w.Y, w.lengthscales, w.outputscales, np.zeros(2) - 1e-3)
+        assert "order" in str(ei.value)
+        eng.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+        iK, beta = eng.factors()
+        iK0, beta0 = orc.factorize(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+        assert rel_err(iK.cpu().numpy(), iK0) < 1e-8
+        assert rel_err(beta.cpu().numpy(), beta0) < 1e-8
+    finally:
+        eng.close()
+
+
 def test_not_positive_definite_is_reported(engine):
     import gp_mpc_amd
     w = synth.make_workload(40, 2, 1, 3, 2, seed=3)
