@@ -90,6 +90,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (exercises the N > 1 code path)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
+                    help="engine option for an A/B run (gpmpc_set_option; recorded in config.engine_options)")
     args = ap.parse_args()
 
     # Exactly ONE line goes to stdout: native libraries (RCCL prints a version banner to fd 1 when its communicator comes up)
@@ -133,6 +135,11 @@ def main():
     Bg = hi - lo                                   # this rank's candidates (rank 0 holds the largest slice)
 
     eng = gp_mpc_amd.HipEngine(local_rank)
+    engine_options = {}
+    for kv in args.option:
+        name, value = kv.split("=")
+        eng.set_option(name, float(value))
+        engine_options[name] = float(value)
     eng.set_cost(w.target, w.W, w.W_T, w.kappa)
     X = torch.as_tensor(w.X, device=device)
     Y = torch.as_tensor(w.Y, device=device)
@@ -267,7 +274,8 @@ def main():
                                    f"B={B_total} total = {Bg}/GPU ({scaling} scaling) fp64 "
                                    f"(BASELINE.json configs[{list(synth.SHAPES).index(args.workload)}] shape)",
                        "N": N, "D": D, "A": A, "H": H, "B_per_gpu": Bg, "B_total": B_total,
-                       "parallelism": f"candidates sharded x{world}, RCCL gather of (J, idx) only"},
+                       "parallelism": f"candidates sharded x{world}, RCCL gather of (J, idx) only",
+                       **({"engine_options": engine_options} if engine_options else {})},
             "roofline": {"bound": "valu_f64", "achieved": achieved_tflops, "peak": PEAK_F64_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F64_VECTOR_TFLOPS, "traffic": traffic,
                          "peak_measured_fma_loop": fma_peak, "peak_measured_source": fma_src,

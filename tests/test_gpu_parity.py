@@ -187,7 +187,9 @@ def test_large_memory_factorisation_paths(N, D, opts):
             f = orc.Factors(w.X, w.Y, w.lengthscales, w.outputscales, w.noises, iK0, beta0)
             mu, Sig = orc.predict_trajectory(f, w.actions[:1, :1], w.mu0, w.S0)
             assert rel_err(out["mu"].cpu().numpy(), mu) < 1e-8
-            assert rel_err(out["Sig"].cpu().numpy(), Sig) < 5e-6
+            # S is an O(1e-6) remainder of N^2 terms of size ~1e2 here: two correct fp64 evaluations differ by ~3e-11
+            # absolute; a wrong or misplaced T_a is an O(1) error
+            assert rel_err(out["Sig"].cpu().numpy(), Sig) < 2e-4
     finally:
         eng.close()
 
@@ -652,7 +654,8 @@ def test_full_size_c2_against_oracle_subset(engine):
     assert np.isfinite(out["J"].cpu().numpy()).all()
 
 
-@pytest.mark.parametrize("N,D,A,tm", [(40, 3, 1, False), (200, 3, 1, False), (130, 4, 2, True), (65, 1, 1, False), (300, 6, 3, False)])
+@pytest.mark.parametrize("N,D,A,tm", [(40, 3, 1, False), (200, 3, 1, False), (130, 4, 2, True), (65, 1, 1, False), (300, 6, 3, False),
+                                      (1100, 2, 1, False)])
 def test_training_loss_and_gradient(N, D, A, tm):
     """gpmpc_mll: -log p(y | X, theta) / N of every GP and its gradient wrt (lengthscales, outputscale, noise), the loss
     of the reference's LBFGS training loop (gp_model.py:262-275), vs the closed form of oracle/gp_training.py.
