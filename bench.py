@@ -281,6 +281,11 @@ def main():
                          "peak_measured_fma_loop": fma_peak, "peak_measured_source": fma_src,
                          "frac_of_measured_fma_loop": None if not fma_peak else achieved_tflops / fma_peak,
                          "valu_busy_frac": valu_busy,
+                         # measured bytes at the L2 -> fabric boundary (Infinity Cache or HBM behind it) per second of kernel
+                         # time: at N = 1000 (c4) the T_a tiles no longer stay in the 4 MB L2 of an XCD and this, not the
+                         # VALU, is the higher of the two utilisations
+                         "traffic_gbps": None if not traffic else traffic / (kernel_ms * 1e-3) / 1e9,
+                         "traffic_frac_of_hbm_peak": None if not traffic else traffic / (kernel_ms * 1e-3) / 1e9 / 8000.0,
                          "counters": counters,
                          "hbm_view": {"achieved_gbps": algorithmic_bytes_per_rollout(N, D, E, H) * Bg / (kernel_ms * 1e-3) / 1e9,
                                       "peak_gbps": 8000.0,
@@ -295,7 +300,9 @@ def main():
                                  "separable off-diagonal pairs), so it can exceed what a direct evaluation could reach; "
                                  "valu_busy_frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz) is the "
                                  "hardware-utilisation view of the same launch (null until the counters of this build and "
-                                 "shape are under profiles/); bound is fp64 VALU, not HBM (table T_a is L2-resident)"},
+                                 "shape are under profiles/); bound is fp64 VALU, not HBM, while the tables T_a are L2-resident "
+                                 "(c1-c3: traffic_frac_of_hbm_peak ~ 0); at c4 (D N^2 / 2 x 8 B = 16 MB of T_a per candidate and "
+                                 "step) they are re-streamed through the fabric: compare traffic_frac_of_hbm_peak with valu_busy_frac"},
             "prepare_ms": prepare_ms,
             "prepare_incremental_ms": prepare_incremental_ms,
             "control_step_ms": prepare_ms + elapsed / args.steps * 1e3,
