@@ -198,7 +198,17 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     // 16 waves per candidate beat 8 even when the batch oversubscribes the 256 CUs (340k vs 265k
     // rollouts/s at B = 2048), so 1024 threads unless asked otherwise.
     int nt = h->opt_threads;
-    if (nt != 256 && nt != 512 && nt != 1024) nt = 1024;
+    if (nt != 256 && nt != 512 && nt != 1024) {
+        nt = 1024;
+        // Small memories with batches of several workgroups per CU: the pairwise pass of a step is a few hundred elements per
+        // thread at most, the step is barrier- and latency-bound, and narrower workgroups overlap each other's serial phases
+        // (N = 50, H = 15, tools/gpu_bench_ab.sh: B = 512: 1.85 / 2.61 / 2.16 M rollouts/s with 1024 / 512 / 256 threads,
+        // B = 2048: 2.03 / 3.08 / 3.18 M, B = 8192: 2.08 / 3.27 / 3.51 M; at N = 200 1024 threads win at every B).
+        if (N <= 64) {
+            if (a.B >= 8 * h->num_cu) nt = 256;
+            else if (a.B >= 2 * h->num_cu) nt = 512;
+        }
+    }
     const int nw = nt / 64;
     int rcm = ensure_monomials(h, D);
     if (rcm) return rcm;

@@ -578,6 +578,32 @@ def test_candidates_are_independent(engine):
     assert np.array_equal(full[13:29], part)
 
 
+def test_results_do_not_depend_on_the_workgroup_size():
+    """Small memories with large batches run with narrower workgroups (rollout.hip: 512 / 256 threads from B = 2 / 8 per CU at
+    N <= 64).  The sums are formed per work item in a fixed order, so the results are the same bits for every workgroup size
+    -- and the batch-independence (sharding) property survives the batch-dependent choice."""
+    import gp_mpc_amd
+    w = synth.make_workload(50, 3, 1, 15, 600, seed=6)
+    eng = gp_mpc_amd.HipEngine(0)
+    try:
+        eng.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+        _set_cost(eng, w)
+        res = {}
+        for nt in (1024, 512, 256):
+            eng.set_option("threads", nt)
+            res[nt] = {k: v.cpu().numpy().copy() for k, v in eng.rollout(w.actions, w.mu0, w.S0).items()}
+        for nt in (512, 256):
+            for k in ("J", "mu", "Sig"):
+                assert np.array_equal(res[nt][k], res[1024][k]), (nt, k)
+        eng.set_option("threads", 0)
+        full = eng.rollout(w.actions, w.mu0, w.S0)["J"].cpu().numpy()            # 600 candidates: 512 threads
+        part = eng.rollout(w.actions[13:29], w.mu0, w.S0)["J"].cpu().numpy()     # 16 candidates: 1024 threads
+        assert np.array_equal(full, res[1024]["J"])
+        assert np.array_equal(full[13:29], part)
+    finally:
+        eng.close()
+
+
 def test_argmin_trace_matches_reference(engine):
     g = load("argmin_trace")
     w = workload_of(g)
