@@ -146,20 +146,20 @@ __device__ inline double block_mfma_taylor(const double* st, int ntiles, const d
 
 // Mid-range form of the same item (|g.w| beyond the Taylor range, up to kTableMaxArg): exp(ka' + kb' + c) =
 // e^ka' e^kb' e^c with the per-point factors already in the row record / column factor (exactly as in the Taylor form),
-// and e^c = T[n] P_6(r), n = round(64 c), r = c - n / 64 (exact), |r| <= 1/128, T[n] = exp(n / 64) tabulated in LDS
-// (1025 entries), truncation r^7 / 5040 <= 3.5e-19: 12 VALU instructions per element where the general fast_exp of the
+// and e^c = T[n] P_5(r), n = round(128 c), r = c - n / 128 (exact), |r| <= 1/256, T[n] = exp(n / 128) tabulated in LDS
+// (2049 entries), truncation r^6 / 720 <= 5e-18: 11 VALU instructions per element where the general fast_exp of the
 // direct form needs 16 plus the two additions that form its argument -- on this part the fp64 vector and matrix
 // instructions share one pipe, so every instruction saved per element is time.  Config 5 spends most of its horizon
 // here (predicted variances ~1e-2 give |g.w| ~ 0.5 .. 4).
 constexpr double kTableMaxArg = 7.99;
-constexpr int kTableHalf = 512;                  // T[kTableHalf + n] = exp(n / 64), |n| <= 512
+constexpr int kTableHalf = 1024;                 // T[kTableHalf + n] = exp(n / 128), |n| <= 1024 (16 KB of LDS)
 
 __device__ inline double table_exp(double c, const double* tab /* centre of the table */) {
-    const double n = __builtin_rint(c * 64.0);
-    const double r = fma(n, -0.015625, c);
+    // |r| <= 1 / 256: the degree-5 polynomial truncates at r^6 / 720 <= 5e-18 (spacing 1 / 64 needed degree 6)
+    const double n = __builtin_rint(c * 128.0);
+    const double r = fma(n, -0.0078125, c);
     const double t = tab[(int)n];
-    double q = fma(r, 1.0 / 720, 1.0 / 120);
-    q = fma(q, r, 1.0 / 24);
+    double q = fma(r, 1.0 / 120, 1.0 / 24);
     q = fma(q, r, 1.0 / 6);
     q = fma(q, r, 0.5);
     q = fma(q, r, 1.0);
@@ -190,11 +190,35 @@ __device__ inline double block_mfma_table(const double* st, int ntiles, const do
             const double* w1 = w0 + 16 * RS;
             if (DIAG) { wt[r] *= w0[0]; wt[4 + r] *= w1[0]; } else { wt[r] = w0[1]; wt[4 + r] = w1[1]; }
         }
-        double ev[8];
+        // the 8 evaluations of table_exp stage by stage: written as 8 calls the compiler emits 8 serial chains of 11 dependent
+        // instructions (a dependent fp64 instruction issues every ~40 cycles: 16 cycles per instruction and SIMD even with
+        // four wavefronts), interleaved every instruction has 7 independent ones behind it
+        double cv[8], nv[8], tv[8], qv[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { ev[r] = table_exp(c0[r], tab); ev[4 + r] = table_exp(c1[r], tab); }
+        for (int r = 0; r < 4; ++r) { cv[r] = c0[r]; cv[4 + r] = c1[r]; }
+        // range reduction without rint / convert: adding 1.5 * 2^45 (ulp 2^-7) rounds c to the nearest n / 128 and leaves the
+        // integer n in the low mantissa bits (two's complement); n / 128 comes back exactly by subtracting the constant
+        constexpr double kShift = 52776558133248.0;                                     // 1.5 * 2^45
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e & 3] = fma(ev[e], wt[e], acc[e & 3]);
+        for (int e = 0; e < 8; ++e) nv[e] = cv[e] + kShift;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) tv[e] = tab[(int)__double2loint(nv[e])];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cv[e] -= nv[e] - kShift;                            // r = c - n / 128 (exact)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = fma(cv[e], 1.0 / 120, 1.0 / 24);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = fma(qv[e], cv[e], 1.0 / 6);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = fma(qv[e], cv[e], 0.5);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = fma(qv[e], cv[e], 1.0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qv[e] = fma(qv[e], cv[e], 1.0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wt[e] *= tv[e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e & 3] = fma(qv[e], wt[e], acc[e & 3]);
     }
     return (acc[0] + acc[1]) + (acc[2] + acc[3]);
 }
@@ -261,7 +285,7 @@ __host__ __device__ inline StreamLayout make_stream_layout(int N, int D, int A, 
     L.c_xr = o;     o += rnd2(2 * E);
     L.c_act = o;    o += rnd2(HA);
     L.c_exptab = o; o += 64;
-    L.c_etab = o;   o += (DP % 4 == 0 && DP >= 8) ? 2 * kTableHalf + 2 : 0;     // exp(n / 64), |n| <= 512 (matrix-core pair pass only)
+    L.c_etab = o;   o += (DP % 4 == 0 && DP >= 8) ? 2 * kTableHalf + 2 : 0;     // exp(n / 128), |n| <= 1024 (matrix-core pair pass only)
     L.ush = o;      o += (DP == 16) ? 16 * 64 : 0;                                  // per-wavefront hand-off slot of the D = 16 stage fill
     L.total = o;
     return L;
@@ -317,7 +341,7 @@ __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p)
     double* c_etab = smem + L.c_etab + kTableHalf;                     // centre of the table
     double* s_ush = smem + L.ush;
     if constexpr (kMfma) {
-        for (int i = tid0; i <= 2 * kTableHalf; i += NT) c_etab[i - kTableHalf] = exp((double)(i - kTableHalf) * 0.015625);
+        for (int i = tid0; i <= 2 * kTableHalf; i += NT) c_etab[i - kTableHalf] = exp((double)(i - kTableHalf) * 0.0078125);
     }
     __syncthreads();
     for (int i = tid0; i < D; i += NT) p.mu_out[((size_t)c * (H + 1)) * D + i] = s_mu[i];
