@@ -1769,6 +1769,9 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     // per 16 bytes read and written, HBM-bound at N = 4096.  With outer panels of 128 columns the 32-wide steps only update
     // the strip inside the outer panel and one LDS-tiled rank-128 product per outer panel does the rest.
     const int OW = (N >= 1024 && h->opt_outer_block != 0) ? 128 : 0;
+    // the 128 x 128 tiled kernels address a GP's matrix with 32-bit byte offsets (buffer loads): N^2 * 8 < 4 GiB, N <= 23170;
+    // beyond that the 64 x 64 kernels with 64-bit addresses run
+    const bool tile128 = h->opt_tile128 != 0 && (size_t)N * N * sizeof(double) < 0xFFFFFFFFull;
     // trailing update after the outer panel that ends at column cend (128 x 128 tiles, binary outer levels)
     auto outer_update = [&](int cend) -> int {
         // Binary outer levels: after m = cend / 128 outer panels, with 2^t the largest power of two dividing m
@@ -1791,7 +1794,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     };
     for (int k0 = 0; k0 < N; k0 += NB) {
         const int nb = (N - k0 < NB) ? (N - k0) : NB;
-        const bool blk128 = OW && h->opt_tile128 != 0 && h->opt_block128 != 0;
+        const bool blk128 = OW && tile128 && h->opt_block128 != 0;
         if (!factored && blk128) {
             // whole outer panel: block factorisation (+ its inverse) and the solve of the rows below, two launches
             if (k0 % OW == 0) {
@@ -1827,7 +1830,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
                 if (ntx > 0 && !ll)
                     hipLaunchKernelGGL(syrk_trailing_kernel, dim3(ntx < nt ? ntx : nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb, cend);
                 if (OW && k0 + nb == cend && cend < N) {             // outer panel [cend - OW, cend) complete: rank-OW update of the rest
-                    if (h->opt_tile128 != 0) {
+                    if (tile128) {
                         if ((rc = outer_update(cend))) return rc;
                     } else {
                         const int nto = (N - cend + TS - 1) / TS;
@@ -1840,7 +1843,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
             hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb, 0, 0, 0);
         }
     }
-    if (OW && h->opt_tile128 != 0) {
+    if (OW && tile128) {
         // Y = L^-1 by recursive doubling.  All diagonal 128-blocks Y_KK at once (the 32-row recursion restricted to the columns
         // of the block: 3 launches), then for b = 128, 256, ...: every pair of adjacent b-blocks [[Y11, 0], [Y21, Y22]] gets
         // Y21 = -Y22 (L21 Y11) from two batched tiled products (scratch W = L21 Y11: the iK buffer, written later).  5 levels
@@ -1897,7 +1900,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     GPMPC_HIP_CHECK(h, hipGetLastError());
     hipLaunchKernelGGL(targets_by_gp_kernel, dim3((N * D + 255) / 256), dim3(256), 0, s, Y, N, D, h->vv.p);      // vv: border-update scratch, free here
     hipLaunchKernelGGL(zvec_kernel, dim3((N + 3) / 4, D), dim3(256), 0, s, h->linv.p, h->vv.p, N, h->zvec.p);
-    if (N >= 1024 && h->opt_tile128 != 0) {
+    if (N >= 1024 && tile128) {
         // partials in the iK buffer (written by the product that follows)
         const int nch = (N + 255) / 256;
         hipLaunchKernelGGL(beta_partial_kernel, dim3((N + 63) / 64, nch, D), dim3(256), 0, s, h->linv.p, h->zvec.p, N, h->iK.p);
@@ -1905,7 +1908,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     } else {
         hipLaunchKernelGGL(beta_kernel, dim3((N + 63) / 64, D), dim3(256), 0, s, h->linv.p, h->zvec.p, N, h->beta.p);
     }
-    if (N >= 1024 && h->opt_outer_block != 0 && h->opt_tile128 != 0) {
+    if (N >= 1024 && h->opt_outer_block != 0 && tile128) {
         const int nt = (N + T2 - 1) / T2, ntile = nt * (nt + 1) / 2;
         hipLaunchKernelGGL(syrk_inverse_t128_kernel, dim3(8 * ntile * ((D + 7) / 8)), dim3(512), 0, s, h->linv.p, h->beta.p, N, D, ntile,
                            h->iK.p, h->Tm.p);
