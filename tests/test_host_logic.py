@@ -335,9 +335,9 @@ def test_pending_best_combines_rank_records_like_the_reference_loop():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """profiles/r02_c2_bench.json is the line bench.py printed on the MI355X: schema of the driver's contract."""
+    """profiles/r02b_c2_bench.json is the line bench.py printed on the MI355X: schema of the driver's contract."""
     import json
-    d = json.loads(open(os.path.join(ROOT, "profiles", "r02_c2_bench.json")).read().strip().splitlines()[-1])
+    d = json.loads(open(os.path.join(ROOT, "profiles", "r02b_c2_bench.json")).read().strip().splitlines()[-1])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -353,5 +353,5 @@ def test_committed_bench_line_has_the_contract_fields():
         assert k in c, k
     assert c["kind"] in ("port", "reference")
     assert d["scaling"] == "weak" and 0.0 < r["valu_busy_frac"] < 1.0 and r["peak_measured_fma_loop"] > 30.0
-    d5 = json.loads(open(os.path.join(ROOT, "profiles", "r02_c5_bench_B256.json")).read().strip().splitlines()[-1])
+    d5 = json.loads(open(os.path.join(ROOT, "profiles", "r02b_c5_bench_B256.json")).read().strip().splitlines()[-1])
     assert d5["scaling"] == "strong" and d5["cpu_baseline"].get("extrapolated") is True and d5["config"]["N"] == 4096
