@@ -109,6 +109,7 @@ int gpmpc_set_option(gpmpc_t* g, const char* name, long long value) {
     else if (!strcmp(name, "outer_block")) h->opt_outer_block = (int)value;
     else if (!strcmp(name, "tile128")) h->opt_tile128 = (int)value;
     else if (!strcmp(name, "block128")) h->opt_block128 = (int)value;
+    else if (!strcmp(name, "outer_min_n")) h->opt_outer_min_n = (int)value < 256 ? 256 : (int)value;
     else if (!strcmp(name, "inner_left")) h->opt_inner_left = (int)value;
     else if (!strcmp(name, "outer2")) h->opt_outer2 = (int)value;
     else if (!strcmp(name, "refresh_every")) h->opt_refresh_every = (int)value;

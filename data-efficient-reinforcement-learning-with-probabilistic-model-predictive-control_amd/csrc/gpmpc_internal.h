@@ -128,6 +128,8 @@ struct Handle {
     int opt_incremental = 1;         // reuse / border-update the cached factors when the memory only grew
     int opt_refresh_every = 32;      // full refactorisation after this many border updates (bounds drift)
     int opt_outer2 = 2;              // large N: binary outer levels of the trailing update, up to 128 * 2^value columns (0: 128 only)
+    int opt_outer_min_n = 640;       // memories from this size on take the outer-panel factorisation path (measured crossover:
+                                     // N = 500: 0.61 vs 0.66 ms, 640: 0.92 vs 0.92, 768: 1.22 vs 1.07, 1000: 1.81 vs 1.37; tools/gpu_outer_min_n.py)
     int opt_block128 = 1;            // large N: a whole 128-column outer panel in two launches (LDS-resident block factorisation + tiled solve)
     int opt_inner_left = 1;          // large N: left-looking 32-column panels inside an outer panel; 0: right-looking (A/B)
     int opt_tile128 = 1;             // large N: 128 x 128 tiles (8 wavefronts) for the tiled products; 0: 64 x 64 (A/B)

@@ -1758,7 +1758,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     if (!factored) GPMPC_HIP_CHECK(h, hipMemsetAsync(h->Tm.p, 0, (size_t)D * (N + kTPadRows) * N * sizeof(double), s));
     if (!factored) {
         const dim3 grid((N + 63) / 64, (N + 63) / 64, D);
-        const int lower = (N >= 1024 && h->opt_outer_block != 0) ? 1 : 0;
+        const int lower = (N >= h->opt_outer_min_n && h->opt_outer_block != 0) ? 1 : 0;
         if (E <= 4) hipLaunchKernelGGL(gram_kernel<4>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p, lower);
         else if (E <= 8) hipLaunchKernelGGL(gram_kernel<8>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p, lower);
         else if (E <= 16) hipLaunchKernelGGL(gram_kernel<16>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p, lower);
@@ -1768,7 +1768,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     // Outer blocking (large N): the rank-32 trailing update touches the whole trailing matrix per panel -- 32 multiply-adds
     // per 16 bytes read and written, HBM-bound at N = 4096.  With outer panels of 128 columns the 32-wide steps only update
     // the strip inside the outer panel and one LDS-tiled rank-128 product per outer panel does the rest.
-    const int OW = (N >= 1024 && h->opt_outer_block != 0) ? 128 : 0;
+    const int OW = (N >= h->opt_outer_min_n && h->opt_outer_block != 0) ? 128 : 0;
     // the 128 x 128 tiled kernels address a GP's matrix with 32-bit byte offsets (buffer loads): N^2 * 8 < 4 GiB, N <= 23170;
     // beyond that the 64 x 64 kernels with 64-bit addresses run
     const bool tile128 = h->opt_tile128 != 0 && (size_t)N * N * sizeof(double) < 0xFFFFFFFFull;
@@ -1900,7 +1900,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     GPMPC_HIP_CHECK(h, hipGetLastError());
     hipLaunchKernelGGL(targets_by_gp_kernel, dim3((N * D + 255) / 256), dim3(256), 0, s, Y, N, D, h->vv.p);      // vv: border-update scratch, free here
     hipLaunchKernelGGL(zvec_kernel, dim3((N + 3) / 4, D), dim3(256), 0, s, h->linv.p, h->vv.p, N, h->zvec.p);
-    if (N >= 1024 && tile128) {
+    if (N >= h->opt_outer_min_n && tile128) {
         // partials in the iK buffer (written by the product that follows)
         const int nch = (N + 255) / 256;
         hipLaunchKernelGGL(beta_partial_kernel, dim3((N + 63) / 64, nch, D), dim3(256), 0, s, h->linv.p, h->zvec.p, N, h->iK.p);
@@ -1908,7 +1908,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     } else {
         hipLaunchKernelGGL(beta_kernel, dim3((N + 63) / 64, D), dim3(256), 0, s, h->linv.p, h->zvec.p, N, h->beta.p);
     }
-    if (N >= 1024 && h->opt_outer_block != 0 && tile128) {
+    if (N >= h->opt_outer_min_n && h->opt_outer_block != 0 && tile128) {
         const int nt = (N + T2 - 1) / T2, ntile = nt * (nt + 1) / 2;
         hipLaunchKernelGGL(syrk_inverse_t128_kernel, dim3(8 * ntile * ((D + 7) / 8)), dim3(512), 0, s, h->linv.p, h->beta.p, N, D, ntile,
                            h->iK.p, h->Tm.p);

@@ -107,7 +107,8 @@ int gpmpc_read_factors(gpmpc_t* h, double* iK_dst_dev, double* beta_dst_dev, voi
  * "exact_dim" (2: never the compile-time-D kernel instantiation),
  * "incremental" (0/1, default 1), "refresh_every" (default 32), "fused_prepare" (0/1, default 1: memories of
  * up to 256 points are factorised by one launch, one workgroup per GP; 0 = the panel-by-panel path),
- * and, for memories of 1024 points and more (defaults = the shipped path, the others are A/B and test hooks):
+ * and, for memories of "outer_min_n" (default 640, the measured crossover) points and more (defaults = the shipped path,
+ * the others are A/B and test hooks):
  * "outer_block" (1; 0: 32-wide panels only), "tile128" (1: 128 x 128 tiles with 8 wavefronts for the tiled
  * products; 0: 64 x 64), "outer2" (2: binary outer levels of the trailing update up to 128 * 2^value columns),
  * "block128" (1: a whole 128-column outer panel in two launches; 0: 32-column panels), "inner_left" (1: those
