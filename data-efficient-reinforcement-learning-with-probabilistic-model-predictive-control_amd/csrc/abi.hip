@@ -85,7 +85,6 @@ int gpmpc_destroy(gpmpc_t* g) {
     for (Buf* b : all) free_buf(*b);
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);
-    if (h->mismatch) (void)hipFree(h->mismatch);
     delete g;
     return GPMPC_OK;
 }

@@ -1369,7 +1369,9 @@ __global__ void prefix_mismatch_kernel(const double* __restrict__ a, const doubl
 }
 
 __global__ __launch_bounds__(256) void kvec_kernel(const double* __restrict__ X, int n, int E, const double* __restrict__ ils2,
-                                                   const double* __restrict__ var, int ldk, double* __restrict__ kv) {
+                                                   const double* __restrict__ var, int ldk, double* __restrict__ kv,
+                                                   const int* __restrict__ skip) {
+    if (*skip) return;                                       // the prefix comparison failed: nothing of the update may be written
     const int a = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
@@ -1388,7 +1390,8 @@ __global__ __launch_bounds__(256) void kvec_kernel(const double* __restrict__ X,
 
 // l = L^-1 k  (wave per row, fixed order)
 __global__ __launch_bounds__(256) void border_lvec_kernel(const double* __restrict__ linv, const double* __restrict__ kv, int n,
-                                                          int ldk, double* __restrict__ lv) {
+                                                          int ldk, double* __restrict__ lv, const int* __restrict__ skip) {
+    if (*skip) return;
     const int a = blockIdx.y;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1403,9 +1406,10 @@ __global__ __launch_bounds__(256) void border_lvec_kernel(const double* __restri
 // u (n + 1 entries): 64 columns per workgroup, 16 row slices reduced through LDS in a fixed order
 __global__ __launch_bounds__(1024) void border_u_kernel(const double* __restrict__ linv, const double* __restrict__ lv, int n,
                                                         int ldk, const double* __restrict__ var, const double* __restrict__ noise,
-                                                        double* __restrict__ uv, int* __restrict__ info) {
+                                                        double* __restrict__ uv, int* __restrict__ info, const int* __restrict__ skip) {
     __shared__ double part[16][64];
     __shared__ double ssum[16];
+    if (*skip) return;
     const int a = blockIdx.y;
     const int t = threadIdx.x, lane = t & 63, slice = t >> 6;
     const double* l = lv + (size_t)a * ldk;
@@ -1431,41 +1435,41 @@ __global__ __launch_bounds__(1024) void border_u_kernel(const double* __restrict
     }
 }
 
-// u . y'  (one workgroup per GP)
-__global__ __launch_bounds__(256) void border_dot_kernel(const double* __restrict__ uv, const double* __restrict__ Y, int n, int D,
-                                                         int ldk, double* __restrict__ sc) {
-    __shared__ double r[4];
-    const int a = blockIdx.x;
-    double q = 0.0;
-    for (int i = threadIdx.x; i <= n; i += 256) q = fma(uv[(size_t)a * ldk + i], Y[(size_t)i * D + a], q);
-    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
-    if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = q;
-    __syncthreads();
-    if (threadIdx.x == 0) sc[a] = (r[0] + r[1]) + (r[2] + r[3]);
-}
-
-// iK', L'^-1 ((n+1) x (n+1), compact) and beta' from the n x n ones
+// iK', L'^-1 ((n+1) x (n+1), compact) and beta' from the n x n ones.  The workgroups of the first row band also form
+// u . y' (fixed order) for beta' = [beta; 0] + u (u . y') -- it was a launch of its own.
 __global__ __launch_bounds__(256) void border_apply_kernel(const double* __restrict__ iK, const double* __restrict__ linv,
                                                            const double* __restrict__ beta, const double* __restrict__ uv,
-                                                           const double* __restrict__ sc, int n, int ldk,
+                                                           const double* __restrict__ Y, int D, int n, int ldk,
                                                            double* __restrict__ iKn, double* __restrict__ linvn,
-                                                           double* __restrict__ betan) {
+                                                           double* __restrict__ betan, const int* __restrict__ skip) {
+    __shared__ double r[4];
+    if (*skip) return;
     const int a = blockIdx.z;
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
     const int n1 = n + 1;
+    double dot = 0.0;
+    if (blockIdx.y == 0) {                                   // uniform per workgroup
+        double q = 0.0;
+        for (int p = threadIdx.x; p <= n; p += 256) q = fma(uv[(size_t)a * ldk + p], Y[(size_t)p * D + a], q);
+        for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+        if ((threadIdx.x & 63) == 0) r[threadIdx.x >> 6] = q;
+        __syncthreads();
+        dot = (r[0] + r[1]) + (r[2] + r[3]);
+    }
     if (i > n || j > n) return;
     const double ui = uv[(size_t)a * ldk + i], uj = uv[(size_t)a * ldk + j];
     const bool old = (i < n && j < n);
     const size_t src = ((size_t)a * n + i) * n + j, dst = ((size_t)a * n1 + i) * n1 + j;
     iKn[dst] = fma(ui, uj, old ? iK[src] : 0.0);                    // exactly symmetric
     linvn[dst] = old ? linv[src] : (i == n ? uj : 0.0);
-    if (i == 0) betan[(size_t)a * n1 + j] = fma(uj, sc[a], j < n ? beta[(size_t)a * n + j] : 0.0);
+    if (i == 0) betan[(size_t)a * n1 + j] = fma(uj, dot, j < n ? beta[(size_t)a * n + j] : 0.0);
 }
 
 // T from externally supplied iK / beta (gpmpc_set_factors)
 __global__ __launch_bounds__(256) void tm_kernel(const double* __restrict__ iK, const double* __restrict__ beta, int N,
-                                                 double* __restrict__ T) {
+                                                 double* __restrict__ T, const int* __restrict__ skip) {
+    if (skip && *skip) return;
     const int a = blockIdx.z;
     const int j = blockIdx.x * 64 + (threadIdx.x & 63);
     const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
@@ -1518,8 +1522,11 @@ int ensure_model_buffers(Handle* h, int N, int D, int E, bool need_factor_ws) {
     if ((rc = grow(h, h->kv, DN))) return rc;
     if ((rc = grow(h, h->vv, DN))) return rc;
     if ((rc = grow(h, h->sc, 2 * (size_t)kMaxD))) return rc;
-    if (!h->info) { GPMPC_HIP_CHECK(h, hipMalloc(&h->info, kMaxD * sizeof(int))); GPMPC_HIP_CHECK(h, hipMemset(h->info, 0, kMaxD * sizeof(int))); }
-    if (!h->mismatch) { GPMPC_HIP_CHECK(h, hipMalloc(&h->mismatch, sizeof(int))); GPMPC_HIP_CHECK(h, hipMemset(h->mismatch, 0, sizeof(int))); }
+    if (!h->info) {                                  // info[0 .. kMaxD) | mismatch flag: one read-back covers both
+        GPMPC_HIP_CHECK(h, hipMalloc(&h->info, (kMaxD + 1) * sizeof(int)));
+        GPMPC_HIP_CHECK(h, hipMemset(h->info, 0, (kMaxD + 1) * sizeof(int)));
+        h->mismatch = h->info + kMaxD;
+    }
     return GPMPC_OK;
 }
 
@@ -1553,7 +1560,7 @@ int run_set_factors(Handle* h, const double* X, const double* iK, const double* 
     if ((rc = pack(h, X, ls, os, N, D, E, s))) return rc;
     GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->iK.p, iK, (size_t)D * N * N * sizeof(double), hipMemcpyDeviceToDevice, s));
     GPMPC_HIP_CHECK(h, hipMemcpyAsync(h->beta.p, beta, (size_t)D * N * sizeof(double), hipMemcpyDeviceToDevice, s));
-    hipLaunchKernelGGL(tm_kernel, dim3((N + 63) / 64, (N + kTPadRows + 3) / 4, D), dim3(256), 0, s, h->iK.p, h->beta.p, N, h->Tm.p);
+    hipLaunchKernelGGL(tm_kernel, dim3((N + 63) / 64, (N + kTPadRows + 3) / 4, D), dim3(256), 0, s, h->iK.p, h->beta.p, N, h->Tm.p, nullptr);
     GPMPC_HIP_CHECK(h, hipGetLastError());
     h->N = N; h->D = D; h->E = E; h->ready = true;
     h->have_state = false;                      // no (X, Y, hyper-parameters) record for these factors
@@ -1660,10 +1667,8 @@ __global__ __launch_bounds__(256) void mll_finish_kernel(const double* __restric
 }
 
 // remember what the cached factors were computed from
-static int check_info(Handle* h, int D, hipStream_t s) {
-    int info[kMaxD];
-    GPMPC_HIP_CHECK(h, hipMemcpyAsync(info, h->info, kMaxD * sizeof(int), hipMemcpyDeviceToHost, s));
-    GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
+// pivot info read back from the device -> error state (info is cleared again: zero when idle)
+static int check_info_host(Handle* h, const int* info, int D, hipStream_t s) {
     for (int a = 0; a < D; ++a) {
         if (info[a] != 0) {
             char buf[160];
@@ -1677,6 +1682,13 @@ static int check_info(Handle* h, int D, hipStream_t s) {
         }
     }
     return GPMPC_OK;
+}
+
+static int check_info(Handle* h, int D, hipStream_t s) {
+    int info[kMaxD];
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(info, h->info, kMaxD * sizeof(int), hipMemcpyDeviceToHost, s));
+    GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
+    return check_info_host(h, info, D, s);
 }
 
 // Border-update / reuse of the cached factors; returns 1 if it handled the call, 0 to fall through to the
@@ -1701,27 +1713,41 @@ static int try_incremental(Handle* h, const double* X, const double* Y, const do
         hipLaunchKernelGGL(prefix_mismatch_all_kernel, dim3(nb), dim3(256), 0, s, X, h->Xc.p, nX, Y, h->Yc.p, nY, ls, os, noise,
                            h->hyp.p, D, E, h->mismatch);
     }
-    int flag = 1;
-    GPMPC_HIP_CHECK(h, hipMemcpyAsync(&flag, h->mismatch, sizeof(int), hipMemcpyDeviceToHost, s));
-    GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
-    if (flag) { GPMPC_HIP_CHECK(h, hipMemsetAsync(h->mismatch, 0, sizeof(int), s)); return 0; }
-    if (k == 0) { h->last_prepare_mode = 2; return 1; }           // nothing changed: the factors are current
+    if (k == 0) {                                                  // nothing appended: cache hit if the comparison says so
+        int flag = 1;
+        GPMPC_HIP_CHECK(h, hipMemcpyAsync(&flag, h->mismatch, sizeof(int), hipMemcpyDeviceToHost, s));
+        GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
+        if (flag) { GPMPC_HIP_CHECK(h, hipMemsetAsync(h->mismatch, 0, sizeof(int), s)); return 0; }
+        h->last_prepare_mode = 2;
+        return 1;
+    }
+    // The border update is enqueued behind the comparison without waiting for its verdict: every kernel of it returns at once
+    // when the flag is set, so a failed comparison leaves the cached factors untouched.  ONE read-back (flag + pivot info)
+    // at the end decides (was: a synchronisation for the flag, then one for the pivots).
+    const Buf b_iK = h->iK, b_gram = h->gram, b_linv = h->linv, b_Tm = h->Tm, b_beta = h->beta, b_zvec = h->zvec;
     for (int n = n0; n < N; ++n) {                                  // (info is zero when idle: check_info clears it after a failure)
-        hipLaunchKernelGGL(kvec_kernel, dim3((n + 255) / 256, D), dim3(256), 0, s, X, n, E, h->ils2.p, h->var.p, N, h->kv.p);
-        hipLaunchKernelGGL(border_lvec_kernel, dim3((n + 3) / 4, D), dim3(256), 0, s, h->linv.p, h->kv.p, n, N, h->vv.p);
+        hipLaunchKernelGGL(kvec_kernel, dim3((n + 255) / 256, D), dim3(256), 0, s, X, n, E, h->ils2.p, h->var.p, N, h->kv.p, h->mismatch);
+        hipLaunchKernelGGL(border_lvec_kernel, dim3((n + 3) / 4, D), dim3(256), 0, s, h->linv.p, h->kv.p, n, N, h->vv.p, h->mismatch);
         hipLaunchKernelGGL(border_u_kernel, dim3((n + 64) / 64, D), dim3(1024), 0, s, h->linv.p, h->vv.p, n, N, h->var.p, noise,
-                           h->kv.p, h->info);                                        // u overwrites k
-        hipLaunchKernelGGL(border_dot_kernel, dim3(D), dim3(256), 0, s, h->kv.p, Y, n, D, N, h->sc.p);
+                           h->kv.p, h->info, h->mismatch);                           // u overwrites k
         hipLaunchKernelGGL(border_apply_kernel, dim3((n + 64) / 64, (n + 4) / 4, D), dim3(256), 0, s, h->iK.p, h->linv.p,
-                           h->beta.p, h->kv.p, h->sc.p, n, N, h->gram.p, h->Tm.p, h->zvec.p);
+                           h->beta.p, h->kv.p, Y, D, n, N, h->gram.p, h->Tm.p, h->zvec.p, h->mismatch);
         Buf t = h->iK; h->iK = h->gram; h->gram = t;
         t = h->linv; h->linv = h->Tm; h->Tm = t;
         t = h->beta; h->beta = h->zvec; h->zvec = t;
     }
+    hipLaunchKernelGGL(tm_kernel, dim3((N + 63) / 64, (N + kTPadRows + 3) / 4, D), dim3(256), 0, s, h->iK.p, h->beta.p, N, h->Tm.p,
+                       h->mismatch);
     GPMPC_HIP_CHECK(h, hipGetLastError());
-    hipLaunchKernelGGL(tm_kernel, dim3((N + 63) / 64, (N + kTPadRows + 3) / 4, D), dim3(256), 0, s, h->iK.p, h->beta.p, N, h->Tm.p);
-    GPMPC_HIP_CHECK(h, hipGetLastError());
-    int rc = check_info(h, D, s);
+    int verdict[kMaxD + 1];
+    GPMPC_HIP_CHECK(h, hipMemcpyAsync(verdict, h->info, (kMaxD + 1) * sizeof(int), hipMemcpyDeviceToHost, s));
+    GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
+    if (verdict[kMaxD]) {                                          // not a prefix: nothing was written; back to the full path
+        h->iK = b_iK; h->gram = b_gram; h->linv = b_linv; h->Tm = b_Tm; h->beta = b_beta; h->zvec = b_zvec;
+        GPMPC_HIP_CHECK(h, hipMemsetAsync(h->mismatch, 0, sizeof(int), s));
+        return 0;
+    }
+    int rc = check_info_host(h, verdict, D, s);
     if (rc) return rc;
     if ((rc = pack_and_record(h, X, Y, ls, os, noise, N, D, E, s))) return rc;
     h->N = N;
