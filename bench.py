@@ -306,6 +306,8 @@ def main():
             "prepare_ms": prepare_ms,
             "prepare_incremental_ms": prepare_incremental_ms,
             "control_step_ms": prepare_ms + elapsed / args.steps * 1e3,
+            # the step of a running controller: the memory grew by one point since the previous step (border update)
+            "control_step_incremental_ms": None if prepare_incremental_ms is None else prepare_incremental_ms + elapsed / args.steps * 1e3,
             "gradient": None if grad_ms is None else {
                 "ms_per_launch": grad_ms, "objective_gradients_per_s": Bg / (grad_ms * 1e-3),
                 "rollouts_the_same_gradients_cost_by_differences": Bg * (4 * H * A + 1),
