@@ -441,11 +441,13 @@ __device__ inline double item_exp(const double* rec, int nrows, const double (&w
 // Two columns per lane (j, j + 1): the row operands (ev_i, g_i) are LDS broadcasts whose return bandwidth, not the
 // VALU, bounds the one-column loop at small D (32 bytes per lane and row for 12 FMAs); serving two columns per read
 // halves that traffic.  Two rows x two columns in flight = the same four independent chains as the one-column loop.
-template <int DP, int K>
+// U = rows per trip = depth of the T prefetch.  With the tables in L2 (configs 1-3) two rows ahead are enough and the
+// shorter trip is 2 % faster; at config 4 (N = 1000, D = 4) the loads come from the Infinity Cache and four rows ahead gain
+// 5 % (115.2 -> 109.2 ms); eight rows spill and lose.
+template <int DP, int K, int U>
 __device__ inline void item_taylor2(const double* rec, int nrows, const double (&w0)[DP], const double (&w1)[DP], bool diag,
                                     const double* Tp, int N, double& acc0, double& acc1) {
     constexpr int RS = DP + 2;
-    constexpr int U = 2;
     acc0 = 0.0;
     acc1 = 0.0;
     if (diag) {
@@ -1181,16 +1183,19 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                             item_exp2<DP>(rec, nrows, w, w1, kbj, kb1, diag, Tp, N, c_exptab, acc0, acc1);
                             acc = acc0 * (diag ? 2.0 : p.beta[b * N + j]) + (valid1 ? acc1 * (diag ? 2.0 : p.beta[b * N + j + 1]) : 0.0);
                         } else {
-                            if (K <= 2) item_taylor2<DP, 2>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
-                            else if (K == 3) item_taylor2<DP, 3>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
-                            else if (K == 4) item_taylor2<DP, 4>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
-                            else if (K == 5) item_taylor2<DP, 5>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
-                            else if (K == 6) item_taylor2<DP, 6>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
-                            else if (K == 7) item_taylor2<DP, 7>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
-                            else if (K == 8) item_taylor2<DP, 8>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
-                            else if (K <= 10) item_taylor2<DP, 10>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
-                            else if (K <= 12) item_taylor2<DP, 12>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
-                            else item_taylor2<DP, 14>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            // rows per trip = depth of the T prefetch (see item_taylor2): 4 from DP = 4 up.  One
+                            // instantiation per degree: a second one (choice by N) cost config 2 2.7 % through the larger kernel.
+                            constexpr int TU = DP >= 4 ? 4 : 2;
+                            if (K <= 2) item_taylor2<DP, 2, TU>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K == 3) item_taylor2<DP, 3, TU>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K == 4) item_taylor2<DP, 4, TU>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K == 5) item_taylor2<DP, 5, TU>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K == 6) item_taylor2<DP, 6, TU>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K == 7) item_taylor2<DP, 7, TU>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K == 8) item_taylor2<DP, 8, TU>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K <= 10) item_taylor2<DP, 10, TU>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else if (K <= 12) item_taylor2<DP, 12, TU>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
+                            else item_taylor2<DP, 14, TU>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
                             acc = fma(acc0, kbj, acc1 * kb1) * (diag ? 2.0 : 1.0);
                         }
                     } else if (K == 0) {
