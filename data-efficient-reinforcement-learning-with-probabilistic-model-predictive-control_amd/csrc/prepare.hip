@@ -344,9 +344,22 @@ __global__ __launch_bounds__(256) void trsm_panel_mfma_kernel(double* __restrict
     const int a = blockIdx.y;
     double* K = Kall + (size_t)a * N * N;
     const double* Y = Yall + (size_t)a * N * N;
-    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
-        const int j = idx / NB, k = idx % NB;
-        yt[k][j] = (j < nb && k <= j) ? Y[(size_t)(k0 + j) * N + k0 + k] : 0.0;
+    {
+        // the four loads of a thread in flight (clamped address + select; a branch per element makes the compiler wait for
+        // every load before the next: 4 L2 round trips on the critical path of every panel)
+        const int k = threadIdx.x & 31, j0 = threadIdx.x >> 5;
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 8 * u;
+            const int jj = j < nb ? j : nb - 1, kk = k <= jj ? k : jj;
+            v[u] = Y[(size_t)(k0 + jj) * N + k0 + kk];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + 8 * u;
+            yt[k][j] = (j < nb && k <= j) ? v[u] : 0.0;
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -495,9 +508,20 @@ __global__ __launch_bounds__(256) void trinv_row_kernel(const double* __restrict
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
     const int li = lane & 15, lk = lane >> 4;
-    for (int idx = threadIdx.x; idx < NB * NB; idx += 256) {
-        const int r = idx / NB, c = idx % NB;
-        ykk[r][c] = (r < nb && c <= r) ? Y[(size_t)(k0 + r) * N + (k0 + c)] : 0.0;
+    {
+        const int c = threadIdx.x & 31, r0 = threadIdx.x >> 5;          // four loads in flight (see trsm_panel_mfma_kernel)
+        double v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 8 * u;
+            const int rr = r < nb ? r : nb - 1, cc = c <= rr ? c : rr;
+            v[u] = Y[(size_t)(k0 + rr) * N + (k0 + cc)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 8 * u;
+            ykk[r][c] = (r < nb && c <= r) ? v[u] : 0.0;
+        }
     }
     d4 acc = {0.0, 0.0, 0.0, 0.0};
     const bool rowin = (wi + li < nb);
@@ -1016,9 +1040,22 @@ __global__ __launch_bounds__(1024) void potrf_block128_kernel(double* __restrict
     const int li = lane & 15, lk = lane >> 4;
     const int c32 = tid >> 5, r32 = tid & 31;
     const int nr = (N - J0 < T2) ? (N - J0) : T2;
-    for (int idx = tid; idx < T2 * T2; idx += 1024) {
-        const int r = idx >> 7, c = idx & 127;
-        Bk[r * kPS + c] = (r < nr && c <= r) ? K[(size_t)(J0 + r) * N + J0 + c] : 0.0;
+    {
+        // all 16 loads of a thread in flight (clamped addresses + selects: with a branch per element the compiler emitted
+        // load - wait - store sixteen times, ~20 us of a 59 us kernel)
+        const int c = tid & 127, r0 = tid >> 7;
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = r0 + 8 * u;
+            const int rr = r < nr ? r : nr - 1, cc = c <= rr ? c : rr;
+            v[u] = K[(size_t)(J0 + rr) * N + J0 + cc];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int r = r0 + 8 * u;
+            Bk[r * kPS + c] = (r < nr && c <= r) ? v[u] : 0.0;
+        }
     }
     __syncthreads();
     for (int k0 = 0; k0 < nr; k0 += NB) {
