@@ -1266,9 +1266,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int M = (q == g.nq - 1) ? g.M_last : g.M;
     const int NC = g.NC;
     const int Kd = g.kd_is_m ? M : g.Kd;
-    // long tiles first: with a triangular left factor the k range grows with the row tile
-    const int trow = g.ktri ? (g.tiles / g.tiles_x - 1 - t / g.tiles_x) : t / g.tiles_x;
-    const int i0 = trow * T2, c0 = (t % g.tiles_x) * T2;
+    // long tiles first: with a triangular left factor (ktri) the k range grows with the row tile -> rows in descending order;
+    // with a triangular right factor (kskip) it shrinks with the column tile -> column by column
+    const int trows = g.tiles / g.tiles_x;
+    int trow, tcol;
+    if (g.kskip) { tcol = t / trows; trow = t - tcol * trows; }
+    else { trow = g.ktri ? (trows - 1 - t / g.tiles_x) : t / g.tiles_x; tcol = t % g.tiles_x; }
+    const int i0 = trow * T2, c0 = tcol * T2;
     if (i0 >= M) return;
     const double* A = g.A + (size_t)a * g.sa + (size_t)q * g.qa;
     const double* B = g.B + (size_t)a * g.sb + (size_t)q * g.qb;
