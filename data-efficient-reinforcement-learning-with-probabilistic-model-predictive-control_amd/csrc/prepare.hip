@@ -834,6 +834,21 @@ constexpr int T2 = 128;
 constexpr int SI2 = KC + 2;        // i-major slice: 128 rows x 32 k, stride 34
 constexpr int SK2 = T2 + 16;       // k-major slice: 32 k x 128 columns, stride 144 (144 mod 32 = 16: see SK)
 
+// 1-D grid of nbatch x ntile workgroups -> (batch, tile).  Workgroup ids are dealt round-robin to the 8 XCDs; when the
+// number of batches (GPs) is a multiple of 8 every XCD works through whole batches (a, a + 8, ...) tile by tile, so the
+// workgroups sharing an L2 read the same operand blocks.  Otherwise (D = 4 at config 4) that would leave XCDs without work:
+// batches are then laid out one after the other and their tiles spread over all XCDs.
+__device__ inline void xcd_batch_tile(int id, int nbatch, int ntile, int& batch, int& tile) {
+    if ((nbatch & 7) == 0) {
+        const int x = id & 7, l = id >> 3;
+        batch = x + 8 * (l / ntile);
+        tile = l - (l / ntile) * ntile;
+    } else {
+        batch = id / ntile;
+        tile = id - batch * ntile;
+    }
+}
+
 // lower-triangle tile (ti >= tj) number t -> (ti, tj), row by row
 __device__ inline void tri_tile(int t, int& ti, int& tj) {
     int r = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
@@ -883,10 +898,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ double Bs[KC * SK2];
     int a, t;
     {
-        const int id = blockIdx.x, x = id & 7, l = id >> 3;
-        // GPs a = x, x + 8, ... on XCD x (D need not be a multiple of 8: ids past the end fall out below)
-        a = x + 8 * (l / ntile);
-        t = l - (l / ntile) * ntile;
+        xcd_batch_tile(blockIdx.x, D, ntile, a, t);
         if (a >= D) return;
     }
     int ti, tj;
@@ -957,9 +969,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     double* const Bs = S + T2 * SI2;
     int a, t;
     {
-        const int id = blockIdx.x, x = id & 7, l = id >> 3;
-        a = x + 8 * (l / ntile);
-        t = l - (l / ntile) * ntile;
+        xcd_batch_tile(blockIdx.x, D, ntile, a, t);
         if (a >= D) return;
     }
     int ti, tj;
@@ -1186,9 +1196,7 @@ void trsm_outer_t128_kernel(double* __restrict__ Kall, const double* __restrict_
     double* const Bs = S + T2 * SI2;
     int a, t;
     {
-        const int id = blockIdx.x, x = id & 7, l = id >> 3;
-        a = x + 8 * (l / ntile);
-        t = l - (l / ntile) * ntile;
+        xcd_batch_tile(blockIdx.x, D, ntile, a, t);
         if (a >= D) return;
     }
     double* K = Kall + (size_t)a * N * N;
@@ -1257,9 +1265,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     __shared__ double Bs[KC * SK2];
     int z, t;
     {
-        const int id = blockIdx.x, x = id & 7, l = id >> 3;
-        z = x + 8 * (l / g.tiles);
-        t = l - (l / g.tiles) * g.tiles;
+        xcd_batch_tile(blockIdx.x, g.nbatch, g.tiles, z, t);
         if (z >= g.nbatch) return;
     }
     const int a = z / g.nq, q = z - a * g.nq;
@@ -1854,7 +1860,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
         if (nct > nto) nct = nto;
         const int ntile = nct * nto - nct * (nct - 1) / 2;
         const int wk = OW << t;
-        hipLaunchKernelGGL(syrk_outer_t128_kernel, dim3(8 * ntile * ((D + 7) / 8)), dim3(512), 0, s, h->gram.p, N, D, ntile,
+        hipLaunchKernelGGL(syrk_outer_t128_kernel, dim3(ntile * D), dim3(512), 0, s, h->gram.p, N, D, ntile,
                            cend - wk, wk, nto);
         GPMPC_HIP_CHECK(h, hipGetLastError());
         return GPMPC_OK;
@@ -1872,7 +1878,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
                 const int cend = k0 + OW;
                 if (cend < N) {
                     const int nrow = (N - cend + T2 - 1) / T2;
-                    hipLaunchKernelGGL(trsm_outer_t128_kernel, dim3(8 * nrow * ((D + 7) / 8)), dim3(512), 0, s, h->gram.p, h->linv.p, N, D,
+                    hipLaunchKernelGGL(trsm_outer_t128_kernel, dim3(nrow * D), dim3(512), 0, s, h->gram.p, h->linv.p, N, D,
                                        nrow, k0, OW);
                     if ((rc = outer_update(cend))) return rc;
                 }
@@ -1933,7 +1939,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
             g.tiles = g.tiles_x * ((b + T2 - 1) / T2);
             const size_t off21 = (size_t)b * N;                        // block (1, 0) of a pair relative to its block (0, 0)
             const size_t off22 = (size_t)b * N + b;
-            const dim3 grid(8 * g.tiles * ((g.nbatch + 7) / 8));
+            const dim3 grid(g.tiles * g.nbatch);
             // W = L21 Y11
             g.A = h->gram.p + off21; g.B = h->linv.p; g.C = h->iK.p + off21;
             g.a_rem = NN - off21;
@@ -1977,7 +1983,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     }
     if (N >= h->opt_outer_min_n && h->opt_outer_block != 0 && tile128) {
         const int nt = (N + T2 - 1) / T2, ntile = nt * (nt + 1) / 2;
-        hipLaunchKernelGGL(syrk_inverse_t128_kernel, dim3(8 * ntile * ((D + 7) / 8)), dim3(512), 0, s, h->linv.p, h->beta.p, N, D, ntile,
+        hipLaunchKernelGGL(syrk_inverse_t128_kernel, dim3(ntile * D), dim3(512), 0, s, h->linv.p, h->beta.p, N, D, ntile,
                            h->iK.p, h->Tm.p);
     } else if (N >= 512 && h->opt_outer_block != 0) {
         const int nt = (N + TS - 1) / TS;
