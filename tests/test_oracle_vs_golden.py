@@ -198,7 +198,8 @@ def test_numpy_adjoint_replays_the_reference_optimize_true_trace(name):
         assert rel_err(grad.reshape(-1), g["eval_grad"][k]) < 1e-6, k
 
 
-@pytest.mark.parametrize("N,D,A,H,tm", [(30, 3, 1, 5, False), (25, 2, 2, 4, True), (40, 4, 2, 3, False)])
+@pytest.mark.parametrize("N,D,A,H,tm", [(30, 3, 1, 5, False), (25, 2, 2, 4, True), (40, 4, 2, 3, False),
+                                        (24, 9, 2, 2, False), (20, 16, 4, 2, True)])      # D > 8: beyond the gradient kernels today
 def test_numpy_adjoint_matches_torch_autograd_of_the_reference_op_sequence(N, D, A, H, tm):
     import torch
     from oracle import adjoint, synth
