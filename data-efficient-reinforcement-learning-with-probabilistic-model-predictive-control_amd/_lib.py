@@ -41,6 +41,8 @@ SIGNATURES = {
     "gpmpc_get_factors": (C.c_int, [_P, C.POINTER(_P), C.POINTER(_P)]),
     "gpmpc_read_factors": (C.c_int, [_P, _P, _P, _P]),
     "gpmpc_last_prepare_mode": (C.c_int, [_P]),
+    "gpmpc_last_rollout_path": (C.c_int, [_P]),
+    "gpmpc_build_id": (C.c_char_p, []),
     "gpmpc_mll": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(_D), _P]),
     "gpmpc_set_option": (C.c_int, [_P, C.c_char_p, C.c_longlong]),
     "gpmpc_set_cost": (C.c_int, [_P, _P, _P, _P, _D, _I, _P, _P, _I, _I]),
@@ -53,7 +55,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 def load(path=LIB_PATH):

@@ -206,6 +206,13 @@ class GpMpcController(BaseControllerObject):
                       "keeping the current hyper-parameters")
                 params = None
             self.p_train.join()
+            if isinstance(params, TrainingFailed):
+                # the child answered, but could not train (no GPU for it, unsupported device, search raised): say so
+                # instead of silently carrying stale hyper-parameters (they are the incoming ones)
+                self.training_failures = getattr(self, "training_failures", 0) + 1
+                print(f"GP training failed ({params.reason}): keeping the current hyper-parameters "
+                      f"({self.training_failures} failed training(s) so far)")
+                params = None
             if params is not None:
                 for model, p in zip(self.transition_model.models, params):
                     model.initialize(**p)

@@ -97,23 +97,91 @@ def create_models(gp_init_dict, num_models, num_inputs):
             for i in range(num_models)]
 
 
+class TrainingFailed(list):
+    """Answer of a training process that could not train: the list of the INCOMING parameter dicts (so a consumer
+    that only wants parameters can use it as is) with the reason attached."""
+
+    def __init__(self, parameters=(), reason=""):
+        super().__init__(parameters)
+        self.reason = reason
+
+    def __reduce__(self):
+        return (TrainingFailed, (list(self), self.reason))
+
+
+class _LockstepMll:
+    """Rendezvous of the per-GP optimiser threads of `train`: a thread asks for the loss of its GP and waits; when every
+    unfinished GP is waiting, the last one to arrive evaluates ALL pending GPs with one gpmpc_mll call (the kernels
+    batch over GPs).  If the batched call fails (a GP whose K is not positive definite at its trial point), the pending
+    GPs are evaluated one by one so that only the failing GP sees the error."""
+
+    def __init__(self, engine, X_dev, Y_dev, n_gp):
+        import threading
+        self.engine, self.X, self.Y = engine, X_dev, Y_dev
+        self.cond = threading.Condition()
+        self.pending, self.results = {}, {}
+        self.running = n_gp
+        self.launches = 0
+
+    def _flush(self):                                  # called with the lock held
+        idx = sorted(self.pending)
+        ls = torch.stack([self.pending[i][0].reshape(-1) for i in idx])
+        osc = torch.stack([self.pending[i][1].reshape(()) for i in idx])
+        nz = torch.stack([self.pending[i][2].reshape(()) for i in idx])
+        try:
+            out = self.engine.mll(self.X, self.Y[:, idx].contiguous(), ls, osc, nz)
+            self.launches += 1
+            for k, i in enumerate(idx):
+                self.results[i] = (float(out["loss"][k]), out["d_lengthscale"][k], float(out["d_outputscale"][k]),
+                                   float(out["d_noise"][k]))
+        except Exception:
+            for k, i in enumerate(idx):
+                try:
+                    o = self.engine.mll(self.X, self.Y[:, i:i + 1].contiguous(), ls[k:k + 1], osc[k:k + 1], nz[k:k + 1])
+                    self.launches += 1
+                    self.results[i] = (float(o["loss"][0]), o["d_lengthscale"][0], float(o["d_outputscale"][0]),
+                                       float(o["d_noise"][0]))
+                except Exception as e:
+                    self.results[i] = e
+        self.pending.clear()
+        self.cond.notify_all()
+
+    def evaluate(self, a, ls, osc, nz):
+        with self.cond:
+            self.pending[a] = (ls, osc, nz)
+            if len(self.pending) == self.running:
+                self._flush()
+            while a not in self.results:
+                self.cond.wait()
+            r = self.results.pop(a)
+        if isinstance(r, Exception):
+            raise r
+        return r
+
+    def finished(self, a):
+        with self.cond:
+            self.running -= 1
+            if self.pending and len(self.pending) == self.running:
+                self._flush()
+
+
 class _DeviceNegMll(torch.autograd.Function):
     """-log p(y | X, theta) / N with its gradient from gpmpc_mll (reference: gpytorch ExactMarginalLogLikelihood +
-    autograd, gp_model.py:262-275)."""
+    autograd, gp_model.py:262-275); `shared` batches the evaluations of the GPs that are waiting (see _LockstepMll)."""
 
     @staticmethod
-    def forward(ctx, ls, osc, nz, engine, X_dev, y_dev):
-        out = engine.mll(X_dev, y_dev, ls.detach().reshape(1, -1), osc.detach().reshape(1), nz.detach().reshape(1))
+    def forward(ctx, ls, osc, nz, shared, a):
+        loss, gl, go, gn = shared.evaluate(a, ls.detach(), osc.detach(), nz.detach())
         ctx.shapes = (ls.shape, osc.shape, nz.shape)
-        ctx.grads = (out["d_lengthscale"][0], out["d_outputscale"][0], out["d_noise"][0])
-        return torch.tensor(float(out["loss"][0]), dtype=F64)
+        ctx.grads = (gl, go, gn)
+        return torch.tensor(loss, dtype=F64)
 
     @staticmethod
     def backward(ctx, gout):
         gl, go, gn = ctx.grads
         sl, so, sn = ctx.shapes
         return (gout * torch.as_tensor(gl, dtype=F64).reshape(sl), gout * torch.tensor(float(go), dtype=F64).reshape(so),
-                gout * torch.tensor(float(gn), dtype=F64).reshape(sn), None, None, None)
+                gout * torch.tensor(float(gn), dtype=F64).reshape(sn), None, None)
 
 
 class GpStateTransitionModel(AbstractStateTransitionModel):
@@ -128,6 +196,8 @@ class GpStateTransitionModel(AbstractStateTransitionModel):
         self.x_mem = None
         self.y_mem = None
         self._cost_key = None
+
+    last_training_launches = None       # gpmpc_mll calls of the last `train` in this process (lockstep: ~ the longest GP's count)
 
     # -- engine ------------------------------------------------------------------------
     @property
@@ -224,57 +294,72 @@ class GpStateTransitionModel(AbstractStateTransitionModel):
     @staticmethod
     def train(queue, saved_state, lr_train, num_iter_train, clip_grad_value, print_train=False, step_print_train=25,
               device="auto", loss_evaluator=None):
-        """Exact-MLL hyper-parameter search (reference :193-306), one GP at a time: random restart inside
-        the constraint box, LBFGS(strong_wolfe), keep the best, never return something worse than the
-        incoming parameters.  Runs in the spawned training process, fp64.  The loss and its gradient come from
-        gpmpc_mll (K build + Cholesky + inverse + gradient contraction on the GPU) through an engine of this
-        process's own; there is no CPU expression of the loss in this package.  `loss_evaluator(X, y, ls, os, nz)`
-        replaces it in tests (the oracle's torch expression, as the checker of the driver logic).
+        """Exact-MLL hyper-parameter search (reference :193-306): per GP a random restart inside the constraint box
+        (drawn in the reference's order: outputscale, lengthscale, noise; GP after GP), LBFGS(strong_wolfe), keep the
+        best, never return something worse than the incoming parameters.  Runs in the spawned training process, fp64.
+        The loss and its gradient come from gpmpc_mll (K build + Cholesky + inverse + gradient contraction on the GPU)
+        through an engine of this process's own; there is no CPU expression of the loss in this package.
 
-        Whatever happens in here, exactly ONE list of parameter dicts is put on the queue -- the incoming
-        parameters when the engine cannot be created or nothing better was found -- so the controller's
-        check_and_close_processes never waits on a dead child."""
+        The D optimisations are independent, so they run as D threads advanced in LOCKSTEP: whenever every unfinished
+        GP waits for a loss, ONE gpmpc_mll call evaluates all of them (the kernels batch over GPs; the reference runs
+        them one after the other, :233-290).  Each GP sees the values its own sequential run would see.
+        `loss_evaluator(X, y, ls, os, nz)` replaces the device loss in tests (the oracle's torch expression, as the
+        checker of the driver logic); it is called per GP.
+
+        Whatever happens in here, exactly ONE answer is put on the queue: the list of parameter dicts, or a
+        `TrainingFailed` (a list holding the INCOMING parameters, with the reason attached) when the engine cannot be
+        created, the device is not one this package computes on, or the search raised -- so the controller's
+        check_and_close_processes never waits on a dead child and can tell a failed training from a finished one."""
+        import threading
         t0 = time.time()
-        incoming = [{k: np.asarray(v).copy() for k, v in p.items()} for p in saved_state.parameters]
-        out, engine = None, None
+        incoming, out, engine, reason = None, None, None, "interrupted"
         try:
+            incoming = [{k: np.asarray(v).copy() for k, v in p.items()} for p in saved_state.parameters]
             saved_state.to_tensors()
             X, Y = saved_state.inputs, saved_state.states_change
             cons = saved_state.constraints_hyperparams
             N, E = X.shape
+            n_gp = len(saved_state.parameters)
+            shared = None
             if loss_evaluator is None:
                 if device not in ("auto", "hip"):
                     raise ValueError(f"training device {device!r}: the loss runs on the GPU only ('auto' or 'hip')")
                 from ...engine import HipEngine       # raises without a GPU / without the HIP library
                 engine = HipEngine(0)
-                X_dev = torch.as_tensor(X, dtype=F64).to(engine.device).contiguous()
-            out = []
-            for a, p in enumerate(saved_state.parameters):
-                lo = {"ls": _t(cons["min_lengthscale"])[a], "os": _t(cons["min_outputscale"])[a],
-                      "nz": _t(cons["min_std_noise"])[a] ** 2}
-                hi = {"ls": _t(cons["max_lengthscale"])[a], "os": _t(cons["max_outputscale"])[a],
-                      "nz": _t(cons["max_std_noise"])[a] ** 2}
+                shared = _LockstepMll(engine, torch.as_tensor(X, dtype=F64).to(engine.device).contiguous(),
+                                      torch.as_tensor(Y, dtype=F64).to(engine.device).contiguous(), n_gp)
+            K0, K1, K2 = GpHyperParameters.KEYS
+            lo = [{"ls": _t(cons["min_lengthscale"])[a], "os": _t(cons["min_outputscale"])[a],
+                   "nz": _t(cons["min_std_noise"])[a] ** 2} for a in range(n_gp)]
+            hi = [{"ls": _t(cons["max_lengthscale"])[a], "os": _t(cons["max_outputscale"])[a],
+                   "nz": _t(cons["max_std_noise"])[a] ** 2} for a in range(n_gp)]
+            start = [{"ls": p[K0].reshape(-1), "os": p[K1].reshape(()), "nz": p[K2].reshape(())}
+                     for p in saved_state.parameters]
+            # the restarts, drawn up front in the order the reference's sequential loop consumes the generator (:236-252)
+            raws = []
+            for a in range(n_gp):
+                raws.append({k: torch.logit(torch.rand(start[a][k].shape, dtype=F64).clamp(1e-6, 1 - 1e-6)).requires_grad_(True)
+                             for k in ("os", "ls", "nz")})
+            results = [None] * n_gp
+
+            def search(a):
                 y = Y[:, a]
-                if engine is not None:
-                    y_dev = torch.as_tensor(y, dtype=F64).reshape(N, 1).to(engine.device).contiguous()
 
                 def neg_mll(ls, osc, nz):
-                    if engine is not None:
-                        return _DeviceNegMll.apply(ls, osc, nz, engine, X_dev, y_dev)
+                    if shared is not None:
+                        return _DeviceNegMll.apply(ls, osc, nz, shared, a)
                     return loss_evaluator(X, y, ls, osc, nz)
 
-                best = {"ls": p[GpHyperParameters.KEYS[0]].reshape(-1), "os": p[GpHyperParameters.KEYS[1]].reshape(()),
-                        "nz": p[GpHyperParameters.KEYS[2]].reshape(())}
+                best = dict(start[a])
                 try:
                     best_loss = float(neg_mll(best["ls"], best["os"], best["nz"]))
                 except Exception:
                     best_loss = float("inf")
-                raw = {k: torch.logit(torch.rand(best[k].shape, dtype=F64).clamp(1e-6, 1 - 1e-6)).requires_grad_(True)
-                       for k in ("ls", "os", "nz")}
+                raw = raws[a]
 
                 def val(k):
-                    return lo[k] + (hi[k] - lo[k]) * torch.sigmoid(raw[k])
-                opt = torch.optim.LBFGS(list(raw.values()), lr=lr_train, line_search_fn="strong_wolfe")
+                    return lo[a][k] + (hi[a][k] - lo[a][k]) * torch.sigmoid(raw[k])
+                opt = torch.optim.LBFGS([raw["ls"], raw["os"], raw["nz"]], lr=lr_train, line_search_fn="strong_wolfe")
                 try:
                     for i in range(num_iter_train):
                         def closure():
@@ -290,15 +375,44 @@ class GpStateTransitionModel(AbstractStateTransitionModel):
                             best = {k: val(k).detach().clone() for k in raw}
                 except Exception as e:         # keep the best found so far, like the reference (:289-290)
                     print(e)
-                out.append({GpHyperParameters.KEYS[0]: best["ls"].reshape(1, E).numpy(),
-                            GpHyperParameters.KEYS[1]: best["os"].reshape(()).numpy(),
-                            GpHyperParameters.KEYS[2]: best["nz"].reshape(1).numpy()})
+                return {K0: best["ls"].reshape(1, E).numpy(), K1: best["os"].reshape(()).numpy(),
+                        K2: best["nz"].reshape(1).numpy()}
+
+            def worker(a):
+                try:
+                    results[a] = search(a)
+                except BaseException as e:
+                    results[a] = e
+                finally:
+                    if shared is not None:
+                        shared.finished(a)
+
+            if shared is not None and n_gp > 1:
+                threads = [threading.Thread(target=worker, args=(a,), daemon=True) for a in range(n_gp)]
+                for th in threads:
+                    th.start()
+                for th in threads:
+                    th.join()
+            else:
+                for a in range(n_gp):
+                    worker(a)
+            for r in results:
+                if isinstance(r, BaseException):
+                    raise r
+            out = results
+            if shared is not None:
+                GpStateTransitionModel.last_training_launches = shared.launches
             if print_train:
                 print(f"training process: {time.time() - t0:.2f} s")
-        except BaseException as e:
-            print(f"training process failed ({e!r}): keeping the incoming hyper-parameters")
+        except Exception as e:
+            reason = repr(e)
+            print(f"training process failed ({reason}): keeping the incoming hyper-parameters")
             out = None
         finally:
             if engine is not None:
                 engine.close()
-            queue.put(out if out is not None and len(out) == len(incoming) else incoming)
+            if out is not None and incoming is not None and len(out) == len(incoming):
+                queue.put(out)
+            else:
+                keep = incoming if incoming is not None else [dict(p) for p in getattr(saved_state, "parameters", [])]
+                queue.put(TrainingFailed(keep, reason))

@@ -53,7 +53,7 @@ static void free_buf(Buf& b) {
 
 extern "C" {
 
-int gpmpc_abi_version(void) { return 8; }
+int gpmpc_abi_version(void) { return 9; }
 
 int gpmpc_create(gpmpc_t** out, int device_id) {
     if (!out) return GPMPC_ERR_ARG;
@@ -81,7 +81,7 @@ int gpmpc_destroy(gpmpc_t* g) {
     (void)hipSetDevice(h->device);
     Buf* all[] = {&h->Xt, &h->beta, &h->iK, &h->Tm, &h->ils2, &h->var, &h->logvar, &h->gram,
                   &h->linv, &h->zvec, &h->cost, &h->best, &h->xrange, &h->mono_w, &h->traj, &h->Xc, &h->Yc,
-                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws, &h->cemws};
+                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws, &h->cemws, &h->tilews};
     for (Buf* b : all) free_buf(*b);
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);
@@ -112,6 +112,8 @@ int gpmpc_set_option(gpmpc_t* g, const char* name, long long value) {
     else if (!strcmp(name, "inner_left")) h->opt_inner_left = (int)value;
     else if (!strcmp(name, "outer2")) h->opt_outer2 = (int)value;
     else if (!strcmp(name, "refresh_every")) h->opt_refresh_every = (int)value;
+    else if (!strcmp(name, "pair_tiles")) h->opt_pair_tiles = (int)value;
+    else if (!strcmp(name, "tile_chunk")) h->opt_tile_chunk = (int)value;
     else return bad(g, "unknown option");
     return GPMPC_OK;
 }
@@ -171,6 +173,13 @@ int gpmpc_mll(gpmpc_t* g, const double* X, const double* Y, const double* ls, co
 }
 
 int gpmpc_last_prepare_mode(gpmpc_t* g) { return g ? g->h.last_prepare_mode : GPMPC_ERR_ARG; }
+
+int gpmpc_last_rollout_path(gpmpc_t* g) { return g ? g->h.last_rollout_path : GPMPC_ERR_ARG; }
+
+#ifndef GPMPC_BUILD_ID
+#define GPMPC_BUILD_ID "unknown"
+#endif
+const char* gpmpc_build_id(void) { return GPMPC_BUILD_ID; }
 
 int gpmpc_set_cost(gpmpc_t* g, const double* target, const double* W, const double* W_T, double kappa,
                    int clip, const double* smin, const double* smax, int D, int A) {

@@ -59,6 +59,12 @@ struct RolloutArgs {
     int RC;       // row chunks per column
     unsigned magic_N;        // ceil(2^32 / NC):  x / NC  == umulhi(x, magic_N), NC = N (or ceil(N / 2) with cols2)
     unsigned magic_wpp;      // ceil(2^32 / wpp): x / wpp == umulhi(x, magic_wpp)
+    // batch-major path (pair_tile_kernel.h): the per-candidate kernel runs the horizon slice [t_begin, t_end) from the
+    // state stored in mu_out / Sig_out and takes the diagonal pairs' sums from tile_part (B, D, ntiles)
+    int tiled;               // host side: 1 = launch the TILED instantiation
+    int t_begin, t_end;
+    int ntiles;
+    const double* tile_part;
     // initial state distribution
     double mu0[kMaxD];
     double S0[kMaxD * kMaxD];
@@ -94,6 +100,7 @@ struct Handle {
     Buf gradws;   // gradient workspace: pair moments | mean sums | cost variances
     Buf mllws;    // marginal-likelihood workspace: tile partial sums | results
     Buf cemws;    // cross-entropy search workspace: optimiser vectors | model actions | J | mean | std | warm start | mapper
+    Buf tilews;   // batch-major path: per-(candidate, output) step parameters | per-tile partial sums
     // incremental factorisation: what the cached factors were computed from, and border-update scratch
     Buf Xc, Yc;   // (N, E), (N, D) copies of the memory points of the last prepare
     Buf hyp;      // lengthscales (D*E) | outputscales (D) | noises (D) of the last prepare
@@ -134,6 +141,9 @@ struct Handle {
     int opt_inner_left = 1;          // large N: left-looking 32-column panels inside an outer panel; 0: right-looking (A/B)
     int opt_tile128 = 1;             // large N: 128 x 128 tiles (8 wavefronts) for the tiled products; 0: 64 x 64 (A/B)
     int opt_outer_block = 1;         // large N: outer panels of 128 columns + LDS-tiled products; 0: the 32-wide path only (A/B, tests)
+    int opt_pair_tiles = 0;          // batch-major pairwise pass of the diagonal pairs: 0 auto (by N, D, B), 1 always (D <= 4), 2 never
+    int opt_tile_chunk = 0;          // candidates per workgroup of the batch-major pass (0: chosen from the batch)
+    int last_rollout_path = 0;       // what the last rollout launch used: 0 fused-horizon kernel, 1 streaming kernel, 2 batch-major tiles
     int opt_fused_prepare = 1;       // N <= 256: the whole factorisation in one launch (prepare_small.hip); 0: panel path (A/B, tests)
     int last_prepare_mode = 0;       // 0 full, 1 border update(s), 2 unchanged (cache hit)
     int lds_limit = 160 * 1024;
@@ -162,6 +172,10 @@ inline int allow_full_lds(Handle* h, const void* kernel) {
 // rollout.hip
 int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s);
 int launch_argmin(Handle* h, const double* J, int B, long long first, hipStream_t s);
+// pair_tile.hip: the batch-major pass of horizon step t (a.mu_out / a.Sig_out hold the state), a.tile_part / a.ntiles set on return
+int tile_workspace(Handle* h, RolloutArgs& a);
+int launch_tile_state_init(Handle* h, const RolloutArgs& a, hipStream_t s);
+int launch_pair_tiles(Handle* h, const RolloutArgs& a, int t, hipStream_t s);
 // grad.hip
 int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t s);
 int launch_argmin_to(Handle* h, const double* J, int B, long long first, const double* actions, int HA, double* out_dev,

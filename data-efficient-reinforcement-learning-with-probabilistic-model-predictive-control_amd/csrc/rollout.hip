@@ -227,6 +227,14 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     size_t lds_bytes = 0;
     // two adjacent columns per lane where the one-column loop is bound by the LDS broadcast bandwidth (small D)
     const bool cols2 = !gs && (h->opt_cols_per_lane == 2 || (h->opt_cols_per_lane == 0 && DP <= 4));
+    // Batch-major pass for the diagonal pairs (pair_tile_kernel.h) when the D tables T_a no longer stay in an XCD's 4 MiB L2
+    // and the batch is large enough to amortise a tile over many candidates; the fused-horizon kernel otherwise.
+    bool tiled = false;
+    if (!gs && cols2 && DP <= 4 && nt == 1024 && h->opt_pair_tiles != 2) {
+        const double tri_bytes = 4.0 * D * (double)N * N;          // upper triangles of the D tables
+        tiled = h->opt_pair_tiles == 1 || (tri_bytes >= 6.0e6 && a.B >= 2 * h->num_cu);
+    }
+    const int Pg = tiled ? (P - D > 0 ? P - D : 1) : P;           // pairs the per-candidate kernel keeps row records for
     const int NCu = cols2 ? (N + 1) / 2 : N;     // column units per row chunk
     auto chunking = [&](int g) {
         // row chunks of up to 64 rows (fewer, longer items amortise the per-item prologue: 0.76 vs 0.80 ms at
@@ -247,7 +255,7 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     if (!gs) {
         // X^T in LDS when it is small next to the budget (<= 32 KiB) and the layout still fits
         for (int xl = ((size_t)E * N * 8 <= 32 * 1024) ? 1 : 0; xl >= 0 && G == 0; --xl) {
-            for (int g = P; g >= 1; --g) {
+            for (int g = Pg; g >= 1; --g) {
                 chunking(g);
                 const int wpp = (RC * NCu + 63) / 64;
                 Layout L = make_layout(N, D, A, E, g, DP, wpp, CM, CH, a.H * A, xl != 0);
@@ -257,9 +265,9 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
                 }
             }
             // prefer all pairs in one group over the X^T copy
-            if (G != 0 && G < P && xl == 1) { G = 0; }
+            if (G != 0 && G < Pg && xl == 1) { G = 0; }
         }
-        if (G == 0) gs = true;
+        if (G == 0) { gs = true; tiled = false; }
     }
     if (gs) {
         // large-N variant (rollout_stream_kernel.h): column factors + a double-buffered 64-row stage in LDS
@@ -308,14 +316,30 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
             if (!a.Sig_out) a.Sig_out = h->traj.p + nmu;
         }
     }
-    int rc;
-    switch (DP) {
-        case 2:  rc = launch_rollout_dp2(h, a, nt, gs, lds_bytes, s); break;
-        case 3:  rc = launch_rollout_dp3(h, a, nt, gs, lds_bytes, s); break;
-        case 4:  rc = launch_rollout_dp4(h, a, nt, gs, lds_bytes, s); break;
-        case 6:  rc = launch_rollout_dp6(h, a, nt, gs, lds_bytes, s); break;
-        case 8:  rc = launch_rollout_dp8(h, a, nt, gs, lds_bytes, s); break;
-        default: rc = launch_rollout_dp16(h, a, nt, gs, lds_bytes, s); break;
+    int rc = GPMPC_OK;
+    auto launch_kernel = [&]() {
+        switch (DP) {
+            case 2:  return launch_rollout_dp2(h, a, nt, gs, lds_bytes, s);
+            case 3:  return launch_rollout_dp3(h, a, nt, gs, lds_bytes, s);
+            case 4:  return launch_rollout_dp4(h, a, nt, gs, lds_bytes, s);
+            case 6:  return launch_rollout_dp6(h, a, nt, gs, lds_bytes, s);
+            case 8:  return launch_rollout_dp8(h, a, nt, gs, lds_bytes, s);
+            default: return launch_rollout_dp16(h, a, nt, gs, lds_bytes, s);
+        }
+    };
+    h->last_rollout_path = gs ? 1 : (tiled ? 2 : 0);
+    if (tiled) {
+        // per horizon step: parameters + batch-major tiles of the diagonal pairs, then the per-candidate rest of the step
+        a.tiled = 1;
+        rc = tile_workspace(h, a);
+        if (!rc) rc = launch_tile_state_init(h, a, s);
+        for (int t = 0; t < a.H && !rc; ++t) {
+            rc = launch_pair_tiles(h, a, t, s);
+            a.t_begin = t; a.t_end = t + 1;
+            if (!rc) rc = launch_kernel();
+        }
+    } else {
+        rc = launch_kernel();
     }
     if (rc) return rc;
     if (user_cm || user_cv || user_J) {

@@ -25,6 +25,18 @@ static int launch_variant(Handle* h, RolloutArgs& a, bool global_scratch, size_t
     // still measured faster or equal at every D (tools/gpu_exact_ab.py: 19.1 vs 19.8 ms at config 4, 5.1 vs 6.0 ms at
     // D = 6, 14.2 vs 15.6 ms at D = 8, equal at D = 16), so it is used whenever D == DP; option "exact_dim" = 2 forbids it.
     const bool exact = (a.D == DP) && a.exact_dim != 2;
+    if constexpr (DP <= 4 && NT == 1024) {
+        if (a.tiled) {
+            // one horizon step of the per-candidate part of the batch-major path (diagonal pairs: pair_tile_kernel.h)
+            auto tk = exact ? rollout_kernel<DP, NT, DP, true, true> : rollout_kernel<DP, NT, 0, true, true>;
+            int rc = allow_full_lds(h, reinterpret_cast<const void*>(tk));
+            if (rc) return rc;
+            hipLaunchKernelGGL(tk, dim3(a.B), dim3(NT), lds_bytes, s, a);
+            GPMPC_HIP_CHECK(h, hipGetLastError());
+            return GPMPC_OK;
+        }
+    }
+    if (a.tiled) { h->err = "rollout: batch-major path asked for an unsupported kernel variant"; return GPMPC_ERR_ARG; }
     auto kern = a.cols2 ? (exact ? rollout_kernel<DP, NT, DP, true> : rollout_kernel<DP, NT, 0, true>)
                         : (exact ? rollout_kernel<DP, NT, DP, false> : rollout_kernel<DP, NT, 0, false>);
     {

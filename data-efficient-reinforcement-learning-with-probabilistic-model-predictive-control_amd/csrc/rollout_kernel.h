@@ -688,8 +688,12 @@ __device__ inline int wave_max_i32(int v) {
 // ------------------------------------------------------------------------------------------
 // DX = exact state dimension known at compile time (0: runtime p.D <= DP): folds every D-dependent
 // offset and small loop, which is what keeps the 128-VGPR budget of a 1024-thread workgroup.
-template <int DP, int NT, int DX, bool C2>
+// TILED = one step of the per-candidate part of the batch-major path (pair_tile_kernel.h): the horizon slice
+// [p.t_begin, p.t_end) starts from the state stored in the trajectory arrays, the diagonal output pairs are not
+// processed here -- their N x N sums arrive as per-tile partial sums in p.tile_part and are added in a fixed order.
+template <int DP, int NT, int DX, bool C2, bool TILED = false>
 __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
+    static_assert(!TILED || (DP <= 4 && NT >= 256), "the batch-major path is built for D <= 4");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NT / kWave;
     constexpr int RS = DP + 2;              // row record: [0] ea_i | ka'_i, [1] ra_i | beta_ai, [2..] g_i
@@ -697,7 +701,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     const int c = blockIdx.x;
     const int D = (DX > 0) ? DX : p.D;
     const int N = p.N, A = p.A, E = p.E, H = p.H, G = p.G, CM = p.CM;
-    const int P = D * (D + 1) / 2;
+    const int P = TILED ? D * (D - 1) / 2 : D * (D + 1) / 2;      // output pairs whose N x N work is done here
     const int DA = D + A;
     const int LD = 2 * D;                   // row stride of an augmented block
     const int NC = C2 ? (N + 1) / 2 : N;    // column units per row chunk: columns, or pairs of adjacent columns
@@ -715,6 +719,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     double* s_Vs = smem + L.Vs;             // [k][a]
     double* s_Sp = smem + L.Sp;
     double* s_rdet = smem + L.rdet;
+    [[maybe_unused]] double* s_rdiag = smem + L.misc;      // TILED: 1 / sqrt(det R_aa) [0, D) and the tile sums [4, 4 + D)
     double* s_aug = smem + L.aug;           // problems [0, D): mean part, [D, D+G): pairs of the group
     double* s_part = smem + L.part;
     double* s_mom = smem + L.mom;           // [gq][side][CM]
@@ -750,8 +755,13 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     long long prof_last = __builtin_readcyclecounter();
 #endif
     // ---- init -----------------------------------------------------------------------
-    for (int i = tid; i < D; i += NT) { s_mu[i] = p.mu0[i]; c_logvar[i] = p.logvar[i]; c_var[i] = p.var[i]; }
-    for (int i = tid; i < D * D; i += NT) s_Sig2[i] = p.S0[i];
+    if constexpr (TILED) {
+        for (int i = tid; i < D; i += NT) { s_mu[i] = p.mu_out[((size_t)c * (H + 1) + p.t_begin) * D + i]; c_logvar[i] = p.logvar[i]; c_var[i] = p.var[i]; }
+        for (int i = tid; i < D * D; i += NT) s_Sig2[i] = p.Sig_out[((size_t)c * (H + 1) + p.t_begin) * D * D + i];
+    } else {
+        for (int i = tid; i < D; i += NT) { s_mu[i] = p.mu0[i]; c_logvar[i] = p.logvar[i]; c_var[i] = p.var[i]; }
+        for (int i = tid; i < D * D; i += NT) s_Sig2[i] = p.S0[i];
+    }
     for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
     for (int i = tid; i < 2 * E; i += NT) c_xr[i] = p.xrange[i];
     for (int i = tid; i < H * A; i += NT) c_act[i] = act[i];
@@ -770,7 +780,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     if (tid == 0) {
         int q = 0;
         for (int a = 0; a < D; ++a)
-            for (int b = a; b < D; ++b) { s_pa[q] = a; s_pb[q] = b; ++q; }
+            for (int b = TILED ? a + 1 : a; b < D; ++b) { s_pa[q] = a; s_pb[q] = b; ++q; }
         // a column unit (one column, or the pair (2 jc, 2 jc + 1)) is useful for row chunk r if its last column >= r CH
         int run = 0;
         for (int r = 0; r <= p.RC; ++r) {
@@ -781,12 +791,14 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     }
     __syncthreads();
     GPMPC_TRACE(1);
-    for (int i = tid; i < D; i += NT) p.mu_out[((size_t)c * (H + 1)) * D + i] = s_mu[i];
-    for (int i = tid; i < D * D; i += NT) p.Sig_out[((size_t)c * (H + 1)) * D * D + i] = s_Sig2[i];
+    if constexpr (!TILED) {
+        for (int i = tid; i < D; i += NT) p.mu_out[((size_t)c * (H + 1)) * D + i] = s_mu[i];
+        for (int i = tid; i < D * D; i += NT) p.Sig_out[((size_t)c * (H + 1)) * D * D + i] = s_Sig2[i];
+    }
 
     int cur = 0;
     const int tid_outer = tid;
-    for (int t = 0; t < H; ++t) {
+    for (int t = TILED ? p.t_begin : 0; t < (TILED ? p.t_end : H); ++t) {
         t_dbg = t;
         // Re-derive the thread coordinates inside every step from an opaque copy: otherwise the compiler
         // hoists dozens of per-thread address computations out of the horizon loop and keeps them live
@@ -799,7 +811,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
         const double* s_Sig = s_Sig2 + cur * SD2;
         double* s_SigNext = s_Sig2 + (cur ^ 1) * SD2;
 
-        for (int q0 = 0; q0 < P; q0 += G) {
+        for (int q0 = 0; q0 < P || (TILED && q0 == 0); q0 += G) {       // TILED, D = 1: no pair, the mean part still runs
             const int Gc = (P - q0 < G) ? (P - q0) : G;
             const bool first = (q0 == 0);
             const int nmean = first ? D : 0;
@@ -938,6 +950,33 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     if (p.force_sep || cost_sep < cost_el) K |= 64;
                 }
                 s_K[gq] = K;
+            }
+            if constexpr (TILED) {
+                if (first && tid >= 128 && tid < 128 + D) {
+                    // diagonal pair (a, a): only det R is needed here (Z and the degree: tile_params_kernel)
+                    const int a = tid - 128;
+                    double m[DP][2 * DP];
+#pragma unroll
+                    for (int i = 0; i < DP; ++i)
+#pragma unroll
+                        for (int j = 0; j < DP; ++j) {
+                            const bool in = (i < D && j < D);
+                            const double sg = in ? s_Sig[i * D + j] : 0.0;
+                            const double dab = in ? c_ils2[a * E + j] + c_ils2[a * E + j] : 0.0;
+                            m[i][j] = sg * dab + (i == j ? 1.0 : 0.0);
+                            m[i][DP + j] = sg;
+                        }
+                    s_rdiag[a] = 1.0 / sqrt(small_solve<DP>(m));
+                } else if (first && wave == 3) {
+                    // sums of the per-tile partial sums of pair_tile_kernel, fixed order
+                    for (int a = 0; a < D; ++a) {
+                        const double* tp = p.tile_part + ((size_t)c * D + a) * p.ntiles;
+                        double v = 0.0;
+                        for (int k = lane; k < p.ntiles; k += 64) v += tp[k];
+                        v = wave_sum(v);
+                        if (lane == 0) s_rdiag[4 + a] = v;
+                    }
+                }
             }
 #if defined(GPMPC_PROF_ON)
             if (threadIdx.x == 0 && blockIdx.x == 0) { long long now_ = __builtin_readcyclecounter(); prof_acc[7] += now_ - prof_last; }
@@ -1235,7 +1274,16 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     for (int k = lane; k < wpp; k += 64) v += s_part[gq * wpp + k];
                 }
                 v = wave_sum(v);
-                if (lane == 0) s_Sp[q0 + gq] = v * s_rdet[gq];
+                if constexpr (TILED) {
+                    const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
+                    if (lane == 0) s_Sp[a * D - (a * (a - 1)) / 2 + (b - a)] = v * s_rdet[gq];
+                } else {
+                    if (lane == 0) s_Sp[q0 + gq] = v * s_rdet[gq];
+                }
+            }
+            if constexpr (TILED) {
+                // i <= j only: factor 2
+                if (first && tid < D) s_Sp[tid * D - (tid * (tid - 1)) / 2] = 2.0 * s_rdiag[4 + tid] * s_rdiag[tid];
             }
             if (first) {
                 if (tid < D) s_M[tid] = s_cc[tid] * s_s1[tid * (D + 1)];                 // M_a (:152)

@@ -103,6 +103,16 @@ class HipEngine:
         """0 = full factorisation, 1 = border update of the cached factors, 2 = cache hit."""
         return int(self.lib.gpmpc_last_prepare_mode(self._h))
 
+    @property
+    def last_rollout_path(self):
+        """Kernels of the last forward pass: 0 = fused-horizon kernel, 1 = streaming kernel, 2 = batch-major tiles."""
+        return int(self.lib.gpmpc_last_rollout_path(self._h))
+
+    @property
+    def build_id(self):
+        """Hash over the sources the loaded library was built from (gpmpc_build_id)."""
+        return self.lib.gpmpc_build_id().decode()
+
     def set_factors(self, X, iK, beta, lengthscales, outputscales):
         X = self._dev(X)
         N, E = X.shape
@@ -148,7 +158,8 @@ class HipEngine:
         S0 = _host(S0, (D, D))
         if out is None:
             out = {}
-            if stage_costs or self._cost is not None:          # the objective needs gpmpc_set_cost; the trajectory does not
+            # the objective needs gpmpc_set_cost FOR THIS (D, A); a trajectory-only call passes no cost pointer at all
+            if stage_costs or self._cost == (D, A):
                 out["J"] = torch.empty(B, dtype=torch.float64, device=self.device)
             if trajectories:
                 out["mu"] = torch.empty((B, H + 1, D), dtype=torch.float64, device=self.device)

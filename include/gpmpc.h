@@ -44,6 +44,10 @@ enum {
 /* Library ABI version (bumped on any signature change). */
 int gpmpc_abi_version(void);
 
+/* Identifier of the build: a hash over the library's sources (csrc/Makefile), so that counter files kept under
+ * profiles/ can name the build they were collected on (bench.py nulls counter-derived figures of another build). */
+const char* gpmpc_build_id(void);
+
 /* Create / destroy a handle bound to HIP device `device_id`. */
 int gpmpc_create(gpmpc_t** out, int device_id);
 int gpmpc_destroy(gpmpc_t* h);
@@ -82,6 +86,14 @@ int gpmpc_mll(gpmpc_t* h, const double* X_dev, const double* Y_dev, const double
  * (gp_mpc_controller.py:117).  Option "incremental" (default 1) switches the reuse off, "refresh_every"
  * (default 32) bounds the number of border updates between full factorisations. */
 int gpmpc_last_prepare_mode(gpmpc_t* h);
+
+/* Which kernels the last gpmpc_rollout / _grad / _cem_search launch used for the forward pass: 0 = the fused-horizon
+ * kernel (one workgroup per candidate, all H steps in one launch), 1 = the streaming kernel (per-point arrays beyond
+ * the LDS), 2 = the batch-major path (per horizon step: the N x N work of the diagonal output pairs, gp_model.py:161-175,
+ * by workgroups that own a 128 x 128 tile of beta beta^T - iK and loop over the candidates, + a per-candidate step
+ * kernel) -- chosen when D <= 4, the D tables exceed an XCD's L2 and B >= 512; option "pair_tiles" 1 forces, 2 forbids it,
+ * "tile_chunk" sets the candidates per tile workgroup. */
+int gpmpc_last_rollout_path(gpmpc_t* h);
 
 /*
  * Same cached state as gpmpc_prepare but with iK (D,N,N) and beta (D,N) supplied by the
