@@ -81,10 +81,11 @@ int gpmpc_destroy(gpmpc_t* g) {
     (void)hipSetDevice(h->device);
     Buf* all[] = {&h->Xt, &h->beta, &h->iK, &h->Tm, &h->ils2, &h->var, &h->logvar, &h->gram,
                   &h->linv, &h->zvec, &h->cost, &h->best, &h->xrange, &h->mono_w, &h->traj, &h->Xc, &h->Yc,
-                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws, &h->cemws, &h->tilews};
+                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws, &h->cemws, &h->tilews, &h->sepw};
     for (Buf* b : all) free_buf(*b);
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);
+    if (h->septab) (void)hipFree(h->septab);
     delete g;
     return GPMPC_OK;
 }

@@ -65,6 +65,7 @@ struct RolloutArgs {
     int t_begin, t_end;
     int ntiles;
     const double* tile_part;
+    const int* slow;         // (B) t + 1: the candidate's step t is this kernel's (off-diagonal pair outside the separable range)
     // initial state distribution
     double mu0[kMaxD];
     double S0[kMaxD * kMaxD];
@@ -100,7 +101,10 @@ struct Handle {
     Buf gradws;   // gradient workspace: pair moments | mean sums | cost variances
     Buf mllws;    // marginal-likelihood workspace: tile partial sums | results
     Buf cemws;    // cross-entropy search workspace: optimiser vectors | model actions | J | mean | std | warm start | mapper
-    Buf tilews;   // batch-major path: per-(candidate, output) step parameters | per-tile partial sums
+    Buf tilews;   // batch-major path: step records of the candidates | per-tile partial sums | hand-over flags
+    struct SepTable* septab = nullptr;   // monomial bands of the separable evaluation (point_pass_kernel.h), device copy
+    Buf sepw;                            // their weights 1 / alpha!
+    int septab_D = -1, sep_ks = 0, sep_cmax = 0;
     // incremental factorisation: what the cached factors were computed from, and border-update scratch
     Buf Xc, Yc;   // (N, E), (N, D) copies of the memory points of the last prepare
     Buf hyp;      // lengthscales (D*E) | outputscales (D) | noises (D) of the last prepare

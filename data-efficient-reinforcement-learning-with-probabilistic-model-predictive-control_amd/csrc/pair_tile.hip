@@ -1,16 +1,108 @@
-// pair_tile.hip -- host side of the batch-major pairwise pass (pair_tile_kernel.h): workspace, tiling, launches.
+// pair_tile.hip -- host side of the batch-major path: per horizon step  step_params_kernel (all D x D algebra) ->
+// pair_tile_kernel (N x N work of the diagonal pairs, tiles x candidates) -> point_pass_kernel (O(N) work per candidate:
+// mean part, separable off-diagonal pairs, state update); candidates outside the separable range go to the element-wise
+// kernel launched after these by launch_rollout.  Workspace, tiling, the table of monomial bands, launches.
+#include <vector>
+
 #include "pair_tile_kernel.h"
 
 namespace gpmpc_hip {
 
 static int tile_dp(int D) { return D <= 2 ? 2 : (D == 3 ? 3 : 4); }
 
-static void tile_geometry(const Handle* h, const RolloutArgs& a, TileArgs& t) {
+// ------------------------------------------------------------------------------------------
+// Bands of the separable evaluation (point_pass_kernel.h): the monomials of degree <= m in the variables s .. D-1, times the
+// prefix x^e, are one band when there are at most kSepCap of them; otherwise split by the exponent of x_s (0 | >= 1).
+static void decompose(int D, int s, int m, int (&e)[4], std::vector<SepBand>& out) {
+    const int nv = D - s;
+    const long long cnt = sep_binom(nv + m, nv);
+    if (cnt <= kSepCap || nv == 1) {
+        SepBand b{};
+        b.nv = nv; b.m = m; b.s = s; b.cnt = (int)cnt; b.off = 0;
+        for (int d = 0; d < 4; ++d) b.e[d] = e[d];
+        out.push_back(b);
+        return;
+    }
+    decompose(D, s + 1, m, e, out);
+    e[s] += 1;
+    decompose(D, s, m - 1, e, out);
+    e[s] -= 1;
+}
+
+// weights 1 / alpha! of a band's monomials in the device's enumeration order (tail2 / tail3 / tail4: first tail variable outermost)
+static void band_weights(const SepBand& b, std::vector<double>& w) {
+    auto fact = [](int n) { double f = 1.0; for (int i = 2; i <= n; ++i) f *= i; return f; };
+    int ex[4];
+    std::vector<int> t(b.nv, 0);
+    // nested loops over the tail exponents with total degree <= m, lexicographic with the first variable outermost
+    std::vector<int> cur(b.nv, 0);
+    for (;;) {
+        for (int d = 0; d < 4; ++d) ex[d] = b.e[d];
+        for (int k = 0; k < b.nv; ++k) ex[b.s + k] += cur[k];
+        double v = 1.0;
+        for (int d = 0; d < 4; ++d) v /= fact(ex[d]);
+        w.push_back(v);
+        // increment: innermost (last) variable first, bounded by the remaining degree
+        int k = b.nv - 1;
+        for (;;) {
+            int used = 0;
+            for (int i = 0; i < k; ++i) used += cur[i];
+            if (cur[k] < b.m - used) { ++cur[k]; break; }
+            cur[k] = 0;
+            if (--k < 0) return;
+        }
+    }
+}
+
+static int ensure_sep_table(Handle* h, int D) {
+    if (h->septab_D == D && h->septab) return GPMPC_OK;
+    SepTable T{};
+    std::vector<double> w;
+    // highest degree whose monomial count stays within the LDS moment arrays (as the fused-horizon kernel: <= kMaxMono)
+    int ks = 0, nb_total = 0;
+    for (int K = 1; K <= kMaxTaylor && D >= 2; ++K) {
+        if (sep_binom(D + K, D) > kMaxMono) break;
+        std::vector<SepBand> bands;
+        int e[4] = {0, 0, 0, 0};
+        decompose(D, 0, K, e, bands);
+        bool ok = nb_total + (int)bands.size() <= kSepMaxBands;
+        for (const SepBand& b : bands) ok = ok && sep_band_supported(b.nv, b.m);
+        if (!ok) break;
+        T.first[K] = nb_total; T.nb[K] = (int)bands.size(); T.woff[K] = (int)w.size();
+        int off = 0;
+        for (SepBand& b : bands) {
+            b.off = off;
+            off += b.cnt;
+            band_weights(b, w);
+            T.band[nb_total++] = b;
+        }
+        T.total[K] = off;
+        ks = K;
+    }
+    T.ks = ks;
+    if (!h->septab) GPMPC_HIP_CHECK(h, hipMalloc(&h->septab, sizeof(SepTable)));
+    GPMPC_HIP_CHECK(h, hipMemcpy(h->septab, &T, sizeof(SepTable), hipMemcpyHostToDevice));
+    int rc = grow(h, h->sepw, w.size() + 1);
+    if (rc) return rc;
+    if (!w.empty()) GPMPC_HIP_CHECK(h, hipMemcpy(h->sepw.p, w.data(), w.size() * sizeof(double), hipMemcpyHostToDevice));
+    h->septab_D = D;
+    h->sep_ks = ks;
+    h->sep_cmax = ks ? T.total[ks] : 0;
+    return GPMPC_OK;
+}
+
+static void step_geometry(const Handle* h, const RolloutArgs& a, StepArgs& t) {
     const int DP = tile_dp(a.D);
+    const int P = a.D * (a.D + 1) / 2;
     t.nb = (a.N + kTileW - 1) / kTileW;
     t.ntiles = t.nb * (t.nb + 1) / 2;
-    t.PS = tile_par_stride(DP, a.E);
-    // candidates per workgroup: enough workgroups for ~8 rounds over the 2 x 256 resident ones (tail), few enough that the
+    t.PR = DP * DP + 2;
+    t.off_mean = (a.E + 1) & ~1;
+    t.off_pair = t.off_mean + a.D * t.PR;
+    t.CS = t.off_pair + P * t.PR;
+    t.ksep = h->sep_ks;
+    t.mom_stride = (h->sep_cmax + 1) & ~1;
+    // candidates per tile workgroup: enough workgroups for ~8 rounds over the 2 x 256 resident ones (tail), few enough that the
     // tile's 128 KiB and the prologue are amortised over >= 16 candidates; even (records are made two candidates at a time)
     int cch = h->opt_tile_chunk;
     if (cch <= 0) {
@@ -25,56 +117,76 @@ static void tile_geometry(const Handle* h, const RolloutArgs& a, TileArgs& t) {
     t.nchunk = (a.B + cch - 1) / cch;
 }
 
-// Workspace of the batch-major path: per-(candidate, output) parameters | per-tile partial sums.
+// Workspace of the batch-major path: step records | per-tile partial sums | hand-over flags.
 int tile_workspace(Handle* h, RolloutArgs& a) {
-    TileArgs t{};
-    tile_geometry(h, a, t);
-    const size_t npar = (size_t)a.B * a.D * t.PS, npart = (size_t)a.B * a.D * t.ntiles;
-    int rc = grow(h, h->tilews, npar + npart);
+    int rc = ensure_sep_table(h, a.D);
     if (rc) return rc;
-    a.tile_part = h->tilews.p + npar;
+    StepArgs t{};
+    step_geometry(h, a, t);
+    const size_t nrec = (size_t)a.B * t.CS, npart = (size_t)a.B * a.D * t.ntiles, nflag = ((size_t)a.B + 1) / 2;
+    rc = grow(h, h->tilews, nrec + npart + nflag);
+    if (rc) return rc;
+    a.tile_part = h->tilews.p + nrec;
     a.ntiles = t.ntiles;
+    a.slow = reinterpret_cast<const int*>(h->tilews.p + nrec + npart);
     return GPMPC_OK;
 }
 
 int launch_tile_state_init(Handle* h, const RolloutArgs& a, hipStream_t s) {
     const size_t n = (size_t)a.B * ((size_t)a.D + (size_t)a.D * a.D);
-    hipLaunchKernelGGL(tile_state_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(step_state_init_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, const_cast<int*>(a.slow));
     GPMPC_HIP_CHECK(h, hipGetLastError());
     return GPMPC_OK;
 }
 
 template <int DP>
-static int launch_tiles_dp(Handle* h, const TileArgs& t, hipStream_t s) {
-    hipLaunchKernelGGL(tile_params_kernel<DP>, dim3((t.B * t.D + 255) / 256), dim3(256), 0, s, t);
+static int launch_step_dp(Handle* h, const StepArgs& t, hipStream_t s) {
+    const int P = t.D * (t.D + 1) / 2;
+    hipLaunchKernelGGL(step_params_kernel<DP>, dim3((t.B * (t.D + P) + 255) / 256), dim3(256), 0, s, t);
     GPMPC_HIP_CHECK(h, hipGetLastError());
-    auto kern = pair_tile_kernel<DP>;
-    int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
-    if (rc) return rc;
-    const TileLayout L = make_tile_layout(DP, t.E, t.cch);
-    const size_t lds = (size_t)L.total * sizeof(double);
-    if (lds > (size_t)h->lds_limit) { h->err = "pair tiles: input dimension too large for the LDS layout"; return GPMPC_ERR_LIMIT; }
-    const int nta = t.ntiles * t.D;
-    const int per_xcd = (nta + 7) / 8;
-    hipLaunchKernelGGL(kern, dim3(8 * per_xcd * t.nchunk), dim3(kTileWaves * 64), lds, s, t);
-    GPMPC_HIP_CHECK(h, hipGetLastError());
+    {
+        auto kern = pair_tile_kernel<DP>;
+        int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+        if (rc) return rc;
+        const TileLayout L = make_tile_layout(DP, t.E, t.cch);
+        const size_t lds = (size_t)L.total * sizeof(double);
+        if (lds > (size_t)h->lds_limit) { h->err = "pair tiles: input dimension too large for the LDS layout"; return GPMPC_ERR_LIMIT; }
+        const int nta = t.ntiles * t.D;
+        const int per_xcd = (nta + 7) / 8;
+        hipLaunchKernelGGL(kern, dim3(8 * per_xcd * t.nchunk), dim3(kTileWaves * 64), lds, s, t);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+    }
+    {
+        auto kern = point_pass_kernel<DP>;
+        int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+        if (rc) return rc;
+        const PointLayout L = make_point_layout(t.D, t.E, t.CS, t.mom_stride);
+        const size_t lds = (size_t)L.total * sizeof(double);
+        if (lds > (size_t)h->lds_limit) { h->err = "point pass: LDS layout too large"; return GPMPC_ERR_LIMIT; }
+        hipLaunchKernelGGL(kern, dim3(t.B), dim3(256), lds, s, t);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+    }
     return GPMPC_OK;
 }
 
+// Horizon step `step` of the batch-major path for every candidate the separable forms cover (a.mu_out / a.Sig_out hold the state).
 int launch_pair_tiles(Handle* h, const RolloutArgs& a, int step, hipStream_t s) {
-    TileArgs t{};
-    tile_geometry(h, a, t);
-    t.Xt = a.Xt; t.Tm = a.Tm; t.ils2 = a.ils2; t.logvar = a.logvar; t.xrange = a.xrange; t.actions = a.actions;
+    StepArgs t{};
+    step_geometry(h, a, t);
+    t.Xt = a.Xt; t.beta = a.beta; t.Tm = a.Tm; t.ils2 = a.ils2; t.var = a.var; t.logvar = a.logvar; t.xrange = a.xrange;
+    t.actions = a.actions;
     t.mu = a.mu_out; t.Sig = a.Sig_out;
-    t.tpar = h->tilews.p;
+    t.crec = h->tilews.p;
     t.part = const_cast<double*>(a.tile_part);
+    t.slow = const_cast<int*>(a.slow);
+    t.septab = h->septab; t.sepw = h->sepw.p;
     t.N = a.N; t.D = a.D; t.A = a.A; t.E = a.E; t.H = a.H; t.B = a.B; t.t = step;
     t.include_time = a.include_time; t.time0 = a.time0;
     t.force_path = a.force_path;
     switch (tile_dp(a.D)) {
-        case 2:  return launch_tiles_dp<2>(h, t, s);
-        case 3:  return launch_tiles_dp<3>(h, t, s);
-        default: return launch_tiles_dp<4>(h, t, s);
+        case 2:  return launch_step_dp<2>(h, t, s);
+        case 3:  return launch_step_dp<3>(h, t, s);
+        default: return launch_step_dp<4>(h, t, s);
     }
 }
 

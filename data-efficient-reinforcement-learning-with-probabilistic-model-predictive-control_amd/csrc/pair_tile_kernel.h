@@ -11,7 +11,7 @@
 // (8 wavefronts x 16 rows x 128 columns, lane = two adjacent columns) and loops over a chunk of candidates.  Per
 // candidate it needs only the per-point factors of the tile's 128 row and 128 column points, which it recomputes
 // from X (kept in LDS) and the candidate's D x D quantities (Z = R^-1 Sigma, the input mean, the Taylor degree:
-// tile_params_kernel) -- ~10 % more arithmetic, no table traffic: T is read once per (tile, chunk).
+// step_params_kernel) -- ~10 % more arithmetic, no table traffic: T is read once per (tile, chunk).
 // One launch per horizon step (the step's state must exist); partial sums per (candidate, a, tile) go to HBM and
 // are added in a fixed order by the per-candidate step kernel (rollout_kernel<.., TILED>), which keeps everything
 // that is O(N) per candidate: mean part, separable off-diagonal pairs, the D x D update.
@@ -20,7 +20,7 @@
 // degree the data range allows, table-based exp otherwise), fixed summation order (rows inside a wavefront's
 // accumulators, DPP wave sum, the 8 wavefronts, then the tiles) => bitwise reproducible and independent of the batch.
 #pragma once
-#include "rollout_kernel.h"
+#include "point_pass_kernel.h"
 
 namespace gpmpc_hip {
 
@@ -28,103 +28,6 @@ constexpr int kTileW = 128;        // tile edge (rows and columns of T_a per wor
 constexpr int kTileRW = 16;        // rows per wavefront
 constexpr int kTileWaves = 8;      // wavefronts per workgroup (kTileW / kTileRW)
 constexpr int kTileGC = 2;         // candidates per barrier interval (records double-buffered)
-
-struct TileArgs {
-    const double* Xt;       // (E, N)
-    const double* Tm;       // (D, N + kTPad, N)
-    const double* ils2;     // (D, E)
-    const double* logvar;   // (D)
-    const double* xrange;   // (2, E)
-    const double* actions;  // (B, H, A)
-    const double* mu;       // (B, H + 1, D)     trajectory so far: the step reads index t
-    const double* Sig;      // (B, H + 1, D, D)
-    double* tpar;           // (B, D, PS)  per (candidate, output): Z (DP x DP) | K | pad | input mean (E)
-    double* part;           // (B, D, ntiles) partial sums of the diagonal pairs
-    int N, D, A, E, H, B, t;
-    int include_time;
-    double time0;
-    int nb, ntiles;         // tile rows / columns, upper-triangle tile count nb (nb + 1) / 2
-    int cch, nchunk;        // candidates per workgroup, chunks
-    int PS;                 // doubles per tpar record
-    int force_path;         // 1: direct exp for every pair (tests)
-};
-
-__host__ __device__ inline int tile_par_stride(int DP, int E) { return DP * DP + 2 + ((E + 1) & ~1); }
-
-// ------------------------------------------------------------------------------------------
-// Per (candidate, output a): Z = R^-1 Sigma with R = Sigma diag(2 / l_a^2) + I (gp_model.py:156-163 for a == b),
-// the bound on |g_i . w_j| from the data range and the Taylor degree -- the pair branch of phase P1 of
-// rollout_kernel, for the diagonal pairs only.  One thread per problem.
-template <int DP>
-__global__ __launch_bounds__(256) void tile_params_kernel(const TileArgs p) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    const int D = p.D, E = p.E, A = p.A;
-    if (idx >= p.B * D) return;
-    const int c = idx / D, a = idx - c * D;
-    const double* mu = p.mu + ((size_t)c * (p.H + 1) + p.t) * D;
-    const double* Sg = p.Sig + ((size_t)c * (p.H + 1) + p.t) * D * D;
-    const double* il = p.ils2 + (size_t)a * E;
-    double m[DP][2 * DP];
-#pragma unroll
-    for (int i = 0; i < DP; ++i)
-#pragma unroll
-        for (int j = 0; j < DP; ++j) {
-            const bool in = (i < D && j < D);
-            const double sg = in ? Sg[i * D + j] : 0.0;
-            const double dab = in ? il[j] + il[j] : 0.0;
-            m[i][j] = sg * dab + (i == j ? 1.0 : 0.0);
-            m[i][DP + j] = sg;
-        }
-    double ur[DP];
-#pragma unroll
-    for (int i = 0; i < DP; ++i) {
-        const double mi = (i < D) ? mu[i] : 0.0;
-        const double rg = (i < D) ? fmax(fabs(p.xrange[i] - mi), fabs(p.xrange[E + i] - mi)) : 0.0;
-        ur[i] = (i < D) ? rg * il[i] : 0.0;
-    }
-    (void)small_solve<DP>(m);
-    double* out = p.tpar + (size_t)idx * p.PS;
-    double cmax = 0.0;
-#pragma unroll
-    for (int i = 0; i < DP; ++i) {
-        double r = 0.0;
-#pragma unroll
-        for (int j = 0; j < DP; ++j) {
-            const double z = (i < D && j < D) ? m[i][DP + j] : 0.0;
-            out[i * DP + j] = z;
-            r = fma(fabs(z), ur[j], r);
-        }
-        cmax += r * ur[i];
-    }
-    int K = 0;
-    if (p.force_path != 1 && cmax <= kTaylorMaxArg[kMaxTaylor]) {
-        K = 1;
-#pragma unroll
-        for (int k = 1; k < kMaxTaylor; ++k) K += (cmax > kTaylorMaxArg[k]) ? 1 : 0;
-    }
-    out[DP * DP] = (double)K;
-    out[DP * DP + 1] = 0.0;
-    double* mo = out + DP * DP + 2;
-    for (int e = 0; e < E; ++e) {
-        double v;
-        if (e < D) v = mu[e];
-        else if (e < D + A) v = p.actions[((size_t)c * p.H + p.t) * A + (e - D)];
-        else v = p.time0 + (double)p.t;
-        mo[e] = v;
-    }
-}
-
-// The trajectory's index 0 (the step kernels read their state from the trajectory arrays).
-__global__ __launch_bounds__(256) void tile_state_init_kernel(const RolloutArgs p) {
-    const int D = p.D;
-    const size_t per = (size_t)D + (size_t)D * D;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)p.B * per) return;
-    const size_t c = idx / per;
-    const int k = (int)(idx - c * per);
-    if (k < D) p.mu_out[c * (p.H + 1) * D + k] = p.mu0[k];
-    else p.Sig_out[c * (p.H + 1) * D * D + (k - D)] = p.S0[k - D];
-}
 
 // ------------------------------------------------------------------------------------------
 // 16 rows x 2 columns per lane, Taylor form.  rec: LDS row records {ea_i, g_i[DP]} (stride RSR, broadcast reads);
@@ -192,7 +95,7 @@ __host__ __device__ inline TileLayout make_tile_layout(int DP, int E, int cch) {
 
 // ------------------------------------------------------------------------------------------
 template <int DP>
-__global__ __launch_bounds__(kTileWaves * 64, 4) void pair_tile_kernel(const TileArgs p) {
+__global__ __launch_bounds__(kTileWaves * 64, 4) void pair_tile_kernel(const StepArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int RSR = (DP + 2) & ~1;
     constexpr int NTH = kTileWaves * 64;
@@ -254,13 +157,14 @@ __global__ __launch_bounds__(kTileWaves * 64, 4) void pair_tile_kernel(const Til
     const double* il = p.ils2 + (size_t)a * E;     // wave-uniform: scalar loads
     const double lv = p.logvar[a];
     const int ngroups = (ncand + kTileGC - 1) / kTileGC;
-    const double* __restrict__ tpar = p.tpar;
+    // the (a, a) problem of the candidates' step records: Z (DP x DP) | 1 / sqrt(det R) | degree
+    const double* __restrict__ tpar = p.crec + p.off_pair + pair_index(a, a, D) * p.PR;
     // Taylor degrees of the candidates of a group (0: direct exp), fetched one group ahead
     auto degrees = [&](int g, int (&K)[kTileGC]) {
 #pragma unroll
         for (int kk = 0; kk < kTileGC; ++kk) {
             const int cl = g * kTileGC + kk;
-            K[kk] = (cl < ncand) ? (int)tpar[((size_t)(c0 + cl) * D + a) * p.PS + DP * DP] : 0;
+            K[kk] = (cl < ncand) ? ((int)tpar[(size_t)(c0 + cl) * p.CS + DP * DP + 1] & 63) : 0;
         }
     };
 
@@ -270,9 +174,9 @@ __global__ __launch_bounds__(kTileWaves * 64, 4) void pair_tile_kernel(const Til
         const int kk = wave >> 2;
         const int cl = g * kTileGC + kk;
         if (cl >= ncand) return;
-        const double* par = tpar + ((size_t)(c0 + cl) * D + a) * p.PS;        // wave-uniform
+        const double* par = tpar + (size_t)(c0 + cl) * p.CS;                  // wave-uniform
         const int K = kk ? Kg[1] : Kg[0];
-        const double* mo = par + DP * DP + 2;
+        const double* mo = p.crec + (size_t)(c0 + cl) * p.CS;                  // input mean of the step
         const int side = (wave >> 1) & 1;
         const int pt = (wave & 1) * 64 + lane;
         const double* xp = s_xs + (size_t)side * E * kTileW + pt;

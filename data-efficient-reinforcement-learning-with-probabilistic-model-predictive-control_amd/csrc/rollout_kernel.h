@@ -695,6 +695,10 @@ template <int DP, int NT, int DX, bool C2, bool TILED = false>
 __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     static_assert(!TILED || (DP <= 4 && NT >= 256), "the batch-major path is built for D <= 4");
     extern __shared__ __attribute__((aligned(16))) double smem[];
+    if constexpr (TILED) {
+        // batch-major path: this kernel only takes the candidates point_pass_kernel left (element-wise off-diagonal pairs)
+        if (p.slow[blockIdx.x] != p.t_begin + 1) return;
+    }
     constexpr int NW = NT / kWave;
     constexpr int RS = DP + 2;              // row record: [0] ea_i | ka'_i, [1] ra_i | beta_ai, [2..] g_i
     const int tid = threadIdx.x;
