@@ -177,6 +177,7 @@ inline int allow_full_lds(Handle* h, const void* kernel) {
 int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s);
 int launch_argmin(Handle* h, const double* J, int B, long long first, hipStream_t s);
 // pair_tile.hip: the batch-major pass of horizon step t (a.mu_out / a.Sig_out hold the state), a.tile_part / a.ntiles set on return
+bool tile_path_supported(Handle* h, const RolloutArgs& a);
 int tile_workspace(Handle* h, RolloutArgs& a);
 int launch_tile_state_init(Handle* h, const RolloutArgs& a, hipStream_t s);
 int launch_pair_tiles(Handle* h, const RolloutArgs& a, int t, hipStream_t s);

@@ -97,24 +97,41 @@ static void step_geometry(const Handle* h, const RolloutArgs& a, StepArgs& t) {
     t.nb = (a.N + kTileW - 1) / kTileW;
     t.ntiles = t.nb * (t.nb + 1) / 2;
     t.PR = DP * DP + 2;
+    t.PRP = 4 * DP * DP + 2;
     t.off_mean = (a.E + 1) & ~1;
     t.off_pair = t.off_mean + a.D * t.PR;
-    t.CS = t.off_pair + P * t.PR;
+    t.CS = t.off_pair + P * t.PRP;
     t.ksep = h->sep_ks;
     t.mom_stride = (h->sep_cmax + 1) & ~1;
-    // candidates per tile workgroup: enough workgroups for ~8 rounds over the 2 x 256 resident ones (tail), few enough that the
-    // tile's 128 KiB and the prologue are amortised over >= 16 candidates; even (records are made two candidates at a time)
+    // Candidates per tile workgroup.  All workgroups cost the same (cch candidates + a prologue worth ~8: the tile's 128 KiB,
+    // the points' inputs), 2 are resident per CU, so the launch takes ceil(workgroups / slots) rounds: pick the chunk that
+    // minimises rounds x (cch + 8) -- a last round that is 16 % full cost config 4 3 % (tile_chunk 72 vs 64: 80.0 vs 78.0 ms).
     int cch = h->opt_tile_chunk;
     if (cch <= 0) {
-        const long long nta = (long long)t.ntiles * a.D;
-        cch = (int)(((long long)a.B * nta + 4095) / 4096);
-        if (cch < 16) cch = 16;
-        if (cch > 128) cch = 128;
+        const long long nta = (long long)t.ntiles * a.D, slots = 2LL * h->num_cu;
+        long long best = -1;
+        for (int c = 16; c <= 128; c += 2) {
+            const long long wgs = nta * ((a.B + c - 1) / c);
+            const long long cost = ((wgs + slots - 1) / slots) * (c + 8);
+            if (best < 0 || cost < best) { best = cost; cch = c; }
+        }
     }
     cch = (cch + 1) & ~1;
     if (cch > 256) cch = 256;
     t.cch = cch;
     t.nchunk = (a.B + cch - 1) / cch;
+}
+
+// Whether the LDS layouts of the step kernels fit this shape (launch_rollout asks before it chooses the path).
+bool tile_path_supported(Handle* h, const RolloutArgs& a) {
+    if (a.D > 4) return false;
+    if (ensure_sep_table(h, a.D)) return false;
+    StepArgs t{};
+    step_geometry(h, a, t);
+    const int DP = tile_dp(a.D);
+    const size_t tile_lds = (size_t)make_tile_layout(DP, a.E, t.cch).total * sizeof(double);
+    const size_t point_lds = (size_t)make_point_layout(a.N, a.D, a.E, t.CS, t.mom_stride).total * sizeof(double);
+    return tile_lds <= (size_t)h->lds_limit && point_lds <= (size_t)h->lds_limit;
 }
 
 // Workspace of the batch-major path: step records | per-tile partial sums | hand-over flags.
@@ -160,7 +177,7 @@ static int launch_step_dp(Handle* h, const StepArgs& t, hipStream_t s) {
         auto kern = point_pass_kernel<DP>;
         int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
         if (rc) return rc;
-        const PointLayout L = make_point_layout(t.D, t.E, t.CS, t.mom_stride);
+        const PointLayout L = make_point_layout(t.N, t.D, t.E, t.CS, t.mom_stride);
         const size_t lds = (size_t)L.total * sizeof(double);
         if (lds > (size_t)h->lds_limit) { h->err = "point pass: LDS layout too large"; return GPMPC_ERR_LIMIT; }
         hipLaunchKernelGGL(kern, dim3(t.B), dim3(256), lds, s, t);

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kTileWaves * 64, 4) void pair_tile_kernel(const Ste
     const double lv = p.logvar[a];
     const int ngroups = (ncand + kTileGC - 1) / kTileGC;
     // the (a, a) problem of the candidates' step records: Z (DP x DP) | 1 / sqrt(det R) | degree
-    const double* __restrict__ tpar = p.crec + p.off_pair + pair_index(a, a, D) * p.PR;
+    const double* __restrict__ tpar = p.crec + p.off_pair + pair_index(a, a, D) * p.PRP;
     // Taylor degrees of the candidates of a group (0: direct exp), fetched one group ahead
     auto degrees = [&](int g, int (&K)[kTileGC]) {
 #pragma unroll
@@ -180,32 +180,32 @@ __global__ __launch_bounds__(kTileWaves * 64, 4) void pair_tile_kernel(const Ste
         const int side = (wave >> 1) & 1;
         const int pt = (wave & 1) * 64 + lane;
         const double* xp = s_xs + (size_t)side * E * kTileW + pt;
+        // log-factor and monomial variables of the point from the pair's Q and G (step_params_kernel)
+        const double* Qs = par + DP * DP + 2;
+        const double* Gs = Qs + DP * DP;
         double nu[DP], u[DP], g_[DP];
-        double ks = 0.0;
+        double qf = 0.0;
 #pragma unroll
         for (int d = 0; d < DP; ++d) {
             nu[d] = (d < D) ? xp[d * kTileW] - mo[d] : 0.0;
             u[d] = nu[d] * ((d < D) ? il[d] : 0.0);
-            ks = fma(nu[d], u[d], ks);
-            g_[d] = 0.0;
         }
         for (int e = D; e < E; ++e) {
             const double v = xp[e * kTileW] - mo[e];
-            ks = fma(v * v, il[e], ks);
+            qf = fma(v * v, il[e], qf);
         }
-        double qq = 0.0;
 #pragma unroll
         for (int i = 0; i < DP; ++i) {
-            double zu = 0.0;
+            double r = 0.0, gi = 0.0;
 #pragma unroll
             for (int j = 0; j < DP; ++j) {
-                const double z = par[i * DP + j];
-                zu = fma(z, u[j], zu);
-                g_[j] = fma(z, u[i], g_[j]);          // g = Z^T u
+                r = fma(Qs[i * DP + j], nu[j], r);
+                gi = fma(Gs[i * DP + j], nu[j], gi);
             }
-            qq = fma(u[i], zu, qq);
+            qf = fma(nu[i], r, qf);
+            g_[i] = gi;
         }
-        const double kkv = lv - 0.5 * ks + 0.5 * qq;
+        const double kkv = fma(-0.5, qf, lv);
         const double f = (K > 0) ? fast_exp(kkv, s_tab) : kkv;
         const int buf = g & 1;
         if (side == 0) {

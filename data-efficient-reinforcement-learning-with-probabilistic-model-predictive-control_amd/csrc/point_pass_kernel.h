@@ -61,7 +61,7 @@ struct StepArgs {
     double time0;
     int nb, ntiles;         // tile rows / columns, upper-triangle tile count nb (nb + 1) / 2
     int cch, nchunk;        // candidates per tile workgroup, chunks
-    int CS, off_mean, off_pair, PR;      // record layout: PR = DP * DP + 2 doubles per problem
+    int CS, off_mean, off_pair, PR, PRP; // record layout: PR = DP * DP + 2 doubles per mean problem, PRP = 4 DP * DP + 2 per pair
     int force_path;         // 1: direct exp for every pair, 2: never separable (tests)
     int ksep;               // highest separable degree (septab->ks)
     int mom_stride;         // doubles per (pair, side) moment array in LDS
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void step_params_kernel(const StepArgs p) {
         wr[i] = (i < D) ? rg * ilb[i] : 0.0;
     }
     const double detR = small_solve<DP>(m);
-    double* out = rec + p.off_pair + q * p.PR;
+    double* out = rec + p.off_pair + q * p.PRP;
     double cmax = 0.0;
 #pragma unroll
     for (int i = 0; i < DP; ++i) {
@@ -169,6 +169,23 @@ __global__ __launch_bounds__(256) void step_params_kernel(const StepArgs p) {
     }
     out[DP * DP] = 1.0 / sqrt(detR);
     out[DP * DP + 1] = (double)K;
+    // What the per-point passes need of this pair, so that a point costs two small matrix-vector products:
+    //   log-factor of a point  k' = log var_c - (nu^T Q_c nu + action / time terms) / 2,  Q_c = L_c - L_c sym(Z) L_c,  L_c = diag(1 / l_c^2)
+    //   (= k + u^T Z u / 2 of rollout_kernel.h with u = L_c nu; c = a on the row side, b on the column side), and  g = Z^T L_a nu = G nu.
+    double* Q0 = out + DP * DP + 2;
+    double* G = Q0 + DP * DP;
+    double* Q1 = G + DP * DP;
+#pragma unroll
+    for (int i = 0; i < DP; ++i)
+#pragma unroll
+        for (int k = 0; k < DP; ++k) {
+            const bool in = (i < D && k < D);
+            const double zs = in ? 0.5 * (m[i][DP + k] + m[k][DP + i]) : 0.0;
+            const double lai = in ? ila[i] : 0.0, lak = in ? ila[k] : 0.0, lbi = in ? ilb[i] : 0.0, lbk = in ? ilb[k] : 0.0;
+            Q0[i * DP + k] = (i == k ? lai : 0.0) - lai * zs * lak;
+            Q1[i * DP + k] = (i == k ? lbi : 0.0) - lbi * zs * lbk;
+            G[i * DP + k] = in ? m[k][DP + i] * lak : 0.0;               // g_i = sum_k Z_ki l_ak^-2 nu_k
+        }
 }
 
 // The trajectory's index 0 and the hand-over flags (the step kernels read their state from the trajectory arrays).
@@ -322,10 +339,10 @@ __host__ __device__ inline bool sep_band_supported(int nv, int m) {
 }
 
 struct PointLayout {
-    int rec, tab, exptab, ils2, logvar, var, mu, Sig, s1, M, Vs, Sp, mom, task, total;     // offsets in doubles
+    int rec, tab, exptab, ils2, logvar, var, mu, Sig, s1, M, Vs, Sp, mom, task, act, total;     // offsets in doubles
 };
 
-__host__ __device__ inline PointLayout make_point_layout(int D, int E, int CS, int mom_stride) {
+__host__ __device__ inline PointLayout make_point_layout(int N, int D, int E, int CS, int mom_stride) {
     const int P = D * (D + 1) / 2, Poff = P - D;
     PointLayout L;
     int o = 0;
@@ -343,6 +360,7 @@ __host__ __device__ inline PointLayout make_point_layout(int D, int E, int CS, i
     L.Sp = o;     o += rnd2(P);
     L.task = o;   o += 80;                    // counter, count, up to 150 tasks (ints)
     L.mom = o;    o += (Poff > 0 ? Poff : 1) * 2 * mom_stride;
+    L.act = o;    o += D * rnd2(N);           // action / time terms of the log-factors, per output and point
     L.total = o;
     return L;
 }
@@ -357,7 +375,7 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int N = p.N, D = p.D, E = p.E;
-    const PointLayout L = make_point_layout(D, E, p.CS, p.mom_stride);
+    const PointLayout L = make_point_layout(N, D, E, p.CS, p.mom_stride);
     double* s_exptab = smem + L.exptab;
     double* s_rec = smem + L.rec;
     const SepTable* s_tab = reinterpret_cast<const SepTable*>(smem + L.tab);
@@ -371,6 +389,8 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
     double* s_Vs = smem + L.Vs;
     double* s_Sp = smem + L.Sp;
     double* s_mom = smem + L.mom;
+    double* s_act = smem + L.act;
+    const int NA = rnd2(N);
     int* s_task = reinterpret_cast<int*>(smem + L.task);      // [0] counter, [1] count, [2..] tasks
 
     // ---- stage the candidate's step record and the small tables ------------------------------------------------------
@@ -390,6 +410,16 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
         for (int i = tid; i < D * D; i += NT) s_Sig[i] = p.Sig[((size_t)c * (p.H + 1) + p.t) * D * D + i];
     }
     __syncthreads();
+    // action / time part of every log-factor: sum_{e >= D} (x_e - m_e)^2 / l_ce^2, once per (output, point) instead of once per task
+    for (int i = tid; i < D * N; i += NT) {
+        const int co = i / N, pt = i - co * N;
+        double v = 0.0;
+        for (int e = D; e < E; ++e) {
+            const double dx = p.Xt[(size_t)e * N + pt] - s_rec[e];
+            v = fma(dx * dx, c_ils2[co * E + e], v);
+        }
+        s_act[co * NA + pt] = v;
+    }
     if (tid == 0) {
         // tasks: [kind 0: mean part of output a] [kind 1: (pair q, side, band)]; the long ones (pairs) first
         int n = 0;
@@ -397,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
         for (int a = 0; a < D; ++a)
             for (int b = a; b < D; ++b, ++q) {
                 if (a == b) continue;
-                const int K = (int)s_rec[p.off_pair + q * p.PR + DP * DP + 1] & 63;
+                const int K = (int)s_rec[p.off_pair + q * p.PRP + DP * DP + 1] & 63;
                 for (int side = 0; side < 2; ++side)
                     for (int bi = 0; bi < s_tab->nb[K]; ++bi) s_task[2 + n++] = (1 << 24) | (q << 16) | (side << 8) | (s_tab->first[K] + bi);
             }
@@ -444,10 +474,7 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
                     for (int k = 0; k < DP; ++k) r = fma(Am[i][k], nu[k], r);
                     qv = fma(nu[i], r, qv);
                 }
-                for (int e = D; e < E; ++e) {
-                    const double v = p.Xt[(size_t)e * N + pt] - mo[e];
-                    qv = fma(v * v, c_ils2[a * E + e], qv);
-                }
+                qv += s_act[a * NA + pt];
                 double lb = fast_exp(-0.5 * qv, s_exptab) * p.beta[(size_t)a * N + pt];
                 lb = live ? lb : 0.0;
                 a0 += lb;
@@ -469,15 +496,19 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
         while (rem >= D - a) { rem -= D - a; ++a; }
         const int b = a + rem;
         const int co = side ? b : a;                           // the output whose lengthscales scale nu
-        const double* Zs = s_rec + p.off_pair + q * p.PR;
-        double Z[DP][DP], il[DP];
+        const double* pr = s_rec + p.off_pair + q * p.PRP;
+        const double* Qs = pr + DP * DP + 2 + (side ? 2 * DP * DP : 0);       // Q of this side
+        const double* Gs = pr + 2 * DP * DP + 2;                               // g = G nu (row side)
+        double Qm[DP][DP], Xm[DP][DP];                                        // Xm: the map nu -> monomial variables (G | diag(1 / l_b^2))
 #pragma unroll
-        for (int i = 0; i < DP; ++i) {
-            il[i] = (i < D) ? c_ils2[co * E + i] : 0.0;
+        for (int i = 0; i < DP; ++i)
 #pragma unroll
-            for (int k = 0; k < DP; ++k) Z[i][k] = Zs[i * DP + k];
-        }
+            for (int k = 0; k < DP; ++k) {
+                Qm[i][k] = Qs[i * DP + k];
+                Xm[i][k] = side ? ((i == k && i < D) ? c_ils2[co * E + i] : 0.0) : Gs[i * DP + k];
+            }
         const double lv = c_logvar[co];
+        const double* actc = s_act + co * NA;
         const SepBand* bd = &s_tab->band[bi];
         const int bs = __builtin_amdgcn_readfirstlane(bd->s);
         const int code = __builtin_amdgcn_readfirstlane(bd->nv * 16 + bd->m);
@@ -508,36 +539,27 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
                 for (int d = 0; d < DP; ++d) xn[d] = (d < D) ? p.Xt[(size_t)d * N + ptn] : 0.0;
                 bn = p.beta[(size_t)co * N + ptn];
             }
-            double nu[DP], u[DP], g[DP];
-            double ks = 0.0;
+            double nu[DP], xq[DP];
 #pragma unroll
-            for (int d = 0; d < DP; ++d) {
-                nu[d] = (d < D) ? xc[d] - mo[d] : 0.0;
-                u[d] = nu[d] * il[d];
-                ks = fma(nu[d], u[d], ks);
-                g[d] = 0.0;
-            }
-            for (int e = D; e < E; ++e) {
-                const double v = p.Xt[(size_t)e * N + pt] - mo[e];
-                ks = fma(v * v, c_ils2[co * E + e], ks);
-            }
-            double qq = 0.0;
+            for (int d = 0; d < DP; ++d) nu[d] = (d < D) ? xc[d] - mo[d] : 0.0;
+            double qf = actc[pt];
 #pragma unroll
             for (int i = 0; i < DP; ++i) {
-                double zu = 0.0;
+                double r = 0.0, xi = 0.0;
 #pragma unroll
                 for (int k = 0; k < DP; ++k) {
-                    zu = fma(Z[i][k], u[k], zu);
-                    g[k] = fma(Z[i][k], u[i], g[k]);          // g = Z^T u
+                    r = fma(Qm[i][k], nu[k], r);
+                    xi = fma(Xm[i][k], nu[k], xi);
                 }
-                qq = fma(u[i], zu, qq);
+                qf = fma(nu[i], r, qf);
+                xq[i] = xi;
             }
-            const double kkv = lv - 0.5 * ks + 0.5 * qq;
+            const double kkv = fma(-0.5, qf, lv);
             double wt = fast_exp(kkv, s_exptab) * bc;
             wt = live ? wt : 0.0;
             double x[4];
 #pragma unroll
-            for (int d = 0; d < 4; ++d) x[d] = (d < DP) ? (side ? u[d < DP ? d : 0] : g[d < DP ? d : 0]) : 0.0;
+            for (int d = 0; d < 4; ++d) x[d] = (d < DP) ? xq[d < DP ? d : 0] : 0.0;
             // prefix monomial (wave-uniform exponents)
 #pragma unroll
             for (int d = 0; d < 4; ++d)
@@ -571,7 +593,7 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
             for (int b = a; b < D; ++b, ++q) {
                 const int owner = q & (NW - 1);
                 if (owner != wave) continue;
-                const double* pr = s_rec + p.off_pair + q * p.PR;
+                const double* pr = s_rec + p.off_pair + q * p.PRP;
                 if (a == b) {
                     // sum of the tiles' partial sums (i <= j only: factor 2)
                     const double* tp = p.part + ((size_t)c * D + a) * p.ntiles;

@@ -233,6 +233,7 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     if (!gs && cols2 && DP <= 4 && nt == 1024 && h->opt_pair_tiles != 2) {
         const double tri_bytes = 4.0 * D * (double)N * N;          // upper triangles of the D tables
         tiled = h->opt_pair_tiles == 1 || (tri_bytes >= 6.0e6 && a.B >= 2 * h->num_cu);
+        tiled = tiled && tile_path_supported(h, a);
     }
     const int Pg = tiled ? (P - D > 0 ? P - D : 1) : P;           // pairs the per-candidate kernel keeps row records for
     const int NCu = cols2 ? (N + 1) / 2 : N;     // column units per row chunk
