@@ -78,7 +78,12 @@ class TrainingConfig:
         self.clip_grad_value = clip_grad_value
         self.print_train = print_train
         self.step_print_train = step_print_train
-        self.device = device      # "auto": gpmpc_mll on the GPU when one is visible to the training process; "hip"; "cpu"
+        # where the training loss is evaluated: "auto" / "hip" = gpmpc_mll on the GPU of the training process.  There is no
+        # CPU expression of the loss in this package (the reference's runs in gpytorch): anything else is refused HERE, in
+        # the parent, instead of failing inside the spawned child
+        if device not in ("auto", "hip"):
+            raise ValueError(f"TrainingConfig.device={device!r}: the training loss runs on the GPU only ('auto' or 'hip')")
+        self.device = device
 
 
 _DEFAULT_OPTIMIZER = {"disp": None, "maxcor": 30, "ftol": 1e-99, "gtol": 1e-99, "eps": 1e-2, "maxfun": 30,

@@ -29,7 +29,7 @@ from ..actions_mappers.action_init_functions import (generate_mpc_action_init_fr
                                                      generate_mpc_action_init_random)
 from ..actions_mappers.mappers import DerivativeActionMapper, NormalizationActionMapper
 from ..memories.gp_memory import Memory
-from ..models.gp_model import GpStateTransitionModel
+from ..models.gp_model import GpStateTransitionModel, TrainingFailed
 from ..observations_states_mappers.normalization_observation_state_mapper import NormalizationObservationStateMapper
 from ..states_reward_mappers.setpoint_distance_reward_mapper import SetpointStateRewardMapper
 from .abstract_controller import BaseControllerObject

@@ -367,7 +367,7 @@ class GpStateTransitionModel(AbstractStateTransitionModel):
                             loss = neg_mll(val("ls"), val("os"), val("nz"))
                             loss.backward()
                             return loss
-                        loss = float(opt.step(closure))
+                        loss = float(opt.step(closure).detach())
                         if print_train and i % step_print_train == 0:
                             print(f"train gp {a} iter {i + 1}/{num_iter_train} loss {loss:.5f}")
                         if loss < best_loss:

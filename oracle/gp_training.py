@@ -43,3 +43,58 @@ def neg_mll_torch(X, y, lengthscale, outputscale, noise):
     alpha = torch.cholesky_solve(y[:, None], L)[:, 0]
     ll = -0.5 * (y @ alpha) - torch.log(torch.diagonal(L)).sum() - 0.5 * N * np.log(2 * np.pi)
     return -ll / N
+
+
+def train_loop(X, Y, parameters, constraints, lr, num_iter, seed):
+    """The reference's hyper-parameter search restated on the CPU, independent of the product's driver
+    (rl_gp_mpc/control_objects/models/gp_model.py:193-306): GP after GP --
+      previous loss at the incoming parameters (:226-229); a restart drawn uniformly inside the constraint box in the order
+      outputscale, lengthscale, noise (:236-252; gpytorch's Interval constraint maps a raw parameter through a sigmoid, so
+      the optimisation variable is raw = logit((value - lo) / (hi - lo))); torch LBFGS with strong-Wolfe line search
+      (:256-258), `num_iter` steps, the loss of every step compared with the best so far and the parameters AFTER the step
+      kept (:277-282); the incoming parameters win if nothing better was found.
+    The reference's clip_grad_value_ call sits BEFORE backward() on freshly zeroed gradients (:266-267) and is a no-op.
+    parameters: list of dicts {lengthscale (E,), outputscale, noise}; constraints: dict of (D, ...) arrays
+    min/max_lengthscale, min/max_outputscale, min/max_std_noise.  Returns the list of dicts and the list of best losses."""
+    import torch
+    F = torch.float64
+    X = torch.as_tensor(np.asarray(X), dtype=F)
+    Y = torch.as_tensor(np.asarray(Y), dtype=F)
+    torch.manual_seed(seed)
+    out, losses = [], []
+    for a, p in enumerate(parameters):
+        lo = {"ls": torch.as_tensor(np.asarray(constraints["min_lengthscale"])[a], dtype=F),
+              "os": torch.as_tensor(float(np.asarray(constraints["min_outputscale"])[a]), dtype=F),
+              "nz": torch.as_tensor(float(np.asarray(constraints["min_std_noise"])[a]) ** 2, dtype=F)}
+        hi = {"ls": torch.as_tensor(np.asarray(constraints["max_lengthscale"])[a], dtype=F),
+              "os": torch.as_tensor(float(np.asarray(constraints["max_outputscale"])[a]), dtype=F),
+              "nz": torch.as_tensor(float(np.asarray(constraints["max_std_noise"])[a]) ** 2, dtype=F)}
+        y = Y[:, a]
+        best = {"ls": torch.as_tensor(np.asarray(p["lengthscale"], dtype=float).reshape(-1), dtype=F),
+                "os": torch.as_tensor(float(p["outputscale"]), dtype=F), "nz": torch.as_tensor(float(p["noise"]), dtype=F)}
+        try:
+            best_loss = float(neg_mll_torch(X, y, best["ls"], best["os"], best["nz"]))
+        except Exception:
+            best_loss = float("inf")
+        u = {"os": torch.rand((), dtype=F), "ls": torch.rand(best["ls"].shape, dtype=F), "nz": torch.rand((), dtype=F)}
+        raw = {k: torch.logit(u[k].clamp(1e-6, 1 - 1e-6)).requires_grad_(True) for k in ("ls", "os", "nz")}
+
+        def value(k):
+            return lo[k] + (hi[k] - lo[k]) * torch.sigmoid(raw[k])
+        opt = torch.optim.LBFGS([raw["ls"], raw["os"], raw["nz"]], lr=lr, line_search_fn="strong_wolfe")
+        try:
+            for _ in range(num_iter):
+                def closure():
+                    opt.zero_grad()
+                    loss = neg_mll_torch(X, y, value("ls"), value("os"), value("nz"))
+                    loss.backward()
+                    return loss
+                loss = float(opt.step(closure).detach())
+                if loss < best_loss:
+                    best_loss = loss
+                    best = {k: value(k).detach().clone() for k in raw}
+        except Exception:
+            pass
+        out.append({"lengthscale": best["ls"].numpy().copy(), "outputscale": float(best["os"]), "noise": float(best["nz"])})
+        losses.append(best_loss)
+    return out, losses

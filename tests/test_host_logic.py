@@ -213,12 +213,58 @@ def test_training_always_answers_the_queue():
                      "min_outputscale": np.array([1e-3]), "max_outputscale": np.array([0.95]),
                      "min_std_noise": np.array([1e-3]), "max_std_noise": np.array([3e-1])})
     st.to_arrays()
+    from gp_mpc_amd.control_objects.models.gp_model import TrainingFailed
     for dev in ("hip", "cpu"):                 # no GPU in this container / a device the product does not have
         q = queue.Queue()
         GpStateTransitionModel.train(q, st, 1e-1, 3, 1e-3, device=dev)
-        (out,) = q.get_nowait()
+        answer = q.get_nowait()
+        assert isinstance(answer, TrainingFailed) and answer.reason       # the parent can tell a failed training
+        (out,) = answer
         assert np.array_equal(out["covar_module.base_kernel.lengthscale"], np.asarray(p0["covar_module.base_kernel.lengthscale"]))
         assert q.empty()
+    # the marker survives the trip through a multiprocessing queue (pickle)
+    import pickle
+    back = pickle.loads(pickle.dumps(answer))
+    assert isinstance(back, TrainingFailed) and back.reason == answer.reason and len(back) == 1
+    # ... and a device the package cannot compute on is refused in the parent, at configuration time
+    from gp_mpc_amd.config_classes import TrainingConfig
+    with pytest.raises(ValueError):
+        TrainingConfig(device="cpu")
+
+
+def test_training_draws_its_restarts_in_the_reference_order():
+    """Reference gp_model.py:236-252: per GP the restart is drawn outputscale, lengthscale, noise -- GP after GP.  With the
+    per-GP searches running as lockstep threads the draws are made up front in that order, so a seeded run consumes the
+    generator exactly like the sequential loop."""
+    import queue
+    from gp_mpc_amd.control_objects.models.gp_model import GpStateTransitionModel, SavedState, GpHyperParameters
+    rng = np.random.default_rng(1)
+    X = rng.uniform(size=(30, 2))
+    Y = np.stack([np.sin(3 * X[:, 0]), np.cos(2 * X[:, 1])], axis=1) * 0.2
+    cons = {"min_lengthscale": np.full((2, 2), 4e-3), "max_lengthscale": np.full((2, 2), 10.0),
+            "min_outputscale": np.full(2, 1e-3), "max_outputscale": np.full(2, 0.95),
+            "min_std_noise": np.full(2, 1e-3), "max_std_noise": np.full(2, 3e-1)}
+    seen = []
+
+    def spy(Xt, y, ls, osc, nz):
+        seen.append((ls.detach().numpy().copy(), float(osc), float(nz)))
+        from oracle.gp_training import neg_mll_torch
+        return neg_mll_torch(Xt, y, ls, osc, nz)
+    st = SavedState(X, Y, [GpHyperParameters([5.0, 5.0], 0.9, 0.09).state_dict() for _ in range(2)], cons)
+    st.to_arrays()
+    torch.manual_seed(3)
+    GpStateTransitionModel.train(queue.Queue(), st, 1e-1, 1, 1e-3, loss_evaluator=spy)
+    torch.manual_seed(3)
+    want = []
+    for a in range(2):
+        r_os, r_ls, r_nz = torch.rand((), dtype=torch.float64), torch.rand(2, dtype=torch.float64), torch.rand((), dtype=torch.float64)
+        want.append((4e-3 + (10.0 - 4e-3) * r_ls.numpy(), 1e-3 + (0.95 - 1e-3) * float(r_os), 1e-6 + (9e-2 - 1e-6) * float(r_nz)))
+    # evaluation order without a device: GP 0 (incoming parameters, then its restart), then GP 1
+    first_restart = [s for s in seen if not np.allclose(s[0], 5.0)]
+    got0 = first_restart[0]
+    got1 = next(s for s in first_restart if not np.allclose(s[0], got0[0]) and abs(s[1] - got0[1]) > 1e-12 and np.allclose(s[0], want[1][0], rtol=1e-9))
+    assert np.allclose(got0[0], want[0][0], rtol=1e-9) and abs(got0[1] - want[0][1]) < 1e-9 and abs(got0[2] - want[0][2]) < 1e-9
+    assert abs(got1[1] - want[1][1]) < 1e-9 and abs(got1[2] - want[1][2]) < 1e-9
 
 
 def test_set_cost_follows_in_place_edits_of_the_reward_config():
@@ -355,3 +401,61 @@ def test_committed_bench_line_has_the_contract_fields():
     assert d["scaling"] == "weak" and 0.0 < r["valu_busy_frac"] < 1.0 and r["peak_measured_fma_loop"] > 30.0
     d5 = json.loads(open(os.path.join(ROOT, "profiles", "r02b_c5_bench_B256.json")).read().strip().splitlines()[-1])
     assert d5["scaling"] == "strong" and d5["cpu_baseline"].get("extrapolated") is True and d5["config"]["N"] == 4096
+
+
+def test_lockstep_training_batches_the_gps_and_isolates_a_failing_one():
+    """GpStateTransitionModel.train with a device loss: the D per-GP LBFGS searches run as threads and every round of
+    pending evaluations is ONE engine.mll call over the waiting GPs (reference: GP after GP, gp_model.py:233-290).  A fake
+    engine (the oracle's closed form behind the engine's mll signature) stands in for the GPU here: call count, batch
+    widths, the per-GP fallback when a batched call raises, and the result against the sequential CPU restatement."""
+    import queue
+    from oracle import gp_training
+    import gp_mpc_amd.control_objects.models.gp_model as gm
+
+    class FakeEngine:
+        device = torch.device("cpu")
+        calls = []
+
+        def __init__(self, dev=None):
+            pass
+
+        def mll(self, X, Y, ls, osc, nz):
+            X, Y = np.asarray(X), np.asarray(Y)
+            ls, osc, nz = np.asarray(ls), np.asarray(osc).reshape(-1), np.asarray(nz).reshape(-1)
+            FakeEngine.calls.append(Y.shape[1])
+            if Y.shape[1] > 1 and len(FakeEngine.calls) == 3:
+                raise RuntimeError("batched call fails once: the pending GPs must be evaluated one by one")
+            out = {"loss": [], "d_lengthscale": [], "d_outputscale": [], "d_noise": []}
+            for k in range(Y.shape[1]):
+                loss, g_ls, g_os, g_nz = gp_training.neg_mll_and_grad(X, Y[:, k], ls[k], osc[k], nz[k])
+                out["loss"].append(loss); out["d_lengthscale"].append(g_ls); out["d_outputscale"].append(g_os); out["d_noise"].append(g_nz)
+            return {k: np.asarray(v) for k, v in out.items()}
+
+        def close(self):
+            pass
+
+    rng = np.random.default_rng(2)
+    X = rng.uniform(size=(30, 2))
+    Y = np.stack([0.3 * np.sin(4 * X[:, 0]), 0.2 * np.cos(3 * X[:, 1]), 0.1 * X[:, 0] * X[:, 1]], axis=1) + 0.01 * rng.standard_normal((30, 3))
+    cons = {"min_lengthscale": np.full((3, 2), 4e-3), "max_lengthscale": np.full((3, 2), 10.0),
+            "min_outputscale": np.full(3, 1e-3), "max_outputscale": np.full(3, 0.95),
+            "min_std_noise": np.full(3, 1e-3), "max_std_noise": np.full(3, 3e-1)}
+    st = gm.SavedState(X, Y, [gm.GpHyperParameters([5.0, 5.0], 0.9, 0.09).state_dict() for _ in range(3)], dict(cons))
+    st.to_arrays()
+    import gp_mpc_amd.engine as engine_module
+    real = engine_module.HipEngine
+    engine_module.HipEngine = FakeEngine
+    try:
+        q = queue.Queue()
+        torch.manual_seed(0)
+        gm.GpStateTransitionModel.train(q, st, 1e-1, 4, 1e-3, device="hip")
+        got = q.get_nowait()
+    finally:
+        engine_module.HipEngine = real
+    assert not isinstance(got, gm.TrainingFailed)
+    assert FakeEngine.calls[0] == 3 and max(FakeEngine.calls) == 3          # all GPs in one call while all are running
+    assert FakeEngine.calls[3:6] == [1, 1, 1]                                # the failed batched call, GP by GP
+    want, _ = gp_training.train_loop(X, Y, [{"lengthscale": [5.0, 5.0], "outputscale": 0.9, "noise": 0.09}] * 3, cons, 1e-1, 4, seed=0)
+    for a in range(3):
+        assert np.allclose(np.asarray(got[a][gm.GpHyperParameters.KEYS[0]]).ravel(), want[a]["lengthscale"], rtol=1e-5)
+        assert abs(float(got[a][gm.GpHyperParameters.KEYS[1]]) - want[a]["outputscale"]) < 1e-5 * want[a]["outputscale"]
