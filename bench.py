@@ -89,6 +89,9 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="override N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (exercises the N > 1 code path)")
+    ap.add_argument("--exchange", default="host", choices=["host", "rccl"],
+                    help="N > 1: how the per-rank winner records meet -- 'host': after the device-to-host copy, between the hosts "
+                         "(nothing on the GPU streams); 'rccl': one all_gather per step on the compute stream")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option for an A/B run (gpmpc_set_option; recorded in config.engine_options)")
@@ -159,7 +162,8 @@ def main():
 
     def launch(k):
         out = bufs["out"] = eng.rollout(actions, w.mu0, w.S0, w.include_time, w.time0, out=bufs["out"])
-        pend = sharding.select_best_async(eng, out["J"], actions, lo, B_total, host_buffer=pinned[k & 1], record=bufs["rec"])
+        pend = sharding.select_best_async(eng, out["J"], actions, lo, B_total, host_buffer=pinned[k & 1], record=bufs["rec"],
+                                          exchange=args.exchange)
         pinned[k & 1] = pend.host
         bufs["rec"] = pend.record
         return pend, out
@@ -192,6 +196,7 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -235,28 +240,53 @@ def main():
     # kernel-only time of the dominant kernel: HIP events on the launch stream
     reps = int(max(1, min(args.steps, 20, 3000.0 / max(est_step_ms, 1e-3))))
     kernel_ms, _ = eng.rollout_timed(actions, w.mu0, w.S0, max(reps, 3 if est_step_ms < 1000 else 1), w.include_time, w.time0)
+    rollout_path = eng.last_rollout_path
+    build_id = eng.build_id
+    # per-rank view for a multi-GPU line: every rank's slice and kernel time (a future SCALE line is diagnosable from it)
+    per_rank = None
+    if use_dist:
+        mine = torch.tensor([float(Bg), float(kernel_ms), float(elapsed_local / args.steps * 1e3)], dtype=torch.float64, device=device)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "candidates": int(v[0].item()), "kernel_ms": float(v[1].item()), "ms_per_step": float(v[2].item())}
+                    for r, v in enumerate(allr)]
 
     if rank == 0:
         flops_launch = algorithmic_flops_per_rollout(N, D, A, E, H) * Bg
         achieved_tflops = flops_launch / (kernel_ms * 1e-3) / 1e12
         # counter-derived figures of the same launch shape, collected with rocprofv3 --pmc in separate passes
         # (tools/gpu_counters.sh -> profiles/pmc_traffic.json, profiles/pmc_counters.json)
-        traffic, counters = None, None
+        traffic, counters, counters_note = None, None, None
         key = f"{args.workload}:N{N}:B{Bg}"
         for fname in ("pmc_traffic.json", "pmc_counters.json"):
             try:
                 val = json.load(open(os.path.join(ROOT, "profiles", fname))).get(key)
             except Exception:
                 val = None
+            # counter files name the build they were collected on (gpmpc_build_id); figures of another build are not reported
+            bid = val.get("_build_id" if fname == "pmc_counters.json" else "build_id") if isinstance(val, dict) else None
+            if val is not None and bid != build_id:
+                counters_note = (f"profiles/{fname}[{key}] was collected on build {bid}, the loaded library is {build_id}: "
+                                 "counter-derived figures withheld (re-run tools/gpu_counters.sh)")
+                val = None
             if fname == "pmc_traffic.json":
-                traffic = val
+                traffic = val["bytes"] if isinstance(val, dict) else val
             else:
                 counters = val
         fma_peak, fma_src = measured_fma_loop_peak()
-        valu_busy = None
+        valu_busy, executed = None, None
         if counters and counters.get("SQ_INSTS_VALU"):
             # a wave64 fp64 VALU instruction occupies its SIMD's 16 lanes for 4 cycles; 1024 SIMDs
             valu_busy = counters["SQ_INSTS_VALU"] * 4.0 / (1024.0 * kernel_ms * 1e-3 * NOMINAL_CLOCK_GHZ * 1e9)
+        if counters and counters.get("SQ_INSTS_VALU_FMA_F64") is not None:
+            # fp64 operations the SIMDs actually issued (wave-instructions x 64 lanes; FMA = 2 flop; the f64 matrix counter is
+            # in units of 512 multiply-adds): the EXECUTED-flop roofline beside the algorithmic one
+            flops = 64.0 * (counters.get("SQ_INSTS_VALU_ADD_F64", 0.0) + counters.get("SQ_INSTS_VALU_MUL_F64", 0.0)
+                            + 2.0 * counters["SQ_INSTS_VALU_FMA_F64"]) + 1024.0 * counters.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
+            executed = {"fp64_flops_per_launch": flops, "tflops": flops / (kernel_ms * 1e-3) / 1e12,
+                        "frac_of_peak": flops / (kernel_ms * 1e-3) / 1e12 / PEAK_F64_VECTOR_TFLOPS,
+                        "note": "64 x (ADD_F64 + MUL_F64 + 2 FMA_F64) + 1024 x MFMA_MOPS_F64 from the SQ counters of this build; "
+                                "lanes switched off by the exec mask are counted (upper bound of useful work)"}
         result = {
             "metric": "MPC trajectory rollouts/sec",
             "value": B_total * args.steps / elapsed,
@@ -274,13 +304,18 @@ def main():
                                    f"B={B_total} total = {Bg}/GPU ({scaling} scaling) fp64 "
                                    f"(BASELINE.json configs[{list(synth.SHAPES).index(args.workload)}] shape)",
                        "N": N, "D": D, "A": A, "H": H, "B_per_gpu": Bg, "B_total": B_total,
-                       "parallelism": f"candidates sharded x{world}, RCCL gather of (J, idx) only",
+                       "parallelism": f"candidates sharded x{world}, " + ("host-side exchange of the (J, idx, winner) records after the copy"
+                                                                            if args.exchange == "host" else "RCCL gather of (J, idx, winner) only"),
+                       "exchange": args.exchange,
                        **({"engine_options": engine_options} if engine_options else {})},
             "roofline": {"bound": "valu_f64", "achieved": achieved_tflops, "peak": PEAK_F64_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F64_VECTOR_TFLOPS, "traffic": traffic,
                          "peak_measured_fma_loop": fma_peak, "peak_measured_source": fma_src,
                          "frac_of_measured_fma_loop": None if not fma_peak else achieved_tflops / fma_peak,
                          "valu_busy_frac": valu_busy,
+                         "executed": executed,
+                         "counters_note": counters_note,
+                         "build_id": build_id,
                          # measured bytes at the L2 -> fabric boundary (Infinity Cache or HBM behind it) per second of kernel
                          # time: at N = 1000 (c4) the T_a tiles no longer stay in the 4 MB L2 of an XCD and this, not the
                          # VALU, is the higher of the two utilisations
@@ -291,7 +326,10 @@ def main():
                                       "peak_gbps": 8000.0,
                                       "note": "compulsory bytes without cross-candidate reuse; above the HBM peak because the "
                                               "T_a tiles are shared by the candidates and stay in L2 (see traffic)"},
-                         "kernel": "rollout_kernel", "kernel_ms": kernel_ms,
+                         "kernel": ["rollout_kernel (fused horizon)", "rollout_stream_kernel",
+                                    "pair_tile_kernel + point_pass_kernel per horizon step (batch-major path)"][rollout_path],
+                         "rollout_path": rollout_path,
+                         "kernel_ms": kernel_ms,
                          "algorithmic_flops_per_launch": flops_launch,
                          "algorithmic_bytes_per_launch": algorithmic_bytes_per_rollout(N, D, E, H) * Bg,
                          "note": "frac = SURVEY 8(d) flop count of the REFERENCE formulation (exp = 1 flop) x B candidates / "
@@ -313,6 +351,7 @@ def main():
                 "rollouts_the_same_gradients_cost_by_differences": Bg * (4 * H * A + 1),
                 "note": "J and dJ/du (H x A) for every candidate of the batch: rollout + pair_moments + adjoint_sweep kernels"},
             "best_index": int(best_i), "best_J": float(best_J),
+            "per_rank": per_rank,
         }
         # parity spot check against the CPU oracle on identical inputs (not timed); sized so the checker takes seconds
         from oracle import gpmpc_oracle as orc

@@ -121,27 +121,67 @@ def _winner_of(host, world, H, A):
     return bJ, bi, host[owner, 2:2 + H * A].view(H, A).clone()
 
 
+_HOST_GROUPS = {}
+
+
+def host_group(group=None):
+    """A process group whose collectives run on HOST tensors (gloo) over the same ranks as `group` (None: the default
+    group).  With a gloo default group that is the group itself; with RCCL it is created once (every rank must reach the
+    first call together, like any new_group) and cached."""
+    if dist.get_backend(group) == "gloo":
+        return dist.group.WORLD if group is None else group
+    key = id(group)
+    if key not in _HOST_GROUPS:
+        ranks = None if group is None else dist.get_process_group_ranks(group)
+        _HOST_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo")
+    return _HOST_GROUPS[key]
+
+
 class PendingBest:
     """Winner selection in flight: the packed per-rank records are on their way to a pinned host buffer; `result()`
     waits for THAT copy only (an event), so the host can enqueue the next batch's launches before it looks at this
-    batch's winner."""
+    batch's winner.  With `exchange_group` set the buffer holds THIS rank's record only and `result()` exchanges the
+    records between the hosts (a gloo all_gather of 16 + 8 H A bytes per rank) -- nothing of the exchange is on the GPU's
+    streams, where a per-step RCCL gather cost ~45 us of a 0.47 ms config-2 step."""
 
-    def __init__(self, host, event, world, H, A, record=None):
+    def __init__(self, host, event, world, H, A, record=None, exchange_group=None):
         self.host, self.event, self.world, self.H, self.A = host, event, world, H, A
         self.record = record            # the device record buffer, reusable by the next call
+        self.exchange_group = exchange_group
 
     def result(self):
         if self.event is not None:
             self.event.synchronize()
-        return _winner_of(self.host.view(self.world, -1), self.world, self.H, self.A)
+        host = self.host
+        if self.exchange_group is not None:
+            mine = host.clone()          # gloo wants ordinary (not pinned-view) tensors on some builds
+            flat = torch.empty(self.world * mine.numel(), dtype=torch.float64)
+            dist.all_gather_into_tensor(flat, mine, group=self.exchange_group)
+            host = flat
+        return _winner_of(host.view(self.world, -1), self.world, self.H, self.A)
 
 
-def select_best_async(engine, J, actions_local, lo, num_candidates, group=None, host_buffer=None, record=None):
-    """select_best_on_device without the host synchronisation: local keep-the-best kernel, (N > 1) one RCCL all_gather
-    of the packed records, an asynchronous copy into pinned host memory and an event.  `host_buffer` / `record`:
-    reusable pinned / device buffers of a previous call with the same shapes.  Returns a PendingBest."""
+def select_best_async(engine, J, actions_local, lo, num_candidates, group=None, host_buffer=None, record=None,
+                      exchange="rccl"):
+    """select_best_on_device without the host synchronisation: local keep-the-best kernel, the packed record on its way to
+    pinned host memory behind an event.  `exchange`: "rccl" = (N > 1) one RCCL all_gather of the packed records on the
+    compute stream before the copy; "host" = the copy carries this rank's record only and the records are exchanged
+    between the hosts when the result is read (PendingBest.result) -- the GPU streams carry no collective at all.
+    `host_buffer` / `record`: reusable pinned / device buffers of a previous call with the same shapes.
+    Returns a PendingBest."""
     n, H, A = actions_local.shape
     rec = _local_record(engine, J, actions_local, lo, out=record)
+    if exchange == "host" and dist.is_available() and dist.is_initialized():
+        world = dist.get_world_size(group)
+        xg = host_group(group)
+        if rec.device.type != "cuda":
+            return PendingBest(rec.clone(), None, world, H, A, rec, exchange_group=xg)
+        if host_buffer is None or host_buffer.numel() != rec.numel():
+            host_buffer = torch.empty(rec.numel(), dtype=torch.float64, pin_memory=True)
+        host_buffer.copy_(rec, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(rec.device))
+        return PendingBest(host_buffer, ev, world, H, A, rec, exchange_group=xg)
     world, flat = _gather_records(rec, group)
     if rec.device.type != "cuda":
         return PendingBest(flat.clone(), None, world, H, A, rec)

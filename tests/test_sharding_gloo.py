@@ -116,13 +116,18 @@ def _shipping_worker(rank, world, port, mode, B, ret):
         acts = torch.as_tensor(acts_all[lo:hi])
         J = torch.as_tensor(J_all[lo:hi])
         ok = True
-        for variant in ("blocking", "async", "async_reuse", "extra"):
+        for variant in ("blocking", "async", "async_reuse", "async_host", "extra"):
             if variant == "blocking":
                 bJ, bi, win = sharding.select_best_on_device(eng, J, acts, lo, B)
             elif variant == "extra":
                 payload = torch.full((5,), float(rank))
                 bJ, bi, win, extras = sharding.select_best_on_device(eng, J, acts, lo, B, extra=payload)
                 ok = ok and extras.shape == (world, 5) and all(float(extras[r, 0]) == r for r in range(world))
+            elif variant == "async_host":
+                # the records meet between the hosts when the result is read: nothing collective at selection time
+                pend = sharding.select_best_async(eng, J, acts, lo, B, exchange="host")
+                assert pend.host.numel() == 2 + H * A and pend.exchange_group is not None
+                bJ, bi, win = pend.result()
             else:
                 pend = sharding.select_best_async(eng, J, acts, lo, B)
                 if variant == "async_reuse":

@@ -6,6 +6,8 @@ outputs are stored.
 
   python tools/gen_golden_c5.py            one moment-matched step, 2 candidates  -> oracle_c5_step.npz   (~ minutes)
   python tools/gen_golden_c5.py --steps 5  five horizon steps,     2 candidates  -> oracle_c5_traj.npz   (~ 5x that)
+  python tools/gen_golden_c5.py --steps 50 --candidates 1   BASELINE configs[4]'s full horizon, 1 candidate -> oracle_c5_h50.npz
+                                                             (round 3; ~ an hour on 8 cores: run it in the background)
 """
 import argparse
 import os
@@ -21,10 +23,11 @@ from oracle import gpmpc_oracle as orc  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=1)
+ap.add_argument("--candidates", type=int, default=2)
 args = ap.parse_args()
-N, D, A, H, B = 4096, 16, 4, args.steps, 2
-SEED = 77 if H == 1 else 78
-name = "oracle_c5_step.npz" if H == 1 else "oracle_c5_traj.npz"
+N, D, A, H, B = 4096, 16, 4, args.steps, args.candidates
+SEED = 77 if H == 1 else (78 if H <= 5 else 79)
+name = "oracle_c5_step.npz" if H == 1 else ("oracle_c5_traj.npz" if H <= 5 else f"oracle_c5_h{H}.npz")
 w = synth.make_workload(N, D, A, H, B, seed=SEED)
 t0 = time.time()
 f = orc.Factors(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)

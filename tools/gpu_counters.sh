@@ -4,6 +4,8 @@
 # profiles/pmc_traffic.json under the key bench.py looks up.
 #   tools/gpu_counters.sh <tag> <key> <kernel-name-substring> <bench args...>
 #   e.g. tools/gpu_counters.sh r02_c2 c2:N200:B256 rollout_kernel --workload c2
+#        tools/gpu_counters.sh r03_c4 c4:N1000:B2048 "pair_tile_kernel*30,point_pass_kernel*30,step_params_kernel*30" --workload c4
+#   (a launch made of several kernels per horizon step: sum of average-per-dispatch x count)
 TAG=$1; KEY=$2; KSUB=$3; shift 3
 REPO=$PWD
 OUT=$REPO/gpurun_out
@@ -14,7 +16,8 @@ timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- $B
 DBS=""
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS" \
-           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA"; do
+           "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA" \
+           "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_IDX_ACTIVE"; do
   name=$(echo $grp | cut -d' ' -f1)
   timeout 300 rocprofv3 --pmc $grp -d $OUT/${TAG}_pmc_$name -o bench -- $B --steps 3 --warmup 1 > $OUT/${TAG}_pmc_$name.log 2>&1
   DBS="$DBS $OUT/${TAG}_pmc_$name/bench_results.db"
@@ -22,7 +25,8 @@ done
 cd $REPO
 python tools/rocpd_summary.py trace $OUT/${TAG}_trace/bench_results.db > $OUT/${TAG}_kernel_trace_stats.txt
 python tools/rocpd_summary.py pmc $DBS > $OUT/${TAG}_pmc.txt
-python tools/rocpd_summary.py json $KEY $KSUB $DBS | cut -c1-300
+BID=$(python -c "import gp_mpc_amd; print(gp_mpc_amd._lib.lib().gpmpc_build_id().decode())")
+python tools/rocpd_summary.py json --build-id=$BID $KEY "$KSUB" $DBS | cut -c1-300
 cp profiles/pmc_counters.json profiles/pmc_traffic.json $OUT/
 head -6 $OUT/${TAG}_kernel_trace_stats.txt | cut -c1-150
 # the sqlite outputs are tens of MB each: only the text summaries travel back (gpurun merges at most 64 MiB)

@@ -4,7 +4,8 @@
 
   python tools/rocpd_summary.py trace gpurun_out/prof_trace/bench_results.db
   python tools/rocpd_summary.py pmc   gpurun_out/prof_pmc_fetch/bench_results.db [...]
-  python tools/rocpd_summary.py json  c2:N200:B256 rollout_kernel <pmc dbs...>   (merge into profiles/pmc_*.json)
+  python tools/rocpd_summary.py json  [--build-id=ID] c2:N200:B256 rollout_kernel <pmc dbs...>   (merge into profiles/pmc_*.json;
+                                       "pair_tile_kernel*30,point_pass_kernel*30": a launch made of several kernels)
 """
 import sqlite3
 import sys
@@ -62,28 +63,42 @@ def pmc(paths):
             print(f"{kname[:70]:70s} {cname:22s} {len(vals):10d} {sum(vals)/len(vals):18.2f} {max(vals):16.2f}")
 
 
-def merge_json(key, kernel_substr, paths):
-    """Average per-dispatch counter values of the kernels whose name contains `kernel_substr` -> merged into
-    profiles/pmc_counters.json[key] (all counters) and profiles/pmc_traffic.json[key] (HBM bytes per launch =
-    (2 x FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE under-counts by 2, MI355X_MICROARCH.md HBM section)."""
+def merge_json(key, kernel_spec, paths, build_id=None):
+    """Per-launch counter values -> profiles/pmc_counters.json[key] (all counters) and profiles/pmc_traffic.json[key]
+    (bytes at the L2 -> fabric boundary per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB; the factor 2 on gfx950 is
+    calibrated on known byte counts: profiles/r03_fetch_size_calibration.txt).
+    kernel_spec: "substr" = average per dispatch of the kernels whose name contains it (one launch = one dispatch), or
+    "substrA*30,substrB*30" = sum over the listed kernels of (average per dispatch x count): a launch made of several
+    kernels per horizon step (the batch-major path).  build_id (gpmpc_build_id of the profiled library) is stored beside
+    the values: bench.py nulls counter-derived figures when the loaded library is another build."""
     import json
     import os
     root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
+    parts = []
+    for item in kernel_spec.split(","):
+        sub, _, mult = item.partition("*")
+        parts.append((sub, float(mult) if mult else 1.0))
     vals = {}
     for path in paths:
         cur = sqlite3.connect(path).cursor()
-        acc = defaultdict(lambda: defaultdict(float))
+        acc = defaultdict(lambda: defaultdict(lambda: defaultdict(float)))
         for kname, disp, cname, val in cur.execute(
                 "select kernel_name, dispatch_id, counter_name, value from counters_collection"):
-            if kernel_substr in kname:
-                acc[cname][disp] += val
-        for cname, d in acc.items():
-            # the largest launches only: warm-up / timing launches of other batch sizes share the kernel name
-            v = sorted(d.values())
-            top = [x for x in v if x >= 0.5 * v[-1]] if v[-1] > 0 else v
-            vals[cname] = sum(top) / len(top)
+            for sub, _ in parts:
+                if sub in kname:
+                    acc[sub][cname][disp] += val
+                    break
+        for sub, mult in parts:
+            for cname, d in acc[sub].items():
+                # the largest launches only: warm-up / timing launches of other batch sizes share the kernel name
+                v = sorted(d.values())
+                top = [x for x in v if x >= 0.5 * v[-1]] if v[-1] > 0 else v
+                vals[cname] = vals.get(cname, 0.0) + mult * sum(top) / len(top)
     if not vals:
-        raise SystemExit(f"no dispatch of a kernel matching {kernel_substr!r}")
+        raise SystemExit(f"no dispatch of a kernel matching {kernel_spec!r}")
+    vals["_kernels"] = kernel_spec
+    if build_id:
+        vals["_build_id"] = build_id
 
     def update(fname, value):
         fp = os.path.join(root, fname)
@@ -95,7 +110,8 @@ def merge_json(key, kernel_substr, paths):
         json.dump(cur, open(fp, "w"), indent=1, sort_keys=True)
     update("pmc_counters.json", vals)
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
-        update("pmc_traffic.json", int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024))
+        update("pmc_traffic.json", {"bytes": int((2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024), "build_id": build_id,
+                                    "kernels": kernel_spec})
     print(key, vals)
 
 
@@ -105,6 +121,10 @@ if __name__ == "__main__":
     elif sys.argv[1] == "list":
         dispatches(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "json":
-        merge_json(sys.argv[2], sys.argv[3], sys.argv[4:])
+        args = sys.argv[2:]
+        bid = None
+        if args[0].startswith("--build-id="):
+            bid = args.pop(0).split("=", 1)[1]
+        merge_json(args[0], args[1], args[2:], build_id=bid)
     else:
         pmc(sys.argv[2:])
