@@ -183,6 +183,7 @@ int launch_tile_state_init(Handle* h, const RolloutArgs& a, hipStream_t s);
 int launch_pair_tiles(Handle* h, const RolloutArgs& a, int t, hipStream_t s);
 // grad.hip
 int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t s);
+int launch_rollout_grad_wide(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t s);     // grad_wide.hip: 8 < D <= 16
 int launch_argmin_to(Handle* h, const double* J, int B, long long first, const double* actions, int HA, double* out_dev,
                      hipStream_t s);
 // prepare.hip

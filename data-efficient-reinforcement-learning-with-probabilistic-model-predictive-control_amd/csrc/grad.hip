@@ -65,9 +65,10 @@ int launch_moments_dp(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_
 int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t s) {
     const int N = a.N, D = a.D, A = a.A, E = a.E, H = a.H, B = a.B;
     const int NX = E - D, P = D * (D + 1) / 2;
+    if (D > 8) return launch_rollout_grad_wide(h, a, grad_out, s);
     int DP = 0;
     for (int v : {2, 3, 4, 6, 8}) if (D <= v) { DP = v; break; }
-    if (DP == 0 || NX > 6) { h->err = "gradient: supported for D <= 8 and A (+ time) <= 6"; return GPMPC_ERR_LIMIT; }
+    if (DP == 0 || NX > 6) { h->err = "gradient: supported for D <= 8 with A (+ time) <= 6, and for 8 < D <= 16"; return GPMPC_ERR_LIMIT; }
     const int NXP = NX <= 1 ? 1 : (NX <= 2 ? 2 : 6);
     const int RS = 2 + 2 * DP + NXP;
     const int NSP = 1 + DP + DP * (DP + 1) / 2 + NXP;

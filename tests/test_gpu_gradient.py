@@ -221,9 +221,58 @@ def test_config4_size_has_an_analytic_gradient(engine):
 
 
 def test_unsupported_shape_is_reported_not_approximated(engine):
+    """D <= 8 with more than 6 action (+ time) inputs is outside the gradient kernels: GPMPC_ERR_LIMIT, never an approximation
+    (the controller then differences the rollout).  State dimensions 9 .. 16 have their own path (round 3)."""
     import gp_mpc_amd
-    w = synth.make_workload(40, 12, 2, 2, 2, seed=2)
+    w = synth.make_workload(40, 3, 7, 2, 2, seed=2)
     _load_model(engine, w)
     with pytest.raises(gp_mpc_amd.GpmpcError) as e:
         engine.rollout_grad(w.actions, w.mu0, w.S0)
     assert e.value.code == -4
+
+
+@pytest.mark.parametrize("N,D,A,H,B,tm,s0", [(40, 9, 2, 3, 2, False, 1e-6), (70, 12, 3, 2, 2, False, 1e-5), (128, 16, 4, 3, 2, False, 1e-6),
+                                             (33, 16, 4, 2, 3, True, 1e-5), (50, 10, 1, 4, 2, False, 1e-3), (17, 16, 4, 2, 2, False, 1e-4),
+                                             (1, 9, 1, 2, 2, False, 1e-5)])
+def test_wide_state_gradient_matches_numpy_adjoint(engine, N, D, A, H, B, tm, s0):
+    """gpmpc_rollout_grad for 8 < D <= 16 (csrc/grad_wide_kernel.h: matrix-core moment pass with column sums + V = E^T u,
+    both orientations of an off-diagonal pair, pair-walking reverse sweep) vs oracle/adjoint.py, which is pinned against
+    torch autograd at D = 9 and D = 16 (tests/test_oracle_vs_golden.py) and against the reference's autograd goldens."""
+    w = synth.make_workload(N, D, A, H, B, include_time=tm, seed=N + D, s0=s0, time0=2.0 if tm else 0.0)
+    f = _load_model(engine, w)
+    out = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+    again = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+    assert np.array_equal(out["grad"].cpu().numpy(), again["grad"].cpu().numpy())             # fixed-order sums
+    for b in range(B):
+        J, g, *_ = adjoint.lcb_and_gradient(f, w.actions[b], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
+        assert abs(float(out["J"][b]) - J) < 1e-9 * abs(J)
+        assert rel_err(out["grad"][b].cpu().numpy(), g) < 1e-6
+
+
+def test_wide_state_gradient_with_state_constraints(engine):
+    w = synth.make_workload(60, 10, 2, 3, 2, seed=4, s0=1e-4)
+    smin, smax = np.full(10, -0.2), np.full(10, 1.3)
+    f = factors_of(w)
+    engine.set_factors(w.X, f.iK, f.beta, w.lengthscales, w.outputscales)
+    engine.set_cost(w.target, w.W, w.W_T, w.kappa, False, smin, smax)
+    out = engine.rollout_grad(w.actions, w.mu0, w.S0)
+    for b in range(2):
+        J, g, *_ = adjoint.lcb_and_gradient(f, w.actions[b], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, state_min=smin, state_max=smax)
+        assert abs(float(out["J"][b]) - J) < 1e-9 * abs(J)
+        assert rel_err(out["grad"][b].cpu().numpy(), g) < 1e-6
+
+
+def test_config5_full_size_gradient_against_oracle_fixture(engine):
+    """N = 4096, D = 16, A = 4, H = 2: K build + factorisation + forward + gradient on the GPU vs
+    tests/golden/oracle_c5_grad.npz (numpy adjoint, tools/gen_golden_c5_grad.py; 5 minutes on 8 cores)."""
+    g = load("oracle_c5_grad")
+    w = synth.make_workload(int(g["N"]), int(g["D"]), int(g["A"]), int(g["H"]), int(g["B"]), seed=int(g["seed"]))
+    assert np.allclose([w.X.sum(), w.Y.sum(), w.actions.sum()], g["x_checksum"], rtol=0, atol=1e-9)   # same inputs
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    engine.set_cost(w.target, w.W, w.W_T, w.kappa)
+    out = engine.rollout_grad(w.actions, w.mu0, w.S0)
+    assert abs(float(out["J"][0]) - float(g["J"])) < 1e-8 * abs(float(g["J"]))
+    e = rel_err(out["grad"][0].cpu().numpy(), g["grad"])
+    from helpers import record
+    record("config5_gradient[N4096,D16,H2]", grad=e, J=abs(float(out["J"][0]) - float(g["J"])) / abs(float(g["J"])))
+    assert e < 1e-6

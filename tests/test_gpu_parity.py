@@ -527,6 +527,30 @@ def test_config5_full_size_five_steps_against_oracle_fixture(engine):
     assert rel_err(out["J"].cpu().numpy(), g["J"]) < 1e-7
 
 
+def test_config5_full_horizon_against_oracle_fixture(engine):
+    """BASELINE configs[4] at its REAL horizon: N = 4096, D = 16, A = 4, H = 50, one candidate, vs
+    tests/golden/oracle_c5_h50.npz (CPU oracle, `tools/gen_golden_c5.py --steps 50 --candidates 1`, 39 minutes on 8 cores;
+    the reference formulation cannot run this size).  VERDICT r2: the H = 50 recurrence at D = 16 was extrapolated from 5
+    steps; here every one of the 50 steps is compared and the per-step errors are recorded."""
+    g = load("oracle_c5_h50")
+    H = int(g["H"])
+    w = synth.make_workload(int(g["N"]), int(g["D"]), int(g["A"]), H, int(g["B"]), seed=int(g["seed"]))
+    assert np.allclose([w.X.sum(), w.Y.sum(), w.actions.sum()], g["x_checksum"], rtol=0, atol=1e-9)   # same inputs
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    _set_cost(engine, w)
+    out = engine.rollout(w.actions, w.mu0, w.S0)
+    mu, Sig = out["mu"].cpu().numpy(), out["Sig"].cpu().numpy()
+    per_step = [rel_err(Sig[:, t], g["Sig"][:, t]) for t in range(1, H + 1)]
+    per_step_mu = [rel_err(mu[:, t], g["mu"][:, t]) for t in range(1, H + 1)]
+    record("config5_full_horizon", mu=rel_err(mu, g["mu"]), Sig=rel_err(Sig, g["Sig"]), J=rel_err(out["J"].cpu().numpy(), g["J"]),
+           Sig_worst_step=float(np.argmax(per_step) + 1), Sig_step1=per_step[0], Sig_step10=per_step[9], Sig_step25=per_step[24],
+           Sig_step50=per_step[49], mu_step50=per_step_mu[49])
+    assert max(per_step_mu) < 1e-8
+    assert max(per_step) < 1e-5
+    assert rel_err(out["cost_var"].cpu().numpy(), g["cost_var"]) < 1e-5
+    assert rel_err(out["J"].cpu().numpy(), g["J"]) < 1e-7
+
+
 def test_random_shapes_against_oracle(engine):
     """Seeded fuzz over shapes (N not a multiple of 4 / 16 / 64, single points, padded D, time input, small and
     large input variance): layout, padding and chunking edge cases of both kernels."""
