@@ -86,6 +86,9 @@ int gpmpc_destroy(gpmpc_t* g) {
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);
     if (h->septab) (void)hipFree(h->septab);
+    if (h->side_stream) (void)hipStreamDestroy(h->side_stream);
+    if (h->ev_params) (void)hipEventDestroy(h->ev_params);
+    if (h->ev_points) (void)hipEventDestroy(h->ev_points);
     delete g;
     return GPMPC_OK;
 }
@@ -115,6 +118,7 @@ int gpmpc_set_option(gpmpc_t* g, const char* name, long long value) {
     else if (!strcmp(name, "refresh_every")) h->opt_refresh_every = (int)value;
     else if (!strcmp(name, "pair_tiles")) h->opt_pair_tiles = (int)value;
     else if (!strcmp(name, "tile_chunk")) h->opt_tile_chunk = (int)value;
+    else if (!strcmp(name, "tile_overlap")) h->opt_tile_overlap = (int)value;
     else return bad(g, "unknown option");
     return GPMPC_OK;
 }

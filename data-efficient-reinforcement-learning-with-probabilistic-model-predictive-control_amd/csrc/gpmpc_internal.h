@@ -105,6 +105,8 @@ struct Handle {
     struct SepTable* septab = nullptr;   // monomial bands of the separable evaluation (point_pass_kernel.h), device copy
     Buf sepw;                            // their weights 1 / alpha!
     int septab_D = -1, sep_ks = 0, sep_cmax = 0;
+    hipStream_t side_stream = nullptr;   // batch-major path: the point pass of a step runs beside the tile kernel
+    hipEvent_t ev_params = nullptr, ev_points = nullptr;
     // incremental factorisation: what the cached factors were computed from, and border-update scratch
     Buf Xc, Yc;   // (N, E), (N, D) copies of the memory points of the last prepare
     Buf hyp;      // lengthscales (D*E) | outputscales (D) | noises (D) of the last prepare
@@ -147,6 +149,9 @@ struct Handle {
     int opt_outer_block = 1;         // large N: outer panels of 128 columns + LDS-tiled products; 0: the 32-wide path only (A/B, tests)
     int opt_pair_tiles = 0;          // batch-major pairwise pass of the diagonal pairs: 0 auto (by N, D, B), 1 always (D <= 4), 2 never
     int opt_tile_chunk = 0;          // candidates per workgroup of the batch-major pass (0: chosen from the batch)
+    int opt_tile_overlap = 0;        // batch-major path: 1 = point pass on a side stream, concurrent with the tile kernel.  Measured at config 4
+                                     // (round 3): 77.9 ms either way -- the two kernels do overlap (rocprofv3: 2.58 ms and 1.41 ms side by side instead
+                                     // of 2.14 + 0.49 ms) but the fp64 pipe is already at the ~76 % of its nominal rate an FMA loop reaches
     int last_rollout_path = 0;       // what the last rollout launch used: 0 fused-horizon kernel, 1 streaming kernel, 2 batch-major tiles
     int opt_fused_prepare = 1;       // N <= 256: the whole factorisation in one launch (prepare_small.hip); 0: panel path (A/B, tests)
     int last_prepare_mode = 0;       // 0 full, 1 border update(s), 2 unchanged (cache hit)

@@ -379,7 +379,7 @@ __host__ __device__ inline WideSweepLayout make_wide_sweep_layout(int D, int A, 
 template <int DP>
 __global__ __launch_bounds__(kWideSweepThreads) void wide_adjoint_sweep_kernel(const WideArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    constexpr int NT = kWideSweepThreads, NW = NT / 64;
+    constexpr int NT = kWideSweepThreads;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c = blockIdx.x;
     const int N = p.N, D = p.D, A = p.A, E = p.E, H = p.H;
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(kWideSweepThreads) void wide_adjoint_sweep_kernel(c
     double* s_mbar = smem + L.mbar; double* s_mubar = smem + L.mubar;
     double* s_gmu = smem + L.gmu; double* s_gSig = smem + L.gSig; double* s_gu = smem + L.gu; double* s_ctmp = smem + L.ctmp;
     double* s_aug = smem + L.aug; double* s_Ai = smem + L.Ai; double* s_small = smem + L.small; double* s_G2 = smem + L.G2;
-    double* s_chunk = smem + L.chunk; double* s_red = smem + L.red; double* s_pw = smem + L.pw; double* s_pacc = smem + L.pacc;
+    double* s_chunk = smem + L.chunk; double* s_pw = smem + L.pw; double* s_pacc = smem + L.pacc;
     double* s_s1 = s_small; double* s_y = s_small + D; double* s_vb = s_small + 2 * D; double* s_s1b = s_small + 3 * D;
     double* s_G1 = s_small + 4 * D; double* s_AiG1 = s_small + 5 * D; double* s_sc = s_small + 8 * D;   // scalars: c, s0, cb, s0b
     const int CW = D + NX + 2;                                    // words per point of the chunk

@@ -103,6 +103,7 @@ static void step_geometry(const Handle* h, const RolloutArgs& a, StepArgs& t) {
     t.CS = t.off_pair + P * t.PRP;
     t.ksep = h->sep_ks;
     t.mom_stride = (h->sep_cmax + 1) & ~1;
+    t.PO = (P + a.D * (a.D + 1) + 1) & ~1;
     // Candidates per tile workgroup.  All workgroups cost the same (cch candidates + a prologue worth ~8: the tile's 128 KiB,
     // the points' inputs), 2 are resident per CU, so the launch takes ceil(workgroups / slots) rounds: pick the chunk that
     // minimises rounds x (cch + 8) -- a last round that is 16 % full cost config 4 3 % (tile_chunk 72 vs 64: 80.0 vs 78.0 ms).
@@ -140,12 +141,18 @@ int tile_workspace(Handle* h, RolloutArgs& a) {
     if (rc) return rc;
     StepArgs t{};
     step_geometry(h, a, t);
-    const size_t nrec = (size_t)a.B * t.CS, npart = (size_t)a.B * a.D * t.ntiles, nflag = ((size_t)a.B + 1) / 2;
-    rc = grow(h, h->tilews, nrec + npart + nflag);
+    const size_t nrec = (size_t)a.B * t.CS, npart = (size_t)a.B * a.D * t.ntiles, nflag = ((size_t)a.B + 1) / 2, npo = (size_t)a.B * t.PO;
+    rc = grow(h, h->tilews, nrec + npart + nflag + npo);
     if (rc) return rc;
     a.tile_part = h->tilews.p + nrec;
     a.ntiles = t.ntiles;
     a.slow = reinterpret_cast<const int*>(h->tilews.p + nrec + npart);
+    if (!h->side_stream) {
+        // not blocking against the NULL stream: the dependencies between the two streams are the two events below
+        GPMPC_HIP_CHECK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        GPMPC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
+        GPMPC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_points, hipEventDisableTiming));
+    }
     return GPMPC_OK;
 }
 
@@ -156,11 +163,33 @@ int launch_tile_state_init(Handle* h, const RolloutArgs& a, hipStream_t s) {
     return GPMPC_OK;
 }
 
+// One horizon step: all D x D algebra (params), the per-candidate point pass, the N x N tiles of the diagonal pairs, then the
+// D x D end of the step.  Option "tile_overlap" runs the point pass on a side stream beside the tile kernel (one workgroup of
+// each fits a CU together: registers and LDS).  They do run concurrently, but the step takes the same time (config 4: 77.9 ms per
+// batch both ways): the tile kernel already keeps the fp64 pipe at 77 % of its nominal issue rate (2.27 GHz measured), which is
+// what an 8-chain FMA loop reaches on this part (profiles/fma_loop_microbench.txt: 58.6 of 78.6 TFLOP/s), so the default is one stream.
 template <int DP>
 static int launch_step_dp(Handle* h, const StepArgs& t, hipStream_t s) {
     const int P = t.D * (t.D + 1) / 2;
+    const bool overlap = h->opt_tile_overlap != 0;
+    hipStream_t sp = overlap ? h->side_stream : s;
     hipLaunchKernelGGL(step_params_kernel<DP>, dim3((t.B * (t.D + P) + 255) / 256), dim3(256), 0, s, t);
     GPMPC_HIP_CHECK(h, hipGetLastError());
+    if (overlap) {
+        GPMPC_HIP_CHECK(h, hipEventRecord(h->ev_params, s));
+        GPMPC_HIP_CHECK(h, hipStreamWaitEvent(sp, h->ev_params, 0));
+    }
+    {
+        auto kern = point_pass_kernel<DP>;
+        int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+        if (rc) return rc;
+        const PointLayout L = make_point_layout(t.N, t.D, t.E, t.CS, t.mom_stride);
+        const size_t lds = (size_t)L.total * sizeof(double);
+        if (lds > (size_t)h->lds_limit) { h->err = "point pass: LDS layout too large"; return GPMPC_ERR_LIMIT; }
+        hipLaunchKernelGGL(kern, dim3(t.B), dim3(256), lds, sp, t);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+    }
+    if (overlap) GPMPC_HIP_CHECK(h, hipEventRecord(h->ev_points, sp));
     {
         auto kern = pair_tile_kernel<DP>;
         int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
@@ -173,16 +202,9 @@ static int launch_step_dp(Handle* h, const StepArgs& t, hipStream_t s) {
         hipLaunchKernelGGL(kern, dim3(8 * per_xcd * t.nchunk), dim3(kTileWaves * 64), lds, s, t);
         GPMPC_HIP_CHECK(h, hipGetLastError());
     }
-    {
-        auto kern = point_pass_kernel<DP>;
-        int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
-        if (rc) return rc;
-        const PointLayout L = make_point_layout(t.N, t.D, t.E, t.CS, t.mom_stride);
-        const size_t lds = (size_t)L.total * sizeof(double);
-        if (lds > (size_t)h->lds_limit) { h->err = "point pass: LDS layout too large"; return GPMPC_ERR_LIMIT; }
-        hipLaunchKernelGGL(kern, dim3(t.B), dim3(256), lds, s, t);
-        GPMPC_HIP_CHECK(h, hipGetLastError());
-    }
+    if (overlap) GPMPC_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_points, 0));
+    hipLaunchKernelGGL(step_combine_kernel<DP>, dim3(t.B), dim3(64), 0, s, t);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
     return GPMPC_OK;
 }
 
@@ -196,6 +218,7 @@ int launch_pair_tiles(Handle* h, const RolloutArgs& a, int step, hipStream_t s) 
     t.crec = h->tilews.p;
     t.part = const_cast<double*>(a.tile_part);
     t.slow = const_cast<int*>(a.slow);
+    t.pout = h->tilews.p + (size_t)a.B * t.CS + (size_t)a.B * a.D * t.ntiles + ((size_t)a.B + 1) / 2;
     t.septab = h->septab; t.sepw = h->sepw.p;
     t.N = a.N; t.D = a.D; t.A = a.A; t.E = a.E; t.H = a.H; t.B = a.B; t.t = step;
     t.include_time = a.include_time; t.time0 = a.time0;

@@ -53,6 +53,7 @@ struct StepArgs {
     double* Sig;            // (B, H + 1, D, D)
     double* crec;           // (B, CS) step record of a candidate: input mean | mean problems | pair problems
     double* part;           // (B, D, ntiles) partial sums of the diagonal pairs (pair_tile_kernel)
+    double* pout;           // (B, PO) what the point pass hands to step_combine_kernel: off-diagonal pair totals (P slots) | mean sums D (D + 1)
     int* slow;              // (B) t + 1 when the candidate's step t goes to the element-wise kernel
     const SepTable* septab;
     const double* sepw;     // 1 / alpha! in band order, per degree
@@ -65,6 +66,7 @@ struct StepArgs {
     int force_path;         // 1: direct exp for every pair, 2: never separable (tests)
     int ksep;               // highest separable degree (septab->ks)
     int mom_stride;         // doubles per (pair, side) moment array in LDS
+    int PO;                 // doubles per candidate in pout
 };
 
 __host__ __device__ inline int pair_index(int a, int b, int D) { return a * D - (a * (a - 1)) / 2 + (b - a); }
@@ -381,13 +383,7 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
     const SepTable* s_tab = reinterpret_cast<const SepTable*>(smem + L.tab);
     double* c_ils2 = smem + L.ils2;
     double* c_logvar = smem + L.logvar;
-    double* c_var = smem + L.var;
-    double* s_mu = smem + L.mu;
-    double* s_Sig = smem + L.Sig;
     double* s_s1 = smem + L.s1;
-    double* s_M = smem + L.M;
-    double* s_Vs = smem + L.Vs;
-    double* s_Sp = smem + L.Sp;
     double* s_mom = smem + L.mom;
     double* s_act = smem + L.act;
     const int NA = rnd2(N);
@@ -404,10 +400,7 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
         for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
         for (int i = tid; i < D; i += NT) {
             c_logvar[i] = p.logvar[i];
-            c_var[i] = p.var[i];
-            s_mu[i] = p.mu[((size_t)c * (p.H + 1) + p.t) * D + i];
         }
-        for (int i = tid; i < D * D; i += NT) s_Sig[i] = p.Sig[((size_t)c * (p.H + 1) + p.t) * D * D + i];
     }
     __syncthreads();
     // action / time part of every log-factor: sum_{e >= D} (x_e - m_e)^2 / l_ce^2, once per (output, point) instead of once per task
@@ -586,48 +579,73 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
     }
     __syncthreads();
 
-    // ---- pair totals, M, V -----------------------------------------------------------------------------------------------
+    // ---- totals of the off-diagonal pairs (x 1 / sqrt(det R)) and the mean sums -> HBM for step_combine_kernel ---------
+    {
+        double* po = p.pout + (size_t)c * p.PO;
+        int q = 0;
+        for (int a = 0; a < D; ++a)
+            for (int b = a; b < D; ++b, ++q) {
+                if (a == b || (q & (NW - 1)) != wave) continue;
+                const double* pr = s_rec + p.off_pair + q * p.PRP;
+                const int K = (int)pr[DP * DP + 1] & 63;
+                const int C = s_tab->total[K];
+                const double* wgt = p.sepw + s_tab->woff[K];
+                const double* Gm = s_mom + (size_t)((q - a - 1) * 2) * p.mom_stride;
+                const double* Wm = Gm + p.mom_stride;
+                double v = 0.0;
+                for (int n = lane; n < C; n += 64) v = fma(Gm[n] * Wm[n], wgt[n], v);
+                v = wave_sum(v);
+                if (lane == 0) po[q] = v * pr[DP * DP];
+            }
+        const int P = D * (D + 1) / 2;
+        for (int i = tid; i < D * (D + 1); i += NT) po[P + i] = s_s1[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The D x D end of a step, one wavefront per candidate, once the tiles (diagonal pairs) and the point pass (mean sums,
+// off-diagonal pairs) of the step are there: M, V, S, Sigma_{t+1} = S + Sigma + C + C^T, mu_{t+1} = mu + M
+// (gp_model.py:105-108, 152-153, 176-178).  Candidates of the element-wise kernel are skipped.
+template <int DP>
+__global__ __launch_bounds__(64) void step_combine_kernel(const StepArgs p) {
+    __shared__ double s_Sp[DP * (DP + 1) / 2], s_M[DP], s_Vs[DP * DP], s_Sig[DP * DP];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    if (p.slow[c] == p.t + 1) return;
+    const int D = p.D;
+    const int P = D * (D + 1) / 2;
+    const double* rec = p.crec + (size_t)c * p.CS;
+    const double* po = p.pout + (size_t)c * p.PO;
+    const double* s1 = po + P;
+    for (int i = lane; i < D * D; i += 64) s_Sig[i] = p.Sig[((size_t)c * (p.H + 1) + p.t) * D * D + i];
     {
         int q = 0;
         for (int a = 0; a < D; ++a)
             for (int b = a; b < D; ++b, ++q) {
-                const int owner = q & (NW - 1);
-                if (owner != wave) continue;
-                const double* pr = s_rec + p.off_pair + q * p.PRP;
                 if (a == b) {
-                    // sum of the tiles' partial sums (i <= j only: factor 2)
+                    // sum of the tiles' partial sums in a fixed order (i <= j only: factor 2)
                     const double* tp = p.part + ((size_t)c * D + a) * p.ntiles;
                     double v = 0.0;
                     for (int k = lane; k < p.ntiles; k += 64) v += tp[k];
                     v = wave_sum(v);
-                    if (lane == 0) s_Sp[q] = 2.0 * v * pr[DP * DP];
-                } else {
-                    const int K = (int)pr[DP * DP + 1] & 63;
-                    const int C = s_tab->total[K];
-                    const double* wgt = p.sepw + s_tab->woff[K];
-                    const double* Gm = s_mom + (size_t)((q - a - 1) * 2) * p.mom_stride;
-                    const double* Wm = Gm + p.mom_stride;
-                    double v = 0.0;
-                    for (int n = lane; n < C; n += 64) v = fma(Gm[n] * Wm[n], wgt[n], v);
-                    v = wave_sum(v);
-                    if (lane == 0) s_Sp[q] = v * pr[DP * DP];
+                    if (lane == 0) s_Sp[q] = 2.0 * v * rec[p.off_pair + q * p.PRP + DP * DP];
+                } else if (lane == 0) {
+                    s_Sp[q] = po[q];
                 }
             }
-        if (tid < D) s_M[tid] = s_rec[p.off_mean + tid * p.PR + DP * DP] * s_s1[tid * (D + 1)];                      // M_a (:152)
-        for (int idx = tid; idx < D * D; idx += NT) {
-            const int k = idx / D, a = idx - k * D;
-            const double* Ai = s_rec + p.off_mean + a * p.PR;
-            double s = 0.0;
-            for (int j = 0; j < D; ++j) s = fma(Ai[k * DP + j], s_s1[a * (D + 1) + 1 + j], s);
-            s_Vs[idx] = Ai[DP * DP] * s;                                                                        // state rows of V (:153)
-        }
     }
-    __syncthreads();
-    // ---- state update (gp_model.py:105-108, 177-178) -------------------------------------------------------------------------
-    for (int idx = tid; idx < D * D; idx += NT) {
+    if (lane < D) s_M[lane] = rec[p.off_mean + lane * p.PR + DP * DP] * s1[lane * (D + 1)];                           // M_a (:152)
+    for (int idx = lane; idx < D * D; idx += 64) {
+        const int k = idx / D, a = idx - k * D;
+        const double* Ai = rec + p.off_mean + a * p.PR;
+        double s = 0.0;
+        for (int j = 0; j < D; ++j) s = fma(Ai[k * DP + j], s1[a * (D + 1) + 1 + j], s);
+        s_Vs[idx] = Ai[DP * DP] * s;                                                                              // state rows of V (:153)
+    }
+    wave_lds_sync();
+    for (int idx = lane; idx < D * D; idx += 64) {
         const int i = idx / D, j = idx - i * D;
         const int a = i < j ? i : j, b = i < j ? j : i;
-        const double S = s_Sp[pair_index(a, b, D)] - s_M[i] * s_M[j] + (i == j ? c_var[i] : 0.0);
+        const double S = s_Sp[pair_index(a, b, D)] - s_M[i] * s_M[j] + (i == j ? p.var[i] : 0.0);
         double cij = 0.0, cji = 0.0;
         for (int k = 0; k < D; ++k) {
             cij = fma(s_Sig[i * D + k], s_Vs[k * D + j], cij);
@@ -635,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
         }
         p.Sig[((size_t)c * (p.H + 1) + (p.t + 1)) * D * D + idx] = S + s_Sig[idx] + (cij + cji);
     }
-    for (int i = tid; i < D; i += NT) p.mu[((size_t)c * (p.H + 1) + (p.t + 1)) * D + i] = s_mu[i] + s_M[i];
+    if (lane < D) p.mu[((size_t)c * (p.H + 1) + (p.t + 1)) * D + lane] = p.mu[((size_t)c * (p.H + 1) + p.t) * D + lane] + s_M[lane];
 }
 
 }  // namespace gpmpc_hip
