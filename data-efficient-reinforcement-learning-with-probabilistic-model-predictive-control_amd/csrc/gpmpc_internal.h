@@ -136,6 +136,8 @@ struct Handle {
     int opt_force_sep = 0;
     int opt_grad_stream = 0;         // 1: always the streaming moment pass of the gradient (tests); otherwise only when N needs it
     int opt_grad_cols = 0;           // 2: two columns per lane in the gradient's moment pass (A/B)
+    int opt_grad_sep = 1;            // off-diagonal pairs of the gradient's moment pass in separable form on the matrix cores:
+                                     // 0 never (element-wise), 1 from N = 256 on (measured crossover), 2 always (tests, A/B)
     int opt_exact_dim = 0;           // 2: forbid the compile-time-D kernel instantiation (A/B)
     int opt_cols_per_lane = 0;       // 0 auto, 1 / 2: columns per lane in the pairwise pass of the rollout kernel
     int opt_incremental = 1;         // reuse / border-update the cached factors when the memory only grew

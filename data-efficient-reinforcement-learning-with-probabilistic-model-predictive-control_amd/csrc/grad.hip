@@ -1,5 +1,6 @@
 // grad.hip -- host-side dispatch of the analytic-gradient kernels (grad_kernels.h).
 #include "grad_stream_kernel.h"
+#include "grad_sep_kernel.h"
 #include <cstring>
 
 namespace gpmpc_hip {
@@ -121,12 +122,14 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     }
     auto magic = [](unsigned d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + d - 1) / d); };
 
-    // workspace: moments, mean sums, cost variances (when the caller does not keep them)
+    // workspace: moments, mean sums, cost variances (when the caller does not keep them), flags of the separable pass
     const size_t n_mom = (size_t)B * H * P * NSP, n_ms = (size_t)B * H * D * mean_moment_count(D, NX), n_cv = (size_t)B * (H + 1);
-    int rc = grow(h, h->gradws, n_mom + n_ms + n_cv);
+    const size_t n_flag = ((size_t)B * H * P + 1) / 2;
+    int rc = grow(h, h->gradws, n_mom + n_ms + n_cv + n_flag);
     if (rc) return rc;
     g.mom = h->gradws.p;
     g.msum = g.mom + n_mom;
+    int* sep_flags = reinterpret_cast<int*>(g.msum + n_ms + n_cv);
     if (!a.cv_out) a.cv_out = g.msum + n_ms;
 
     rc = launch_rollout(h, a, s);            // forward: trajectory, costs, J
@@ -143,6 +146,50 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     g.magic_N = magic((unsigned)NCU); g.magic_wpp = magic((unsigned)wpp);
 
     g.xrange = h->xrange.p; g.force_path = h->opt_force_path;
+    // Off-diagonal pairs in separable form on the matrix cores (grad_sep_kernel.h) where the Taylor degree allows; the
+    // element-wise kernels below skip the pairs it wrote.  Monomial tables: those of the forward kernel (ensure_monomials).
+    g.sepdone = nullptr;
+    // Measured (round 3, rocprofv3): config 2 (N = 200) 0.78 ms for this kernel + 1.25 ms element-wise diagonal pairs = the 2.0 ms the
+    // element-wise pass takes alone (its per-(candidate, step) set-up does not shrink with the pairs); config 4 (N = 1000) 128 + 495 ms
+    // against 1145 ms.  Hence from N = 256 on unless forced (option "grad_separable": 0 never, 1 auto, 2 always).
+    if (h->opt_grad_sep != 0 && (N >= 256 || h->opt_grad_sep == 2) && D >= 2 && D <= 4 && h->mono_D == D && h->mono_CM > 0 &&
+        h->opt_force_path == 0) {
+        int kmax = 0;
+        for (int k = 1; k <= h->sep_kmax && k <= kMaxTaylor; ++k)
+            if (h->mono_cum[k] <= 16 * kSepGradBlocks) kmax = k;
+        const int nWt = 1 + D + D * (D + 1) / 2 + NX;
+        if (kmax > 0 && nWt <= 32) {
+            SepGradArgs sg;
+            memset(&sg, 0, sizeof sg);
+            sg.Xt = a.Xt; sg.beta = a.beta; sg.ils2 = a.ils2; sg.logvar = a.logvar; sg.xrange = h->xrange.p; sg.actions = a.actions;
+            sg.mu = a.mu_out; sg.Sig = a.Sig_out; sg.mono_exp = h->mono_exp; sg.mono_w = h->mono_w.p;
+            sg.mom = g.mom; sg.done = sep_flags;
+            for (int k = 0; k < 16; ++k) sg.mono_cum[k] = h->mono_cum[k];
+            sg.N = N; sg.D = D; sg.A = A; sg.E = E; sg.H = H; sg.B = B; sg.include_time = a.include_time; sg.time0 = a.time0;
+            sg.NSP = NSP; sg.NXP = NXP; sg.kmax = kmax; sg.force_path = h->opt_force_path;
+            const int NA = (nWt + 15) / 16;
+            sg.PS = sep_grad_point_words(D, NX, kmax);
+            const int mat_words = nWt * 16 * kSepGradBlocks;          // moment matrix of a (pair, side): weightings x monomial slots
+            sg.wave_words = 64 * sg.PS > mat_words ? 64 * sg.PS : mat_words;
+            const int Poff = P - D;
+            const size_t lds = ((size_t)rnd2(E) + rnd2(D * E) + rnd2((Poff > 0 ? Poff : 1) * DP * DP) + 64 + 8 + 16 * kSepGradBlocks
+                                + 8 * kSepGradBlocks + 8 + (size_t)sep_grad_waves(DP) * sg.wave_words) * sizeof(double);
+            if (lds <= (size_t)h->lds_limit) {
+                auto launch = [&](auto kern) -> int {
+                    int r2 = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+                    if (r2) return r2;
+                    hipLaunchKernelGGL(kern, dim3(H, B), dim3(64 * sep_grad_waves(DP)), lds, s, sg);
+                    GPMPC_HIP_CHECK(h, hipGetLastError());
+                    return GPMPC_OK;
+                };
+                if (DP == 2) rc = launch(sep_grad_moments_kernel<2, 1>);
+                else if (DP == 3) rc = launch(sep_grad_moments_kernel<3, 1>);
+                else rc = (NA == 1) ? launch(sep_grad_moments_kernel<4, 1>) : launch(sep_grad_moments_kernel<4, 2>);
+                if (rc) return rc;
+                g.sepdone = sep_flags;
+            }
+        }
+    }
     if (stream) {
         switch (DP) {
             case 2:  rc = launch_moments_stream_dp<2>(h, g, gs_lds, s); break;

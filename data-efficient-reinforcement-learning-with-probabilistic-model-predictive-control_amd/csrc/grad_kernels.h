@@ -47,6 +47,7 @@ struct GradArgs {
     int cols;               // columns per lane in the pairwise pass (1 or 2)
     int G, CH, RC, wpp;
     int gz;                 // workgroups per (candidate, step) in the moment pass (pair groups spread over blockIdx.z)
+    const int* sepdone;     // (B, H, P) or NULL: 1 = the pair's moments were written by sep_grad_moments_kernel (skip it here)
     unsigned magic_N, magic_wpp;
 };
 
@@ -95,7 +96,7 @@ __host__ __device__ inline MomLayout make_mom_layout(int N, int D, int E, int G,
     L.m = o;        o += rnd2(E);
     L.Sig = o;      o += rnd2(D * D);
     L.aug = o;      o += (D + G) * 2 * D * D;
-    L.ints = o;     o += rnd2((2 * P + G + 2 + ((N + 3) / 4 + 2) + 1) / 2);      // pa[P], pb[P], K[G], counter, tri[RC + 1]
+    L.ints = o;     o += rnd2((3 * P + G + 4 + ((N + 3) / 4 + 2) + 1) / 2);      // pa[P], pb[P], K[G], counter, tri[RC + 1], pq[P], pn
     L.nu = o;       o += rnd2(D * N);
     L.xe = o;       o += rnd2((E - D) * N);
     L.lb = o;       o += rnd2(D * N);
@@ -135,6 +136,8 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
     int* s_K = s_pb + P;                 // per pair of the group: Taylor degree of exp(g.w), 0 = direct exp
     int* s_counter = s_K + G;
     int* s_tri = s_counter + 1;          // diagonal pairs: column units of row chunks < r that can hold an element i <= j
+    int* s_pq = s_tri + ((N + 3) / 4 + 2);      // pair index (a <= b enumeration) of every pair this kernel works on
+    int* s_pn = s_pq + P;                       // their number: all P, or those the separable kernel left (grad_sep_kernel.h)
     double* c_xr = smem + L.c_xr;
     double* a_nu = smem + L.nu;
     double* a_xe = smem + L.xe;
@@ -161,9 +164,13 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
         a_rows[((size_t)gq * NR + N) * RS + k] = 0.0;                      // zero padding rows
     }
     if (tid == 0) {
-        int q = 0;
+        int q = 0, n = 0;
         for (int a = 0; a < D; ++a)
-            for (int b = a; b < D; ++b) { s_pa[q] = a; s_pb[q] = b; ++q; }
+            for (int b = a; b < D; ++b, ++q) {
+                if (p.sepdone && p.sepdone[((size_t)c * H + t) * P + q]) continue;
+                s_pa[n] = a; s_pb[n] = b; s_pq[n] = q; ++n;
+            }
+        *s_pn = n;
         // a column unit (NC adjacent columns) is useful for row chunk r of a diagonal pair if its last column >= r CH
         int run = 0;
         for (int r = 0; r <= p.RC; ++r) {
@@ -252,8 +259,9 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
 
     // small batches: the pair groups of one (candidate, step) are spread over gridDim.z workgroups (each repeats the
     // per-point set-up; the mean moments are written by z = 0)
-    for (int q0 = (int)blockIdx.z * G; q0 < P; q0 += G * (int)gridDim.z) {
-        const int Gc = (P - q0 < G) ? (P - q0) : G;
+    const int Pn = *s_pn;
+    for (int q0 = (int)blockIdx.z * G; q0 < Pn; q0 += G * (int)gridDim.z) {
+        const int Gc = (Pn - q0 < G) ? (Pn - q0) : G;
         if (tid < Gc) {
             const int gq = tid;
             const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
@@ -534,7 +542,7 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
             double v = 0.0;
             for (int s = lane; s < wpp; s += 64) v += s_part[((size_t)gq * wpp + s) * NSP + k];
             v = wave_sum(v);
-            if (lane == 0) p.mom[((((size_t)c * H + t) * P) + q0 + gq) * NSP + k] = v;
+            if (lane == 0) p.mom[((((size_t)c * H + t) * P) + s_pq[q0 + gq]) * NSP + k] = v;
         }
         __syncthreads();
         GPMPC_GTRACE(6);

@@ -1,0 +1,328 @@
+// grad_sep_kernel.h -- moments of the OFF-DIAGONAL output pairs for the analytic gradient, in separable form on the fp64
+// matrix cores (gfx950 / MI355X; D <= 4).
+//
+// The reverse sweep needs, per output pair (a, b) and horizon step, the moments of p_ij = u_i + w_j under the pairwise
+// weights E_ij (grad_kernels.h):  W = sum E,  P1 = sum E p,  P2 = sum E p p^T,  Pe = sum E (nu_ix / l_ax^2 + nu_jx / l_bx^2).
+// pair_moments_kernel evaluates them element by element -- N^2 elements x ~32 instructions per pair -- and the three
+// (config 2) or six (config 4) off-diagonal pairs are two thirds / three quarters of that work.  For a != b the weights
+// factor,  E_ij = ra_i rb_j exp(g_i . w_j),  and with the Taylor polynomial of exp(g . w) the forward kernels already use
+// (degree K from the data range, truncation below fp64 rounding)  exp(g . w) = sum_|alpha|<=K g^alpha w^alpha / alpha!,
+// so every moment is a sum over monomials of (row-side moment) x (column-side moment):
+//     W  = sum_alpha c_alpha G[1][alpha] H[1][alpha]                                   c_alpha = 1 / alpha!
+//     P1 = sum_alpha c_alpha (G[u][alpha] H[1][alpha] + G[1][alpha] H[w][alpha])
+//     P2 = sum_alpha c_alpha (G[u u^T] H[1] + G[u] H[w]^T + H[w] G[u]^T + G[1] H[w w^T])
+//     Pe = sum_alpha c_alpha (G[nu_x] H[1] / l_ax^2 + G[1] H[nu_x] / l_bx^2)
+//   G[f][alpha] = sum_i ra_i f(i) g_i^alpha  over the weightings f in {1, u_d, u_d u_e, nu_x},  H likewise with rb_j, w_j.
+// That is O(N (#weightings x #monomials)) per pair and side instead of O(N^2), and G = F^T Phi is a genuine matrix product
+// with the POINTS as the inner dimension: 16 weightings x 16 monomials per v_mfma_f64_16x16x4_f64, four points per
+// instruction, no cross-lane reduction anywhere (the element-wise form of this idea needed 4 x 16 accumulators per lane
+// and spilled: DESIGN.md section 8 item 3).  A wavefront owns one (pair, side): per 64 points it writes wt_i, the
+// weighting vector (1, u, nu_x) and the powers x_d^e of the monomial variables to LDS (lane = point), then 16 k-steps of
+// MFMAs whose operands every lane assembles from those tables with its own (weighting | monomial) selectors.
+//
+// Pairs whose degree is outside the table (direct-exp form, K beyond kSepGradBlocks x 16 monomials) are left to the
+// element-wise kernels: `done[(c, t, pair)]` says which pairs this kernel wrote.
+#pragma once
+#include "rollout_stream_kernel.h"
+#include "grad_kernels.h"
+
+namespace gpmpc_hip {
+
+// wavefronts per (candidate, step): two pairs x two sides at a time (six at D = 3 -- all tasks in one round -- measured slower:
+// 1.11 vs 0.75 ms at config 2, 77 KB of LDS per workgroup); twelve regions of moment matrices at D = 4 would not fit the LDS
+__host__ __device__ constexpr int sep_grad_waves(int DP) { return DP == 2 ? 2 : 4; }
+constexpr int kSepGradBlocks = 5;            // monomial blocks of 16 per (pair, side): up to 80 monomials
+
+struct SepGradArgs {
+    const double* Xt;       // (E, N)
+    const double* beta;     // (D, N)
+    const double* ils2;     // (D, E)
+    const double* logvar;   // (D)
+    const double* xrange;   // (2, E)
+    const double* actions;  // (B, H, A)
+    const double* mu;       // (B, H + 1, D)
+    const double* Sig;      // (B, H + 1, D, D)
+    const int* mono_exp;    // (CM, 4) exponents, graded order (rollout.hip ensure_monomials)
+    const double* mono_w;   // (CM) 1 / alpha!
+    double* mom;            // (B, H, P, NSP)   [W | P1 (DP) | P2 upper triangle | Pe (NXP)]
+    int* done;              // (B, H, P) 1 = the pair's moments were written here
+    int mono_cum[16];       // monomials of degree <= k
+    int N, D, A, E, H, B;
+    int include_time;
+    double time0;
+    int NSP, NXP;
+    int kmax;               // highest degree this kernel takes (mono_cum[kmax] <= 16 kSepGradBlocks)
+    int force_path;
+    int PS;                 // doubles per point in the LDS tables
+    int wave_words;         // doubles of LDS per wavefront
+};
+
+__host__ __device__ inline int sep_grad_point_words(int D, int NX, int K) {
+    // wt | v = (1, u_0 .., nu_x ..) | powers x_d^e, e = 0 .. K;  odd stride: the four points of a k-step fall on distinct banks
+    const int n = 1 + (1 + D + NX) + D * (K + 1);
+    return n | 1;
+}
+
+// ------------------------------------------------------------------------------------------
+template <int DP, int NA>
+__global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_grad_moments_kernel(const SepGradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr int NW = sep_grad_waves(DP), NT = 64 * NW, NB = kSepGradBlocks;
+    constexpr int NH = DP * (DP + 1) / 2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = blockIdx.x, c = blockIdx.y;
+    const int N = p.N, D = p.D, A = p.A, E = p.E, H = p.H;
+    const int NX = E - D, P = D * (D + 1) / 2, Poff = P - D;
+    const int NV = 1 + D + NX;                           // weighting vector (1, u, nu_x)
+    const int nW = 1 + D + D * (D + 1) / 2 + NX;         // weightings: 1 | u_d | u_d u_e (d <= e) | nu_x
+    const int PS = p.PS;
+    // LDS: shared small data, then one region per wavefront (point tables during the pass, its moment matrix afterwards)
+    double* s_m = smem;                                  // E
+    double* s_ils2 = s_m + rnd2(E);                      // D * E
+    double* s_Z = s_ils2 + rnd2(D * E);                  // Poff * DP * DP
+    double* s_tab = s_Z + rnd2((Poff > 0 ? Poff : 1) * DP * DP);      // exp table
+    int* s_K = reinterpret_cast<int*>(s_tab + 64);       // Poff degrees (0: not taken)
+    int* s_q = s_K + 8;                                  // Poff: full pair index
+    double* s_cw = s_tab + 64 + 8;                       // 16 NB monomial weights
+    int* s_me = reinterpret_cast<int*>(s_cw + 16 * NB);  // 16 NB packed exponents
+    double* s_wave = s_cw + 16 * NB + 8 * NB + 8;
+    double* tabw = s_wave + (size_t)wave * p.wave_words;
+
+    for (int e = tid; e < E; e += NT) {
+        double v;
+        if (e < D) v = p.mu[((size_t)c * (H + 1) + t) * D + e];
+        else if (e < D + A) v = p.actions[((size_t)c * H + t) * A + (e - D)];
+        else v = p.time0 + (double)t;
+        s_m[e] = v;
+    }
+    for (int i = tid; i < D * E; i += NT) s_ils2[i] = p.ils2[i];
+    for (int i = tid; i < 64; i += NT) s_tab[i] = kExp2Tab[i];
+    for (int i = tid; i < 16 * NB; i += NT) {
+        const bool in = i < p.mono_cum[p.kmax];
+        s_cw[i] = in ? p.mono_w[i] : 0.0;
+        s_me[i] = in ? (p.mono_exp[i * 4] | (p.mono_exp[i * 4 + 1] << 8) | (p.mono_exp[i * 4 + 2] << 16) | (p.mono_exp[i * 4 + 3] << 24)) : 0;
+    }
+    __syncthreads();
+    // diagonal pairs are never taken here (their weights do not factor): say so, the flag array is not initialised otherwise
+    if (tid >= 64 && tid < 64 + D) p.done[((size_t)c * H + t) * P + (tid - 64) * D - ((tid - 64) * (tid - 65)) / 2] = 0;
+    // ---- D x D algebra of the off-diagonal pairs: Z = R^-1 Sigma, Taylor degree (phase P1 of rollout_kernel) -------------
+    if (tid < Poff) {
+        int a = 0, b = 0, k = tid, q = 0;
+        for (int aa = 0; aa < D; ++aa)
+            for (int bb = aa; bb < D; ++bb, ++q)
+                if (aa != bb) { if (k == 0) { a = aa; b = bb; s_q[tid] = q; } --k; }
+        const double* Sg = p.Sig + ((size_t)c * (H + 1) + t) * D * D;
+        double m[DP][2 * DP];
+#pragma unroll
+        for (int i = 0; i < DP; ++i)
+#pragma unroll
+            for (int j = 0; j < DP; ++j) {
+                const bool in = (i < D && j < D);
+                const double sg = in ? Sg[i * D + j] : 0.0;
+                m[i][j] = sg * (in ? s_ils2[a * E + j] + s_ils2[b * E + j] : 0.0) + (i == j ? 1.0 : 0.0);
+                m[i][DP + j] = sg;
+            }
+        (void)small_solve<DP>(m);
+        double cmax = 0.0;
+#pragma unroll
+        for (int i = 0; i < DP; ++i) {
+            const double ui = (i < D) ? fmax(fabs(p.xrange[i] - s_m[i]), fabs(p.xrange[E + i] - s_m[i])) * s_ils2[a * E + i] : 0.0;
+#pragma unroll
+            for (int j = 0; j < DP; ++j) {
+                const double z = (i < D && j < D) ? m[i][DP + j] : 0.0;
+                s_Z[(tid * DP + i) * DP + j] = z;
+                const double wj = (j < D) ? fmax(fabs(p.xrange[j] - s_m[j]), fabs(p.xrange[E + j] - s_m[j])) * s_ils2[b * E + j] : 0.0;
+                cmax = fma(fabs(z) * ui, wj, cmax);
+            }
+        }
+        int K = 0;
+        if (p.force_path == 0 && cmax <= kTaylorMaxArg[kMaxTaylor]) {
+            K = 1;
+            for (int k2 = 1; k2 < kMaxTaylor; ++k2) K += (cmax > kTaylorMaxArg[k2]) ? 1 : 0;
+        }
+        if (K > p.kmax) K = 0;
+        s_K[tid] = K;
+        p.done[((size_t)c * H + t) * P + s_q[tid]] = K > 0 ? 1 : 0;
+    }
+    __syncthreads();
+
+    // per-lane selectors.  A operand: weighting r = 16 ia + (lane & 15) -> two indices into the weighting vector;
+    // B operand: monomial n = 16 ib + (lane & 15) -> packed exponents (read per block below)
+    const int r16 = lane & 15, kq = lane >> 4;
+    int selA[NA][2];
+#pragma unroll
+    for (int ia = 0; ia < NA; ++ia) {
+        const int r = ia * 16 + r16;
+        int s1 = 0, s2 = 0;
+        if (r >= 1 && r <= D) s1 = r;
+        else if (r > D && r < 1 + D + D * (D + 1) / 2) {
+            int k = r - 1 - D, d = 0;
+            while (k >= D - d) { k -= D - d; ++d; }
+            s1 = 1 + d; s2 = 1 + d + k;
+        } else if (r >= 1 + D + D * (D + 1) / 2 && r < nW) s1 = 1 + D + (r - 1 - D - D * (D + 1) / 2);
+        selA[ia][0] = (r < nW) ? s1 : -1;
+        selA[ia][1] = s2;
+    }
+
+    // ---- tasks (off-diagonal pair, side): two rounds of wavefronts per pair pair, then the combination ----------------
+    for (int pq0 = 0; pq0 < Poff; pq0 += NW / 2) {
+        const int pq = pq0 + (wave >> 1), side = wave & 1;
+        const bool active = pq < Poff && s_K[pq < Poff ? pq : 0] > 0;
+        const int K = active ? s_K[pq] : 0;
+        const int C = p.mono_cum[K];
+        const int nb = (C + 15) >> 4;
+        if (active) {
+            const int qf = s_q[pq];
+            int a = 0, rem = qf;
+            while (rem >= D - a) { rem -= D - a; ++a; }
+            const int b = a + rem;
+            const int co = side ? b : a;
+            const double* Z = s_Z + pq * DP * DP;
+            const double* il = s_ils2 + co * E;
+            const double lv = p.logvar[co];
+            int expB[NB];
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib) expB[ib] = s_me[ib * 16 + r16];
+            mfma_d4 acc[NA][NB];
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia)
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib) acc[ia][ib] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+            const int K1 = K + 1;
+            for (int c0 = 0; c0 < N; c0 += 64) {
+                // -- per-point tables (lane = point) --
+                {
+                    const int pt0 = c0 + lane;
+                    const bool live = pt0 < N;
+                    const int pt = live ? pt0 : N - 1;
+                    double* tp = tabw + (size_t)lane * PS;
+                    double nu[DP], x[DP], zx[DP];
+                    double ks = 0.0;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) {
+                        nu[d] = (d < D) ? p.Xt[(size_t)d * N + pt] - s_m[d] : 0.0;
+                        x[d] = (d < D) ? nu[d] * il[d] : 0.0;          // u (rows) or w (columns)
+                        ks = fma(nu[d], x[d], ks);
+                    }
+                    tp[1] = 1.0;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) if (d < D) tp[2 + d] = x[d];
+                    for (int xx = 0; xx < NX; ++xx) {
+                        const double v = p.Xt[(size_t)(D + xx) * N + pt] - s_m[D + xx];
+                        ks = fma(v * v, il[D + xx], ks);
+                        tp[2 + D + xx] = v;
+                    }
+                    double qq = 0.0;
+                    double g[DP];
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) g[d] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) {
+                        zx[i] = 0.0;
+#pragma unroll
+                        for (int j = 0; j < DP; ++j) {
+                            zx[i] = fma(Z[i * DP + j], x[j], zx[i]);
+                            g[j] = fma(Z[i * DP + j], x[i], g[j]);            // Z^T x
+                        }
+                        qq = fma(x[i], zx[i], qq);
+                    }
+                    const double kk = lv - 0.5 * ks + 0.5 * qq;
+                    tp[0] = live ? fast_exp(kk, s_tab) * p.beta[(size_t)co * N + pt] : 0.0;
+                    // monomial variables: g = Z^T u on the row side, w itself on the column side
+                    double* pw = tp + 1 + NV;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) {
+                        if (d < D) {
+                            const double xv = side ? x[d] : g[d];
+                            double pv = 1.0;
+                            for (int e = 0; e < K1; ++e) { pw[d * K1 + e] = pv; pv *= xv; }
+                        }
+                    }
+                }
+                wave_lds_sync();
+                // -- 16 k-steps of 4 points: F^T Phi on the matrix cores --
+#pragma unroll 2
+                for (int ks4 = 0; ks4 < 16; ++ks4) {
+                    const double* tp = tabw + (size_t)(ks4 * 4 + kq) * PS;
+                    const double wt = tp[0];
+                    double aF[NA];
+#pragma unroll
+                    for (int ia = 0; ia < NA; ++ia) {
+                        const int s1 = selA[ia][0];
+                        aF[ia] = (s1 >= 0) ? wt * tp[1 + (s1 >= 0 ? s1 : 0)] * tp[1 + selA[ia][1]] : 0.0;
+                    }
+                    const double* pw = tp + 1 + NV;
+#pragma unroll
+                    for (int ib = 0; ib < NB; ++ib) {
+                        if (ib < nb) {
+                            const int ex = expB[ib];
+                            double phi = pw[ex & 255];
+#pragma unroll
+                            for (int d = 1; d < DP; ++d)
+                                if (d < D) phi *= pw[d * K1 + ((ex >> (8 * d)) & 255)];
+                            phi = (ib * 16 + r16 < C) ? phi : 0.0;
+#pragma unroll
+                            for (int ia = 0; ia < NA; ++ia) acc[ia][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[ia], phi, acc[ia][ib], 0, 0, 0);
+                        }
+                    }
+                }
+                wave_lds_sync();
+            }
+            // moment matrix of this (pair, side) into the wavefront's region: M[weighting][monomial], row stride 16 NB
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia)
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib)
+                    if (ib < nb) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (ia * 16 + 4 * r + kq < nW) tabw[(size_t)(ia * 16 + 4 * r + kq) * (16 * NB) + ib * 16 + r16] = acc[ia][ib][r];
+                    }
+        }
+        __syncthreads();
+        // ---- combination: the two wavefronts of a pair share the outputs (side 0 wave: even outputs, side 1: odd) --------
+        if (active) {
+            const int qf = s_q[pq];
+            int a = 0, rem = qf;
+            while (rem >= D - a) { rem -= D - a; ++a; }
+            const int b = a + rem;
+            const double* G = s_wave + (size_t)(wave & ~1) * p.wave_words;           // side 0: rows (u)
+            const double* Hm = G + p.wave_words;                                     // side 1: columns (w)
+            const int RSm = 16 * NB;
+            double* out = p.mom + (((size_t)c * H + t) * P + qf) * p.NSP;
+            // weighting indices: 0: 1 | 1 + d: u_d | 1 + D + tri(d, e): u_d u_e | 1 + D + D (D + 1) / 2 + x: nu_x
+            auto widx_uu = [&](int d, int e) { return 1 + D + d * D - (d * (d - 1)) / 2 + (e - d); };
+            for (int o = side; o < p.NSP; o += 2) {
+                // which moment: [W | P1 (DP) | P2 tri (NH, DP-padded index) | Pe (NXP)]
+                int kind, d = 0, e = 0;
+                if (o == 0) kind = 0;
+                else if (o < 1 + DP) { kind = 1; d = o - 1; }
+                else if (o < 1 + DP + NH) { kind = 2; decode_tri(o - 1 - DP, DP, d, e); }
+                else { kind = 3; d = o - 1 - DP - NH; }
+                double v = 0.0;
+                const bool valid = (kind == 0) || (kind == 1 && d < D) || (kind == 2 && d < D && e < D) || (kind == 3 && d < NX);
+                if (valid) {
+                    for (int n = lane; n < C; n += 64) {
+                        const double cw = s_cw[n];
+                        double s;
+                        if (kind == 0) s = G[n] * Hm[n];
+                        else if (kind == 1) s = G[(1 + d) * RSm + n] * Hm[n] + G[n] * Hm[(1 + d) * RSm + n];
+                        else if (kind == 2) s = G[widx_uu(d, e) * RSm + n] * Hm[n] + G[(1 + d) * RSm + n] * Hm[(1 + e) * RSm + n]
+                                                + G[(1 + e) * RSm + n] * Hm[(1 + d) * RSm + n] + G[n] * Hm[widx_uu(d, e) * RSm + n];
+                        else {
+                            const int wx = 1 + D + D * (D + 1) / 2 + d;
+                            s = G[wx * RSm + n] * Hm[n] * s_ils2[a * E + D + d] + G[n] * Hm[wx * RSm + n] * s_ils2[b * E + D + d];
+                        }
+                        v = fma(cw, s, v);
+                    }
+                    v = wave_sum(v);
+                }
+                if (lane == 0) out[o] = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace gpmpc_hip

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(kGsThreads) void pair_moments_stream_kernel(const G
     const int NCB = (N + 63) >> 6;
     const int RC = NCB;                        // 64-row chunks
     for (int q = (int)blockIdx.z; q < P; q += (int)gridDim.z) {
+        if (p.sepdone && p.sepdone[((size_t)c * H + t) * P + q]) continue;      // written by sep_grad_moments_kernel
         int a = 0, qq = q;
         while (qq >= D - a) { qq -= D - a; ++a; }
         const int b = a + qq;

@@ -276,3 +276,27 @@ def test_config5_full_size_gradient_against_oracle_fixture(engine):
     from helpers import record
     record("config5_gradient[N4096,D16,H2]", grad=e, J=abs(float(out["J"][0]) - float(g["J"])) / abs(float(g["J"])))
     assert e < 1e-6
+
+
+@pytest.mark.parametrize("N,D,A,H,B,tm,s0", [(30, 3, 1, 5, 3, False, 1e-6), (25, 2, 2, 4, 2, True, 1e-5), (70, 4, 2, 3, 2, False, 1e-6),
+                                             (130, 3, 5, 3, 2, True, 1e-5), (200, 3, 1, 6, 3, False, 1e-4), (300, 4, 1, 3, 2, False, 1e-5),
+                                             (65, 2, 1, 4, 2, False, 3e-3), (90, 4, 2, 3, 2, False, 1e-3), (64, 3, 1, 3, 2, False, 1e-5),
+                                             (1, 3, 1, 2, 2, False, 1e-5)])
+def test_separable_moments_of_the_off_diagonal_pairs(engine, N, D, A, H, B, tm, s0):
+    """csrc/grad_sep_kernel.h: the moments of the off-diagonal pairs as products of row-side and column-side monomial
+    moments, F^T Phi on the fp64 matrix cores (forced here at every N; by default from N = 256 on), against the numpy
+    adjoint and against the element-wise moment pass.  Includes more action inputs than 1 (second A block at D = 4),
+    time input, variances that push the Taylor degree to the edge of the monomial table (those pairs stay element-wise)."""
+    w = synth.make_workload(N, D, A, H, B, include_time=tm, seed=N + D, s0=s0, time0=1.0 if tm else 0.0)
+    f = _load_model(engine, w)
+    res = {}
+    for sep in (2, 0):
+        engine.set_option("grad_separable", sep)
+        try:
+            res[sep] = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)["grad"].cpu().numpy()
+        finally:
+            engine.set_option("grad_separable", 1)
+    for b in range(B):
+        J, g, *_ = adjoint.lcb_and_gradient(f, w.actions[b], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
+        assert rel_err(res[2][b], g) < 1e-7
+    assert rel_err(res[2], res[0]) < 1e-7
