@@ -436,7 +436,11 @@ __global__ __launch_bounds__(256) void trinv_cols_small_kernel(const double* __r
 // through, < 0 on error.
 int run_prepare_small(Handle* h, const double* X, const double* Y, const double* ls, const double* os, const double* noise,
                       int N, int D, int E, hipStream_t s) {
-    if (N > kSmallMaxN || N < 1 || h->opt_fused_prepare == 0) return 0;
+    // Crossover with the panel chain, measured (round 3, tools/gpu_prepare_bench.py; the LDS arrays were sized by N for the test):
+    // N = 200: 0.217 vs 0.240 ms, 256: 0.344 vs 0.299, 300: 0.387 vs 0.337, 400: 0.84 vs 0.49, 500: 1.15 vs 0.60 -- one CU's
+    // matrix cores do the N^3 / 3 of the panel updates, so the single launch loses once the chain's launches fill more than a CU.
+    constexpr int kSmallPathMaxN = 240;
+    if (N > kSmallPathMaxN || N < 1 || h->opt_fused_prepare == 0) return 0;
     SmallPrepArgs p;
     // One workgroup per GP is the right shape for the factorisation (a chain of 200 dependent pivots) but not for the
     // N^3 products after it: on one CU they are matrix-core-bound at ~50 k cycles each for N = 200.  From N = 96 up only

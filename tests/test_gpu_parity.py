@@ -143,9 +143,11 @@ def test_factorisation_vs_reference(engine, name):
     assert np.array_equal(iKn, iKn.transpose(0, 2, 1))          # mirrored store: exactly symmetric
 
 
-@pytest.mark.parametrize("N,D,A", [(1, 3, 1), (31, 2, 1), (33, 3, 1), (64, 1, 1), (257, 4, 2), (700, 2, 1)])
+@pytest.mark.parametrize("N,D,A", [(1, 3, 1), (31, 2, 1), (33, 3, 1), (64, 1, 1), (240, 3, 1), (241, 3, 1), (256, 3, 1), (257, 4, 2), (300, 2, 1),
+                                   (500, 2, 1), (512, 4, 2), (700, 2, 1)])
 def test_factorisation_ragged_sizes(engine, N, D, A):
-    """Panel width is 32: sizes below, at and across panel boundaries."""
+    """Panel width is 32: sizes below, at and across panel boundaries; N <= 240 takes the single-launch factorisation
+    (one workgroup per GP; the measured crossover with the panel chain), larger memories the panel chain."""
     w = synth.make_workload(N, D, A, 3, 2, seed=N)
     engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
     iK, beta = engine.factors()

@@ -1,5 +1,5 @@
 """gpmpc_prepare: full factorisation time (reuse switched off) and accuracy vs the CPU oracle.
-  python tools/gpu_prepare_bench.py [N:D:A ...]     N <= 256 is timed with the fused single-launch path and the panel path"""
+  python tools/gpu_prepare_bench.py [N:D:A ...]     N <= 240 is timed with the fused single-launch factorisation and with the panel path"""
 import sys, time
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch
@@ -14,13 +14,13 @@ for (N, D, A) in shapes:
     w = synth.make_workload(N, D, A, 2, 2, seed=1)
     X, Y = torch.as_tensor(w.X).cuda(), torch.as_tensor(w.Y).cuda()
     ls, osc, nz = torch.as_tensor(w.lengthscales).cuda(), torch.as_tensor(w.outputscales).cuda(), torch.as_tensor(w.noises).cuda()
-    for fused in ((1, 2, 0) if N <= 256 else (0,)):
+    for fused in ((1, 2, 0) if N <= 240 else (0,)):
         eng.set_option("fused_prepare", fused)
         eng.prepare(X, Y, ls, osc, nz); torch.cuda.synchronize()
         ts = []
         for _ in range(5):
             t0 = time.perf_counter(); eng.prepare(X, Y, ls, osc, nz); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
-        msg = f"prepare N={N} D={D} { {0: 'panel path', 1: 'default (<= 256: fused factorisation, < 96: all fused)', 2: 'all fused'}[fused] }: {np.median(ts)*1e3:.3f} ms (min {min(ts)*1e3:.3f})"
+        msg = f"prepare N={N} D={D} { {0: 'panel path', 1: 'default (<= 240: fused factorisation, < 96: all fused)', 2: 'all fused'}[fused] }: {np.median(ts)*1e3:.3f} ms (min {min(ts)*1e3:.3f})"
         flops = D * N**3                        # N^3/3 each: Cholesky, triangular inverse, Y^T Y
         msg += f"  ({flops / np.median(ts) / 1e12:.2f} TFLOP/s on the N^3 contractions)"
         if N <= 2048:
