@@ -81,7 +81,7 @@ int gpmpc_destroy(gpmpc_t* g) {
     (void)hipSetDevice(h->device);
     Buf* all[] = {&h->Xt, &h->beta, &h->iK, &h->Tm, &h->ils2, &h->var, &h->logvar, &h->gram,
                   &h->linv, &h->zvec, &h->cost, &h->best, &h->xrange, &h->mono_w, &h->traj, &h->Xc, &h->Yc,
-                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws, &h->cemws, &h->tilews, &h->sepw};
+                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws, &h->cemws, &h->tilews, &h->sepw, &h->tgradws};
     for (Buf* b : all) free_buf(*b);
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);
@@ -109,6 +109,7 @@ int gpmpc_set_option(gpmpc_t* g, const char* name, long long value) {
     else if (!strcmp(name, "incremental")) h->opt_incremental = (int)value;
     else if (!strcmp(name, "grad_stream")) h->opt_grad_stream = (int)value;
     else if (!strcmp(name, "grad_separable")) h->opt_grad_sep = (int)value;
+    else if (!strcmp(name, "grad_tiles")) h->opt_grad_tiles = (int)value;
     else if (!strcmp(name, "fused_prepare")) h->opt_fused_prepare = (int)value;
     else if (!strcmp(name, "outer_block")) h->opt_outer_block = (int)value;
     else if (!strcmp(name, "tile128")) h->opt_tile128 = (int)value;

@@ -102,6 +102,7 @@ struct Handle {
     Buf mllws;    // marginal-likelihood workspace: tile partial sums | results
     Buf cemws;    // cross-entropy search workspace: optimiser vectors | model actions | J | mean | std | warm start | mapper
     Buf tilews;   // batch-major path: step records of the candidates | per-tile partial sums | hand-over flags
+    Buf tgradws;  // gradient's tile pass: records of a block of (candidate, step) items | per-tile partial moments
     struct SepTable* septab = nullptr;   // monomial bands of the separable evaluation (point_pass_kernel.h), device copy
     Buf sepw;                            // their weights 1 / alpha!
     int septab_D = -1, sep_ks = 0, sep_cmax = 0;
@@ -136,6 +137,7 @@ struct Handle {
     int opt_force_sep = 0;
     int opt_grad_stream = 0;         // 1: always the streaming moment pass of the gradient (tests); otherwise only when N needs it
     int opt_grad_cols = 0;           // 2: two columns per lane in the gradient's moment pass (A/B)
+    int opt_grad_tiles = 1;          // diagonal pairs of the gradient's moment pass batch-major (pair_tile_grad_kernel.h): 0 never, 1 auto, 2 always
     int opt_grad_sep = 1;            // off-diagonal pairs of the gradient's moment pass in separable form on the matrix cores:
                                      // 0 never (element-wise), 1 from N = 256 on (measured crossover), 2 always (tests, A/B)
     int opt_exact_dim = 0;           // 2: forbid the compile-time-D kernel instantiation (A/B)
@@ -188,6 +190,8 @@ bool tile_path_supported(Handle* h, const RolloutArgs& a);
 int tile_workspace(Handle* h, RolloutArgs& a);
 int launch_tile_state_init(Handle* h, const RolloutArgs& a, hipStream_t s);
 int launch_pair_tiles(Handle* h, const RolloutArgs& a, int t, hipStream_t s);
+bool tile_moments_supported(Handle* h, const RolloutArgs& a, int NSP);
+int launch_tile_moments(Handle* h, const RolloutArgs& a, double* mom, int* done, int NSP, int NXP, hipStream_t s);
 // grad.hip
 int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t s);
 int launch_rollout_grad_wide(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t s);     // grad_wide.hip: 8 < D <= 16

@@ -190,6 +190,17 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
             }
         }
     }
+    // Diagonal pairs batch-major over all (candidate, step) items (pair_tile_grad_kernel.h) once the tables T_a are large
+    // and the batch fills the chip; the element-wise pass below keeps the mean sums and whatever is flagged 0.
+    if (h->opt_grad_tiles != 0 && D >= 2 && D <= 4 && tile_moments_supported(h, a, NSP) &&
+        (h->opt_grad_tiles == 2 || (4.0 * D * (double)N * N >= 6e6 && (long long)B * H >= 2LL * h->num_cu))) {
+        if (!g.sepdone) {
+            GPMPC_HIP_CHECK(h, hipMemsetAsync(sep_flags, 0, (size_t)B * H * P * sizeof(int), s));
+            g.sepdone = sep_flags;
+        }
+        rc = launch_tile_moments(h, a, g.mom, sep_flags, NSP, NXP, s);
+        if (rc) return rc;
+    }
     if (stream) {
         switch (DP) {
             case 2:  rc = launch_moments_stream_dp<2>(h, g, gs_lds, s); break;

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "pair_tile_kernel.h"
+#include "pair_tile_grad_kernel.h"
 
 namespace gpmpc_hip {
 
@@ -227,6 +228,82 @@ int launch_pair_tiles(Handle* h, const RolloutArgs& a, int step, hipStream_t s) 
         case 2:  return launch_step_dp<2>(h, t, s);
         case 3:  return launch_step_dp<3>(h, t, s);
         default: return launch_step_dp<4>(h, t, s);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Gradient: moments of the diagonal pairs of ALL (candidate, step) items of a stored trajectory, batch-major
+// (pair_tile_grad_kernel.h).  Items are taken in blocks so that the records and per-tile partial moments stay a
+// bounded workspace; per block: records (step_params_kernel<.., TRAJ>) -> tile moments -> ordered tile sum into the
+// moment array, flag per diagonal pair for the element-wise kernels (1: written here).
+template <int DP>
+static int launch_tile_moments_dp(Handle* h, StepArgs t, long long items, double* mom, int* done, int NSP, int NXP, hipStream_t s) {
+    auto kern = pair_tile_moments_kernel<DP>;
+    int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+    if (rc) return rc;
+    const size_t lds = (size_t)make_tile_grad_layout(DP, t.E).total * sizeof(double);
+    const int nta = t.ntiles * t.D;
+    // items per block: a multiple of the chunk that gives every CU a few workgroups per tile row, workspace <= ~1 GiB
+    const size_t per_item = (size_t)t.CS + (size_t)t.D * t.ntiles * kTgMom;
+    long long block = (long long)((size_t)(1u << 27) / per_item);
+    if (block > items) block = items;
+    if (block < 1) block = 1;
+    rc = grow(h, h->tgradws, (size_t)block * per_item);
+    if (rc) return rc;
+    t.crec = h->tgradws.p;
+    double* tmom = h->tgradws.p + (size_t)block * t.CS;
+    for (long long i0 = 0; i0 < items; i0 += block) {
+        const int nb = (int)((items - i0 < block) ? items - i0 : block);
+        t.B = nb;
+        t.item0 = (int)i0;
+        // chunk: rounds x (chunk + prologue) over one workgroup per CU (2 waves per SIMD: ~200 VGPRs)
+        int cch = h->opt_tile_chunk;
+        if (cch <= 0) {
+            long long best = -1;
+            for (int c = 16; c <= 128; c += 2) {
+                const long long wgs = (long long)nta * ((nb + c - 1) / c);
+                const long long cost = ((wgs + h->num_cu - 1) / h->num_cu) * (c + 8);
+                if (best < 0 || cost < best) { best = cost; cch = c; }
+            }
+        }
+        cch = (cch + 1) & ~1;
+        t.cch = cch;
+        t.nchunk = (nb + cch - 1) / cch;
+        const int P = t.D * (t.D + 1) / 2;
+        hipLaunchKernelGGL((step_params_kernel<DP, true>), dim3((unsigned)(((long long)nb * (t.D + P) + 255) / 256)), dim3(256), 0, s, t);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+        const int per_xcd = (nta + 7) / 8;
+        hipLaunchKernelGGL(kern, dim3(8 * per_xcd * t.nchunk), dim3(kTileWaves * 64), lds, s, t, tmom);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+        hipLaunchKernelGGL(tile_moments_reduce_kernel<DP>, dim3(nb), dim3(64), 0, s, t, (const double*)tmom, mom, done, NSP, NXP);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+    }
+    return GPMPC_OK;
+}
+
+bool tile_moments_supported(Handle* h, const RolloutArgs& a, int NSP) {
+    if (a.D < 2 || a.D > 4 || NSP > 64 || a.E - a.D > 8) return false;
+    const int DP = tile_dp(a.D);
+    return (size_t)make_tile_grad_layout(DP, a.E).total * sizeof(double) <= (size_t)h->lds_limit;
+}
+
+int launch_tile_moments(Handle* h, const RolloutArgs& a, double* mom, int* done, int NSP, int NXP, hipStream_t s) {
+    StepArgs t{};
+    step_geometry(h, a, t);
+    const int DP = tile_dp(a.D);
+    t.off_pair = t.off_mean;                       // compact records: inputs | the D diagonal pair problems
+    t.CS = t.off_pair + a.D * t.PRP;
+    t.Xt = a.Xt; t.beta = a.beta; t.Tm = a.Tm; t.ils2 = a.ils2; t.var = a.var; t.logvar = a.logvar; t.xrange = a.xrange;
+    t.actions = a.actions;
+    t.mu = a.mu_out; t.Sig = a.Sig_out;
+    t.N = a.N; t.D = a.D; t.A = a.A; t.E = a.E; t.H = a.H;
+    t.include_time = a.include_time; t.time0 = a.time0;
+    t.force_path = a.force_path;
+    const long long items = (long long)a.B * a.H;
+    switch (DP) {
+        case 2:  return launch_tile_moments_dp<2>(h, t, items, mom, done, NSP, NXP, s);
+        case 3:  return launch_tile_moments_dp<3>(h, t, items, mom, done, NSP, NXP, s);
+        default: return launch_tile_moments_dp<4>(h, t, items, mom, done, NSP, NXP, s);
     }
 }
 

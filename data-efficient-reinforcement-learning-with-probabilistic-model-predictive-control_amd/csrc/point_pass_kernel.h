@@ -67,6 +67,7 @@ struct StepArgs {
     int ksep;               // highest separable degree (septab->ks)
     int mom_stride;         // doubles per (pair, side) moment array in LDS
     int PO;                 // doubles per candidate in pout
+    int item0;              // TRAJ records: first (candidate, step) item of this launch
 };
 
 __host__ __device__ inline int pair_index(int a, int b, int D) { return a * D - (a * (a - 1)) / 2 + (b - a); }
@@ -75,26 +76,31 @@ __host__ __device__ inline int pair_index(int a, int b, int D) { return a * D - 
 // All the D x D algebra of step t, one thread per problem: phase P1 of rollout_kernel.
 //   mean problem a : A_a = Sigma + diag(l_a^2) -> A_a^-1, c_a = var_a / sqrt(det B_a)                 (gp_model.py:141-150)
 //   pair problem q : R = Sigma diag(1/l_a^2 + 1/l_b^2) + I -> Z = R^-1 Sigma, 1 / sqrt(det R), Taylor degree   (:156-163, 176)
-template <int DP>
+// TRAJ: the records of ALL (candidate, step) items of a stored trajectory for the gradient's tile pass (pair_tile_grad_kernel.h):
+// p.B counts items, item = candidate * H + step, only the diagonal pair problems are formed.
+template <int DP, bool TRAJ = false>
 __global__ __launch_bounds__(256) void step_params_kernel(const StepArgs p) {
     const int D = p.D, E = p.E, A = p.A;
     const int P = D * (D + 1) / 2;
     const int per = D + P;
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= p.B * per) return;
-    const int c = idx / per, j = idx - c * per;
-    const double* mu = p.mu + ((size_t)c * (p.H + 1) + p.t) * D;
-    const double* Sg = p.Sig + ((size_t)c * (p.H + 1) + p.t) * D * D;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)p.B * per) return;
+    const int c = (int)(idx / per), j = (int)(idx - (long long)c * per);
+    const int cc = TRAJ ? (p.item0 + c) / p.H : c;          // candidate and step of the trajectory arrays
+    const int tt = TRAJ ? (p.item0 + c) - cc * p.H : p.t;
+    const double* mu = p.mu + ((size_t)cc * (p.H + 1) + tt) * D;
+    const double* Sg = p.Sig + ((size_t)cc * (p.H + 1) + tt) * D * D;
     double* rec = p.crec + (size_t)c * p.CS;
     if (j == 0) {
         for (int e = 0; e < E; ++e) {
             double v;
             if (e < D) v = mu[e];
-            else if (e < D + A) v = p.actions[((size_t)c * p.H + p.t) * A + (e - D)];
-            else v = p.time0 + (double)p.t;
+            else if (e < D + A) v = p.actions[((size_t)cc * p.H + tt) * A + (e - D)];
+            else v = p.time0 + (double)tt;
             rec[e] = v;
         }
     }
+    if (TRAJ && j < D) return;
     double m[DP][2 * DP];
     if (j < D) {
         const int a = j;
@@ -125,6 +131,7 @@ __global__ __launch_bounds__(256) void step_params_kernel(const StepArgs p) {
     int a = 0, rem = q;
     while (rem >= D - a) { rem -= D - a; ++a; }
     const int b = a + rem;
+    if (TRAJ && a != b) return;
     const double* ila = p.ils2 + (size_t)a * E;
     const double* ilb = p.ils2 + (size_t)b * E;
 #pragma unroll
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(256) void step_params_kernel(const StepArgs p) {
         wr[i] = (i < D) ? rg * ilb[i] : 0.0;
     }
     const double detR = small_solve<DP>(m);
-    double* out = rec + p.off_pair + q * p.PRP;
+    double* out = rec + p.off_pair + (TRAJ ? a : q) * p.PRP;      // TRAJ records hold the D diagonal pairs only
     double cmax = 0.0;
 #pragma unroll
     for (int i = 0; i < DP; ++i) {

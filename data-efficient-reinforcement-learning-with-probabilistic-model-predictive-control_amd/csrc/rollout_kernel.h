@@ -554,6 +554,66 @@ __device__ inline double wave_sum8(const double (&v)[8], int lane) {
     return r;
 }
 
+// Sums over the wavefront of 16 (8) values per lane without the LDS crossbar: the halving "transpose" steps ride on
+// v_permlane32_swap / v_permlane16_swap (gfx950: lanes 0-31 <-> 32-63, even <-> odd rows of 16) and on DPP row rotations with
+// bank masks (lane bits 3 and 2) -- one exchange hands over the half a lane gives up AND brings in the partner's half of what it
+// keeps, no selects -- then two quad_perm butterflies.  Lane l ends with the total of value (l >> 2) [& 7].  57 VALU instructions for
+// 16 values against ~70 plus six dependent ds_bpermute round trips for the 8 values of wave_sum8.  Fixed order.
+__device__ inline double dbl_of(unsigned lo, unsigned hi) { return __hiloint2double((int)hi, (int)lo); }
+
+template <int KIND>                     // 32: lane bit 5, 16: lane bit 4
+__device__ inline double swap_add(double a, double b) {
+    const unsigned a0 = (unsigned)__double2loint(a), a1 = (unsigned)__double2hiint(a);
+    const unsigned b0 = (unsigned)__double2loint(b), b1 = (unsigned)__double2hiint(b);
+    if constexpr (KIND == 32) {
+        const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+        return dbl_of(r0[0], r1[0]) + dbl_of(r0[1], r1[1]);
+    } else {
+        const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+        const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+        return dbl_of(r0[0], r1[0]) + dbl_of(r0[1], r1[1]);
+    }
+}
+
+template <int CTRL, int BANKS>
+__device__ inline double dpp_merge(double old, double src) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xf, BANKS, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xf, BANKS, false);
+    return __hiloint2double(hi, lo);
+}
+
+// lanes with bit 3 (2) clear keep `a`, the others `b`; both get the partner's (lane ^ 8, lane ^ 4) share of what they keep
+__device__ inline double rot_add8(double a, double b) { return dpp_merge<0x128, 0x3>(b, a) + dpp_merge<0x128, 0xc>(a, b); }
+__device__ inline double rot_add4(double a, double b) { return dpp_merge<0x12c, 0x5>(b, a) + dpp_merge<0x124, 0xa>(a, b); }
+
+__device__ inline double quad_total(double r) {
+    r += dpp_merge<0x4e, 0xf>(r, r);          // quad_perm [2, 3, 0, 1]
+    r += dpp_merge<0xb1, 0xf>(r, r);          // quad_perm [1, 0, 3, 2]
+    return r;
+}
+
+__device__ inline double wave_reduce16(const double (&v)[16]) {
+    double w8[8], w4[4], w2[2];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) w8[k] = swap_add<32>(v[k], v[k + 8]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w4[k] = swap_add<16>(w8[k], w8[k + 4]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) w2[k] = rot_add8(w4[k], w4[k + 2]);
+    return quad_total(rot_add4(w2[0], w2[1]));
+}
+
+__device__ inline double wave_reduce8(const double (&v)[8]) {
+    double w4[4], w2[2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) w4[k] = swap_add<16>(v[k], v[k + 4]);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) w2[k] = rot_add8(w4[k], w4[k + 2]);
+    const double r = quad_total(rot_add4(w2[0], w2[1]));
+    return swap_add<32>(r, r);
+}
+
 // ------------------------------------------------------------------------------------------
 // Separable moments for three state dimensions with the monomial structure known at compile time.
 // Bands of at most 16 monomials (ranges of the x0 exponent i and, where needed, of the x1 exponent j); fewer, larger

@@ -300,3 +300,31 @@ def test_separable_moments_of_the_off_diagonal_pairs(engine, N, D, A, H, B, tm, 
         J, g, *_ = adjoint.lcb_and_gradient(f, w.actions[b], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
         assert rel_err(res[2][b], g) < 1e-7
     assert rel_err(res[2], res[0]) < 1e-7
+
+
+@pytest.mark.parametrize("N,D,A,H,B,tm,s0", [(30, 3, 1, 5, 3, False, 1e-6), (25, 2, 2, 4, 2, True, 1e-5), (70, 4, 2, 3, 2, False, 1e-6),
+                                             (130, 3, 5, 3, 2, True, 1e-5), (200, 3, 1, 6, 3, False, 1e-4), (300, 4, 1, 3, 2, False, 1e-5),
+                                             (257, 2, 1, 4, 2, False, 3e-3), (128, 4, 2, 3, 5, False, 1e-3), (129, 3, 1, 3, 2, False, 1e-5),
+                                             (1, 3, 1, 2, 2, False, 1e-5), (400, 4, 3, 2, 3, True, 1e-2)])
+@pytest.mark.parametrize("sep", [0, 2])
+def test_tile_moments_of_the_diagonal_pairs(engine, N, D, A, H, B, tm, s0, sep):
+    """csrc/pair_tile_grad_kernel.h: the moments of the diagonal pairs batch-major over all (candidate, step) items (a
+    workgroup keeps a 128 x 128 tile of T_a in registers), forced here at every N (by default where the forward takes its
+    batch-major path), against the numpy adjoint and the element-wise moment pass; with and without the separable pass for
+    the off-diagonal pairs, one to three tile rows, ragged last tiles, time input, large state variance (direct-exp items
+    stay element-wise)."""
+    w = synth.make_workload(N, D, A, H, B, include_time=tm, seed=N + D, s0=s0, time0=1.0 if tm else 0.0)
+    f = _load_model(engine, w)
+    res = {}
+    engine.set_option("grad_separable", sep)
+    try:
+        for tiles in (2, 0):
+            engine.set_option("grad_tiles", tiles)
+            res[tiles] = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)["grad"].cpu().numpy()
+    finally:
+        engine.set_option("grad_separable", 1)
+        engine.set_option("grad_tiles", 1)
+    for b in range(B):
+        J, g, *_ = adjoint.lcb_and_gradient(f, w.actions[b], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
+        assert rel_err(res[2][b], g) < 1e-7
+    assert rel_err(res[2], res[0]) < 1e-7
