@@ -3,7 +3,7 @@
 // The reference obtains the gradient by torch autograd through predict_trajectory (gp_mpc_controller.py:277,
 // `mean_cost.backward()`).  grad_kernels.h covers D <= 8 with per-column register accumulators of every moment
 // (1 + 2 D + D (D + 1) / 2 + A per column): at D = 16 that is 169 accumulators per column, and the reverse sweep's
-// per-pair LDS arrays would be 278 KiB.  This file is the same algebra (oracle/adjoint.py states it in numpy) arranged
+// per-pair LDS arrays would be 278 KiB.  This file is the same algebra (the test suite states it in numpy: the adjoint checker) arranged
 // for wide states:
 //
 //  wide_pair_moments_kernel   one workgroup per (output pair, horizon step, candidate).  The pairwise weights
@@ -18,7 +18,7 @@
 //      The row-side terms (sum_i r_i u_i u_i^T, r_i = sum_j E_ij) are the column-side terms of the pair evaluated in the
 //      other orientation (rows and columns swapped, Z transposed): a second, lighter pass without the V product;
 //      a diagonal pair is symmetric and takes one pass over the full square with weights from the symmetric iK.
-//  wide_adjoint_sweep_kernel  one workgroup per candidate, t = H-1 .. 0: the D x D algebra of oracle/adjoint.py
+//  wide_adjoint_sweep_kernel  one workgroup per candidate, t = H-1 .. 0: the D x D algebra of the reverse step
 //      backward_step with one pair per wavefront at a time (its 16 x 16 blocks in that wavefront's LDS scratch), and the mean
 //      part's point passes (lb_i, then the adjoint weights om_i and their moments G1, G2, Ge) in chunks of 256 points
 //      staged through LDS, every thread owning one entry of G2.
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(kWideSweepThreads) void wide_adjoint_sweep_kernel(c
     __syncthreads();
 
     for (int t = H - 1; t >= 0; --t) {
-        // ---- state of step t, seeds of the adjoints (oracle/adjoint.py backward_step) ------------------------------------
+        // ---- state of step t, seeds of the adjoints (the checker's backward_step) ------------------------------------
         {
             const double* mut = p.mu + ((size_t)c * (H + 1) + t) * D;
             const double* Sgt = p.Sig + ((size_t)c * (H + 1) + t) * DD;

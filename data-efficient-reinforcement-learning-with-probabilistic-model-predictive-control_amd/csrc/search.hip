@@ -120,8 +120,11 @@ __global__ __launch_bounds__(1024) void cem_refit_kernel(int B, int n, int n_eli
         }
     }
     const double bestJ_old = first_iteration ? INFINITY : best[n];
-    const bool improve = key[0] < bestJ_old;
+    // the first iteration always adopts its leader (even when every objective is non-finite): `best` is then never read
+    // uninitialised by the sampler of the next iteration
+    const bool improve = first_iteration || key[0] < bestJ_old;
     const int ib = val[0];
+    __syncthreads();                                       // every thread has read best[n] before thread 0 replaces it
     for (int k = tid; k < n; k += 1024) {
         double s = 0.0;
         for (int e = 0; e < n_elite; ++e) s += X[(size_t)val[e] * n + k];
