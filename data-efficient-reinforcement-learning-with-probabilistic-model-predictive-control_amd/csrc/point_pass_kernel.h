@@ -20,13 +20,14 @@
 //   * candidates that have an off-diagonal pair outside the separable range at this step (direct exp, degree beyond
 //     the table) are left to the element-wise kernel (rollout_kernel<.., TILED>), which runs after this one and
 //     skips everybody else: `slow[c] == t + 1` is the hand-over.
-// Fixed summation order everywhere (lane partials -> wave_sum8 -> ordered sums): bitwise reproducible, batch-independent.
+// Fixed summation order everywhere (lane partials -> wave_reduce16 / 8 -> ordered sums): bitwise reproducible, batch-independent.
 #pragma once
 #include "rollout_kernel.h"
 
 namespace gpmpc_hip {
 
 constexpr int kSepCap = 36;          // monomial sums a task keeps in registers (72 VGPRs; with 72 sums the D = 4 kernel spilled 145)
+constexpr int kSepAcc = (kSepCap + 7) & ~7;      // accumulator array of a task: kSepCap rounded up to the reduction groups
 constexpr int kSepMaxBands = 64;
 
 struct SepBand {
@@ -214,14 +215,14 @@ __global__ __launch_bounds__(256) void step_state_init_kernel(const RolloutArgs 
 // acc[n] += base * (n-th monomial of degree <= M in the NV tail variables), nested order: exponent of the first variable
 // outermost.  Everything unrolls: acc indices are compile-time, one FMA per monomial (powers of the last variable tabulated).
 template <int M>
-__device__ inline void tail1(double (&acc)[kSepCap], double base, double t0) {
+__device__ inline void tail1(double (&acc)[kSepAcc], double base, double t0) {
     double pwr = base;
 #pragma unroll
     for (int l = 0; l <= M; ++l) { acc[l] += pwr; pwr *= t0; }
 }
 
 template <int M>
-__device__ inline void tail2(double (&acc)[kSepCap], double base, double t0, double t1) {
+__device__ inline void tail2(double (&acc)[kSepAcc], double base, double t0, double t1) {
     double pw[M + 1];
     pw[0] = 1.0;
 #pragma unroll
@@ -237,7 +238,7 @@ __device__ inline void tail2(double (&acc)[kSepCap], double base, double t0, dou
 }
 
 template <int M>
-__device__ inline void tail3(double (&acc)[kSepCap], double base, double t0, double t1, double t2) {
+__device__ inline void tail3(double (&acc)[kSepAcc], double base, double t0, double t1, double t2) {
     double pw[M + 1];
     pw[0] = 1.0;
 #pragma unroll
@@ -258,7 +259,7 @@ __device__ inline void tail3(double (&acc)[kSepCap], double base, double t0, dou
 }
 
 template <int M>
-__device__ inline void tail4(double (&acc)[kSepCap], double base, double t0, double t1, double t2, double t3) {
+__device__ inline void tail4(double (&acc)[kSepAcc], double base, double t0, double t1, double t2, double t3) {
     double pw[M + 1];
     pw[0] = 1.0;
 #pragma unroll
@@ -285,7 +286,7 @@ __device__ inline void tail4(double (&acc)[kSepCap], double base, double t0, dou
 
 // code = nv * 16 + m (wave-uniform).  The host only emits bands this switch knows (sep_band_supported).
 template <int DP>
-__device__ inline void tail_dispatch(int code, double (&acc)[kSepCap], double base, double t0, double t1, double t2, double t3) {
+__device__ inline void tail_dispatch(int code, double (&acc)[kSepAcc], double base, double t0, double t1, double t2, double t3) {
     // every acc index below is a compile-time constant: a run-time index would move the sums to scratch memory
     if ((code & 15) == 0) { acc[0] += base; return; }
     switch (code) {
@@ -517,9 +518,9 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
         int pe[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) pe[d] = __builtin_amdgcn_readfirstlane(bd->e[d]);
-        double acc[kSepCap];
+        double acc[kSepAcc];
 #pragma unroll
-        for (int n = 0; n < kSepCap; ++n) acc[n] = 0.0;
+        for (int n = 0; n < kSepAcc; ++n) acc[n] = 0.0;
         // the state coordinates and beta of the next 64 points travel while the current ones are worked on
         double xc[DP], bc;
         {
@@ -574,13 +575,22 @@ __global__ __launch_bounds__(256, 2) void point_pass_kernel(const StepArgs p) {
             bc = bn;
         }
         double* mom = s_mom + (size_t)(((q - a - 1) * 2) + side) * p.mom_stride + boff;       // (q - a - 1): index among the off-diagonal pairs
-        const int mm = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
-#pragma unroll
-        for (int g8 = 0; g8 < kSepCap; g8 += 8) {
-            if (g8 < cnt) {
-                const double(&grp)[8] = *reinterpret_cast<const double(*)[8]>(&acc[g8]);
-                const double tot = wave_sum8(grp, lane);
-                if (lane < 8 && g8 + mm < cnt) mom[g8 + mm] = tot;
+        // lane partials over the wavefront: 16 + 16 + 8 values (wave_reduce*: permlane swaps and DPP, no LDS round trips);
+        // lane 4 m ends with the total of value m of its group
+        static_assert(kSepCap <= 40, "reduction groups below");
+        {
+            const double(&g0)[16] = *reinterpret_cast<const double(*)[16]>(&acc[0]);
+            const double t0r = wave_reduce16(g0);
+            if ((lane & 3) == 0 && (lane >> 2) < cnt) mom[lane >> 2] = t0r;
+            if (cnt > 16) {
+                const double(&g1)[16] = *reinterpret_cast<const double(*)[16]>(&acc[16]);
+                const double t1r = wave_reduce16(g1);
+                if ((lane & 3) == 0 && 16 + (lane >> 2) < cnt) mom[16 + (lane >> 2)] = t1r;
+            }
+            if (cnt > 32) {
+                const double(&g2)[8] = *reinterpret_cast<const double(*)[8]>(&acc[32]);
+                const double t2r = wave_reduce8(g2);
+                if ((lane & 3) == 0 && lane < 32 && 32 + (lane >> 2) < cnt) mom[32 + (lane >> 2)] = t2r;
             }
         }
     }
