@@ -167,7 +167,9 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
             for (int k = 0; k < 16; ++k) sg.mono_cum[k] = h->mono_cum[k];
             sg.N = N; sg.D = D; sg.A = A; sg.E = E; sg.H = H; sg.B = B; sg.include_time = a.include_time; sg.time0 = a.time0;
             sg.NSP = NSP; sg.NXP = NXP; sg.kmax = kmax; sg.force_path = h->opt_force_path;
-            const int NA = (nWt + 15) / 16;
+            // weightings beyond a multiple of 16 (one or two) are accumulated on the VALU instead of opening another A block
+            const int NE = (nWt > 16 && nWt % 16 != 0 && nWt % 16 <= 2) ? nWt % 16 : 0;
+            const int NA = NE ? nWt / 16 : (nWt + 15) / 16;
             sg.PS = sep_grad_point_words(D, NX, kmax);
             const int mat_words = nWt * 16 * kSepGradBlocks;          // moment matrix of a (pair, side): weightings x monomial slots
             sg.wave_words = 64 * sg.PS > mat_words ? 64 * sg.PS : mat_words;
@@ -184,6 +186,7 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
                 };
                 if (DP == 2) rc = launch(sep_grad_moments_kernel<2, 1>);
                 else if (DP == 3) rc = launch(sep_grad_moments_kernel<3, 1>);
+                else if (NE) rc = (NE == 1) ? launch(sep_grad_moments_kernel<4, 1, 1>) : launch(sep_grad_moments_kernel<4, 1, 2>);
                 else rc = (NA == 1) ? launch(sep_grad_moments_kernel<4, 1>) : launch(sep_grad_moments_kernel<4, 2>);
                 if (rc) return rc;
                 g.sepdone = sep_flags;

@@ -59,12 +59,14 @@ struct SepGradArgs {
 
 __host__ __device__ inline int sep_grad_point_words(int D, int NX, int K) {
     // wt | v = (1, u_0 .., nu_x ..) | powers x_d^e, e = 0 .. K;  odd stride: the four points of a k-step fall on distinct banks
-    const int n = 1 + (1 + D + NX) + D * (K + 1);
+    const int n = 1 + (1 + D + NX) + D * (K + 1) + 1;          // ... | one zero (what masked-out lanes multiply by)
     return n | 1;
 }
 
 // ------------------------------------------------------------------------------------------
-template <int DP, int NA>
+// NA: blocks of 16 weightings on the matrix cores; NE: weightings 16 NA .. 16 NA + NE - 1 accumulated by plain FMAs instead (a 17th
+// weighting -- config 4: 1 + 4 + 10 + 2 -- would otherwise cost a second, 94 % empty, A block: twice the matrix instructions).
+template <int DP, int NA, int NE = 0>
 __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_grad_moments_kernel(const SepGradArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = sep_grad_waves(DP), NT = 64 * NW, NB = kSepGradBlocks;
@@ -164,6 +166,21 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
         selA[ia][0] = (r < nW) ? s1 : -1;
         selA[ia][1] = s2;
     }
+    // the extra weightings (wave-uniform selectors)
+    int selE[NE > 0 ? NE : 1][2];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int r = NA * 16 + e;
+        int s1 = 0, s2 = 0;
+        if (r >= 1 && r <= D) s1 = r;
+        else if (r > D && r < 1 + D + D * (D + 1) / 2) {
+            int k = r - 1 - D, d = 0;
+            while (k >= D - d) { k -= D - d; ++d; }
+            s1 = 1 + d; s2 = 1 + d + k;
+        } else if (r >= 1 + D + D * (D + 1) / 2 && r < nW) s1 = 1 + D + (r - 1 - D - D * (D + 1) / 2);
+        selE[e][0] = (r < nW) ? s1 : -1;
+        selE[e][1] = s2;
+    }
 
     // ---- tasks (off-diagonal pair, side): two rounds of wavefronts per pair pair, then the combination ----------------
     for (int pq0 = 0; pq0 < Poff; pq0 += NW / 2) {
@@ -181,15 +198,35 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
             const double* Z = s_Z + pq * DP * DP;
             const double* il = s_ils2 + co * E;
             const double lv = p.logvar[co];
-            int expB[NB];
+            const int K1 = K + 1;
+            // word offsets of the lane's monomial factors inside a point's table (loop-invariant: one address add per LDS read in
+            // the k-steps; forming them from the packed exponents there cost 3 - 4 integer instructions per read, 122 VALU
+            // instructions per 4-point step by the counters against ~16 matrix instructions)
+            const int zslot = 1 + NV + D * K1;                 // the zero of a point's table
+            int offB[NB][DP];
 #pragma unroll
-            for (int ib = 0; ib < NB; ++ib) expB[ib] = s_me[ib * 16 + r16];
+            for (int ib = 0; ib < NB; ++ib) {
+                const int ex = s_me[ib * 16 + r16];
+#pragma unroll
+                for (int d = 0; d < DP; ++d) offB[ib][d] = 1 + NV + d * K1 + ((ex >> (8 * d)) & 255);
+                if (ib * 16 + r16 >= C) offB[ib][0] = zslot;      // monomial slots past the degree's count contribute nothing
+            }
+            // weightings: wt * v[s1] * v[s2]; rows past the last weighting read the zero
+            int offA[NA][2], offE[NE > 0 ? NE : 1][2];
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia) { offA[ia][0] = selA[ia][0] >= 0 ? 1 + selA[ia][0] : zslot; offA[ia][1] = 1 + selA[ia][1]; }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { offE[e][0] = selE[e][0] >= 0 ? 1 + selE[e][0] : zslot; offE[e][1] = 1 + selE[e][1]; }
             mfma_d4 acc[NA][NB];
 #pragma unroll
             for (int ia = 0; ia < NA; ++ia)
 #pragma unroll
                 for (int ib = 0; ib < NB; ++ib) acc[ia][ib] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-            const int K1 = K + 1;
+            double accE[NE > 0 ? NE : 1][NB];
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib) accE[e][ib] = 0.0;
             for (int c0 = 0; c0 < N; c0 += 64) {
                 // -- per-point tables (lane = point) --
                 {
@@ -206,6 +243,7 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
                         ks = fma(nu[d], x[d], ks);
                     }
                     tp[1] = 1.0;
+                    tp[zslot] = 0.0;
 #pragma unroll
                     for (int d = 0; d < DP; ++d) if (d < D) tp[2 + d] = x[d];
                     for (int xx = 0; xx < NX; ++xx) {
@@ -241,31 +279,42 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
                     }
                 }
                 wave_lds_sync();
-                // -- 16 k-steps of 4 points: F^T Phi on the matrix cores --
-#pragma unroll 2
-                for (int ks4 = 0; ks4 < 16; ++ks4) {
-                    const double* tp = tabw + (size_t)(ks4 * 4 + kq) * PS;
-                    const double wt = tp[0];
-                    double aF[NA];
+                // -- 16 k-steps of 4 points: F^T Phi on the matrix cores.  Branch-free for a compile-time block count: every LDS
+                //    read of a step can be in flight before the first product (the first version branched per block and per
+                //    factor, each read followed by its wait: 15 % matrix-pipe and 32 % vector utilisation by the counters) --
+                auto ksteps = [&](auto nbc) {
+                    constexpr int NBK = decltype(nbc)::value;
+#pragma unroll 1
+                    for (int ks4 = 0; ks4 < 16; ++ks4) {
+                        const double* tp = tabw + (size_t)(ks4 * 4 + kq) * PS;
+                        const double wt = tp[0];
+                        double aF[NA], aE[NE > 0 ? NE : 1], phi[NBK];
 #pragma unroll
-                    for (int ia = 0; ia < NA; ++ia) {
-                        const int s1 = selA[ia][0];
-                        aF[ia] = (s1 >= 0) ? wt * tp[1 + (s1 >= 0 ? s1 : 0)] * tp[1 + selA[ia][1]] : 0.0;
-                    }
-                    const double* pw = tp + 1 + NV;
+                        for (int ia = 0; ia < NA; ++ia) aF[ia] = wt * tp[offA[ia][0]] * tp[offA[ia][1]];
 #pragma unroll
-                    for (int ib = 0; ib < NB; ++ib) {
-                        if (ib < nb) {
-                            const int ex = expB[ib];
-                            double phi = pw[ex & 255];
+                        for (int e = 0; e < NE; ++e) aE[e] = wt * tp[offE[e][0]] * tp[offE[e][1]];
 #pragma unroll
-                            for (int d = 1; d < DP; ++d)
-                                if (d < D) phi *= pw[d * K1 + ((ex >> (8 * d)) & 255)];
-                            phi = (ib * 16 + r16 < C) ? phi : 0.0;
+                        for (int ib = 0; ib < NBK; ++ib) {
+                            phi[ib] = tp[offB[ib][0]];
 #pragma unroll
-                            for (int ia = 0; ia < NA; ++ia) acc[ia][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[ia], phi, acc[ia][ib], 0, 0, 0);
+                            for (int d = 1; d < DP; ++d) phi[ib] *= tp[offB[ib][d]];
+                        }
+#pragma unroll
+                        for (int ib = 0; ib < NBK; ++ib) {
+#pragma unroll
+                            for (int ia = 0; ia < NA; ++ia) acc[ia][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[ia], phi[ib], acc[ia][ib], 0, 0, 0);
+#pragma unroll
+                            for (int e = 0; e < NE; ++e) accE[e][ib] = fma(aE[e], phi[ib], accE[e][ib]);
                         }
                     }
+                };
+                static_assert(NB == 5, "block-count dispatch below");
+                switch (nb) {
+                    case 1: ksteps(std::integral_constant<int, 1>{}); break;
+                    case 2: ksteps(std::integral_constant<int, 2>{}); break;
+                    case 3: ksteps(std::integral_constant<int, 3>{}); break;
+                    case 4: ksteps(std::integral_constant<int, 4>{}); break;
+                    default: ksteps(std::integral_constant<int, 5>{}); break;
                 }
                 wave_lds_sync();
             }
@@ -278,6 +327,16 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (ia * 16 + 4 * r + kq < nW) tabw[(size_t)(ia * 16 + 4 * r + kq) * (16 * NB) + ib * 16 + r16] = acc[ia][ib][r];
+                    }
+            // extra weightings: a lane holds the sum over ITS quarter of the points (kq) -> the four quarters, fixed order
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib)
+                    if (ib < nb && NA * 16 + e < nW) {
+                        const double h = swap_add<16>(accE[e][ib], accE[e][ib]);
+                        const double tot = swap_add<32>(h, h);
+                        if (kq == 0) tabw[(size_t)(NA * 16 + e) * (16 * NB) + ib * 16 + r16] = tot;
                     }
         }
         __syncthreads();
