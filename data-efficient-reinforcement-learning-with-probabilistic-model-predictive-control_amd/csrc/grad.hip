@@ -149,10 +149,12 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     // Off-diagonal pairs in separable form on the matrix cores (grad_sep_kernel.h) where the Taylor degree allows; the
     // element-wise kernels below skip the pairs it wrote.  Monomial tables: those of the forward kernel (ensure_monomials).
     g.sepdone = nullptr;
-    // Measured (round 3, rocprofv3): config 2 (N = 200) 0.78 ms for this kernel + 1.25 ms element-wise diagonal pairs = the 2.0 ms the
-    // element-wise pass takes alone (its per-(candidate, step) set-up does not shrink with the pairs); config 4 (N = 1000) 128 + 495 ms
-    // against 1145 ms.  Hence from N = 256 on unless forced (option "grad_separable": 0 never, 1 auto, 2 always).
-    if (h->opt_grad_sep != 0 && (N >= 256 || h->opt_grad_sep == 2) && D >= 2 && D <= 4 && h->mono_D == D && h->mono_CM > 0 &&
+    // Measured (round 3, objective + gradient per launch, separable / element-wise): config 1 (N = 50, B = 256) 0.77 / 0.66 ms,
+    // config 2 (N = 200) B = 256: 2.22 / 2.57 ms, B = 1: 0.65 / 0.61 ms (25 workgroups: the element-wise pass spreads its pair
+    // groups over the idle CUs), config 3 (N = 500, B = 1024) 18.9 / 24.8 ms, config 4 (N = 1000, B = 2048): 69 ms for the 6
+    // off-diagonal pairs against ~650 ms.  Hence from N = 128 on when the items fill the chip (option "grad_separable": 0 never,
+    // 1 auto, 2 always).
+    if (h->opt_grad_sep != 0 && ((N >= 128 && (long long)B * H >= h->num_cu) || h->opt_grad_sep == 2) && D >= 2 && D <= 4 && h->mono_D == D && h->mono_CM > 0 &&
         h->opt_force_path == 0) {
         int kmax = 0;
         for (int k = 1; k <= h->sep_kmax && k <= kMaxTaylor; ++k)

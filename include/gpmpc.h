@@ -118,13 +118,17 @@ int gpmpc_read_factors(gpmpc_t* h, double* iK_dst_dev, double* beta_dst_dev, voi
  * lane in the pairwise pass of the rollout kernel), "grad_cols_per_lane" (same for the gradient's moment pass),
  * "exact_dim" (2: never the compile-time-D kernel instantiation),
  * "incremental" (0/1, default 1), "refresh_every" (default 32), "fused_prepare" (0/1, default 1: memories of
- * up to 256 points are factorised by one launch, one workgroup per GP; 0 = the panel-by-panel path),
+ * up to 240 points (the measured crossover) are factorised by one launch, one workgroup per GP; 0 = the panel-by-panel path),
  * and, for memories of "outer_min_n" (default 640, the measured crossover) points and more (defaults = the shipped path,
  * the others are A/B and test hooks):
  * "outer_block" (1; 0: 32-wide panels only), "tile128" (1: 128 x 128 tiles with 8 wavefronts for the tiled
  * products; 0: 64 x 64), "outer2" (2: binary outer levels of the trailing update up to 128 * 2^value columns),
  * "block128" (1: a whole 128-column outer panel in two launches; 0: 32-column panels), "inner_left" (1: those
- * panels left-looking inside the outer panel; 0: right-looking). */
+ * panels left-looking inside the outer panel; 0: right-looking).
+ * Round 3: "pair_tiles" (0 auto / 1 always / 2 never: the batch-major rollout path -- one set of launches per horizon
+ * step, workgroups own 128 x 128 tiles of T_a and loop over candidates; auto: D <= 4, 4 D N^2 >= 6e6, B >= 2 x CUs),
+ * "tile_chunk" (candidates per tile workgroup, 0 = chosen to fill the last round), "tile_overlap" (1: point pass on a side
+ * stream), "grad_separable" and "grad_tiles" (0 never / 1 auto / 2 always: see gpmpc_rollout_grad). */
 int gpmpc_set_option(gpmpc_t* h, const char* name, long long value);
 
 /*
@@ -177,10 +181,13 @@ int gpmpc_argmin(gpmpc_t* h, const double* J_dev, int B, long long first_global_
  * scipy as `jac` (:132-139, :285).  Three launches on `stream`: the forward rollout (as gpmpc_rollout),
  * the pairwise moment pass (one workgroup per candidate and horizon step) and the reverse sweep.
  * clip_lower_bound_cost_to_0 clips the value only (the reference's clamp passes the gradient through).
- * mu_out_dev / Sig_out_dev / cost_mu_out_dev / cost_var_out_dev as in gpmpc_rollout (nullable).  Supported for D <= 8 and A (+1 with
- * time) <= 6; memories whose per-point arrays exceed the LDS take a streaming moment pass (N up to ~15 000 at D = 4,
- * ~2 000 at D = 8: the column-factor array and the point chunks must fit); otherwise GPMPC_ERR_LIMIT (callers then
- * difference gpmpc_rollout).
+ * mu_out_dev / Sig_out_dev / cost_mu_out_dev / cost_var_out_dev as in gpmpc_rollout (nullable).  Supported for D <= 8 with A (+1 with
+ * time) <= 6 and for 8 < D <= 16 (matrix-core moment pass + pair-walking sweep: config 5); memories whose per-point arrays
+ * exceed the LDS take a streaming moment pass (N up to ~15 000 at D = 4, ~2 000 at D = 8: the column-factor array and the
+ * point chunks must fit); otherwise GPMPC_ERR_LIMIT (callers then difference gpmpc_rollout).  For D <= 4 the moment pass is
+ * split by pair kind where that pays: off-diagonal pairs in separable form on the matrix cores (option "grad_separable"),
+ * diagonal pairs batch-major over all (candidate, step) items at large N x large B (option "grad_tiles"); the results do
+ * not depend on the split beyond rounding (1e-7 of the gradient's scale against the reference's autograd in every form).
  */
 int gpmpc_rollout_grad(gpmpc_t* h, const double* actions_dev, const double* mu0_host, const double* S0_host,
                        int B, int H, int A, int include_time, double time0, double* J_out_dev, double* grad_out_dev,
