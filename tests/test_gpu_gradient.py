@@ -328,3 +328,36 @@ def test_tile_moments_of_the_diagonal_pairs(engine, N, D, A, H, B, tm, s0, sep):
         J, g, *_ = adjoint.lcb_and_gradient(f, w.actions[b], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
         assert rel_err(res[2][b], g) < 1e-7
     assert rel_err(res[2], res[0]) < 1e-7
+
+
+def test_config4_full_batch_gradient_through_the_split_moment_pass(engine):
+    """BASELINE configs[3] at its full batch (N = 1000, D = 4, A = 2, H = 30, B = 2048): here the defaults pick the batch-major
+    forward, the separable off-diagonal moments and the tile moments of the diagonal pairs.  First / middle / last candidates
+    against the same candidates in a 3-candidate launch with every round-3 path switched off (element-wise streaming moment
+    pass, fused forward), and the full launch twice (bitwise)."""
+    n, d, a, h, _, tm = synth.SHAPES["c4"]
+    B = 2048
+    w = synth.make_workload(n, d, a, h, B, include_time=tm, seed=5)
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    engine.set_cost(w.target, w.W, w.W_T, w.kappa)
+    out = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+    assert engine.last_rollout_path == 2
+    g1 = out["grad"].cpu().numpy()
+    J1 = out["J"].cpu().numpy()
+    g2 = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)["grad"].cpu().numpy()
+    assert np.array_equal(g1, g2)
+    assert np.isfinite(g1).all() and np.isfinite(J1).all()
+    pick = [0, B // 2 + 1, B - 1]
+    for name, v in (("grad_tiles", 0), ("grad_separable", 0), ("pair_tiles", 2)):
+        engine.set_option(name, v)
+    try:
+        ref = engine.rollout_grad(w.actions[pick], w.mu0, w.S0, w.include_time, w.time0)
+        assert engine.last_rollout_path != 2
+    finally:
+        for name, v in (("grad_tiles", 1), ("grad_separable", 1), ("pair_tiles", 0)):
+            engine.set_option(name, v)
+    e = rel_err(g1[pick], ref["grad"].cpu().numpy())
+    from helpers import record
+    record("config4_full_batch_gradient[N1000,B2048]", grad_vs_elementwise=e)
+    assert e < 1e-7
+    assert np.allclose(J1[pick], ref["J"].cpu().numpy(), rtol=1e-7, atol=0)       # fused vs batch-major forward: two summation orders
