@@ -28,6 +28,7 @@ int launch_rollout_grad_wide(Handle* h, RolloutArgs& a, double* grad_out, hipStr
     w.actions = a.actions; w.mu = a.mu_out; w.Sig = a.Sig_out; w.cv = a.cv_out;
     w.mom = h->gradws.p; w.grad = grad_out; w.kappa = a.kappa; w.use_constraints = a.use_constraints;
     w.N = N; w.D = D; w.A = A; w.E = E; w.H = H; w.B = B; w.include_time = a.include_time; w.time0 = a.time0; w.NSP = NSP;
+    w.xrange = h->xrange.p; w.force_path = h->opt_force_path;
     {
         auto kern = wide_pair_moments_kernel<16>;
         rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));

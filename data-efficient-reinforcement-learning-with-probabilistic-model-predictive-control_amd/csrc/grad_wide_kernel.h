@@ -30,7 +30,7 @@
 
 namespace gpmpc_hip {
 
-constexpr int kWideThreads = 256;      // moment pass: 4 wavefronts per (pair, step, candidate)
+constexpr int kWideThreads = 512;      // moment pass: 8 wavefronts per (pair, step, candidate), two per SIMD
 constexpr int kWideSweepThreads = 512;     // 256 VGPRs per thread: at 1024 threads the kernel spilled 46 VGPRs and 204 SGPRs
 constexpr int kWidePairWaves = 4;      // sweep: wavefronts that work on pairs concurrently (LDS scratch each)
 
@@ -54,12 +54,18 @@ struct WideArgs {
     int include_time;
     double time0;
     int NSP;
+    const double* xrange;   // (2, E) per-dimension min | max of the memory points
+    int force_path;         // 1: direct exp everywhere (tests)
 };
 
 __host__ __device__ inline int wide_nsp(int D, int NX) { return rnd2(1 + D + D * D + NX); }
 
+constexpr int kWideStageRows = 64;     // rows per staged chunk (two buffers)
+constexpr int kWideRS = 18;            // row record: factor | beta | u (16)
+constexpr int kWideFold = 2 * 256 + 16 + 16 * 16 + 16;     // per wavefront: V tile | w tile | c_j | extra inputs of the 16 columns | column factors
+
 struct WideMomLayout {
-    int aug, Z, m, ila, ilb, ka, kb, exptab, fold, tot, total;
+    int aug, Z, m, ila, ilb, ka, kb, exptab, fold, tot, etab, stage, flag, total;
 };
 
 __host__ __device__ inline WideMomLayout make_wide_mom_layout(int N, int D, int E, int NSP) {
@@ -73,8 +79,12 @@ __host__ __device__ inline WideMomLayout make_wide_mom_layout(int N, int D, int 
     L.ilb = o;    o += rnd2(E);
     L.ka = o;     o += rnd2(N);
     L.kb = o;     o += rnd2(N);
-    L.fold = o;   o += 4 * (2 * 256 + 16 + 16 * 16);          // per wavefront: V tile | w tile | c_j | extra inputs of the 16 columns
-    L.tot = o;    o += 4 * NSP;
+    L.fold = o;   o += (kWideThreads / 64) * kWideFold;
+    L.etab = o;   o += 2 * kTableHalf + 2;                    // exp(n / 128), |n| <= 1024: the tabulated form of the forward kernel
+    // row records of a 64-row chunk, double-buffered; the per-wavefront totals of the epilogue reuse the region
+    const int st = 2 * kWideStageRows * kWideRS, tt = (kWideThreads / 64) * NSP;
+    L.stage = o;  L.tot = o;  o += rnd2(st > tt ? st : tt);
+    L.flag = o;   o += 2;
     L.total = o;
     return L;
 }
@@ -103,12 +113,16 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
     double* s_ilb = smem + L.ilb;
     double* s_ka = smem + L.ka;
     double* s_kb = smem + L.kb;
-    double* s_fold = smem + L.fold + wave * (2 * 256 + 16 + 16 * 16);
+    double* s_fold = smem + L.fold + wave * kWideFold;
     double* s_tot = smem + L.tot;
+    double* s_etab = smem + L.etab + kTableHalf;           // centre of the table
+    double* s_stage = smem + L.stage;
+    int* s_flag = reinterpret_cast<int*>(smem + L.flag);
 
     const double* mu = p.mu + ((size_t)c * (H + 1) + t) * D;
     const double* Sg = p.Sig + ((size_t)c * (H + 1) + t) * D * D;
     for (int i = tid; i < 64; i += NT) s_exptab[i] = kExp2Tab[i];
+    for (int i = tid; i <= 2 * kTableHalf; i += NT) s_etab[i - kTableHalf] = exp((double)(i - kTableHalf) * 0.0078125);
     for (int e = tid; e < E; e += NT) {
         double v;
         if (e < D) v = mu[e];
@@ -135,8 +149,21 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
             s_Z[i * 16 + j] = z;
             s_Z[256 + j * 16 + i] = z;
         }
+        // |u_i^T Z w_j| <= sum_dd' |Z_dd'| umax_d wmax_d' over the data range of the memory points: within the table's range the
+        // pair takes the staged, tabulated form below (as rollout_stream_kernel.h), beyond it the direct exponential
+        double cpart = 0.0;
+        for (int idx = lane; idx < D * D; idx += 64) {
+            const int i = idx / D, j = idx - i * D;
+            const double mi = mu[i], mj = mu[j];
+            const double ui = fmax(fabs(p.xrange[i] - mi), fabs(p.xrange[E + i] - mi)) * s_ila[i];
+            const double wj = fmax(fabs(p.xrange[j] - mj), fabs(p.xrange[E + j] - mj)) * s_ilb[j];
+            cpart = fma(fabs(s_aug[i * LD + D + j]) * ui, wj, cpart);
+        }
+        const double cmax = wave_sum(cpart);
+        if (lane == 0) s_flag[0] = (p.force_path != 1 && cmax <= kTableMaxArg) ? 1 : 0;
     }
     __syncthreads();
+    const bool use_table = __builtin_amdgcn_readfirstlane(s_flag[0]) != 0;
     // per-point log-factors of both sides:  k' = log var - sum_e nu_e^2 / (2 l_e^2) + x^T Z x / 2,  x = nu / l^2 (state part)
     for (int pt = tid; pt < N; pt += NT) {
         double nu[DP];
@@ -176,7 +203,219 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
     double* f_w = s_fold + 256;            // [col][dim]   column-side monomial vector x_j = nu_j / l^2
     double* f_c = s_fold + 512;            // [col]
     double* f_x = s_fold + 528;            // [col][extra input] nu_jx
+    double* f_cf = s_fold + 784;           // [col] column factor (tabulated form)
 
+    // the 16 columns of a tile folded into the moments (lanes own entries); f_c, f_V, f_w, f_x hold the tile
+    auto fold_tile = [&](int orient, const double* il_r, const double* il_c) {
+        if (orient == 0) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = lane * 4 + k, m_ = e >> 4, n_ = e & 15;
+                double s = 0.0;
+                _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) {
+                    const double cj = f_c[cc], wm = f_w[cc * 16 + m_], wn = f_w[cc * 16 + n_];
+                    s = fma(cj * wm, wn, s);
+                    s = fma(f_V[cc * 16 + m_], wn, s);
+                    s = fma(wm, f_V[cc * 16 + n_], s);
+                    if (diag) s = fma(cj * wm, wn, s);            // symmetric pair: the row-side term equals the column-side one
+                }
+                tP2[k] += s;
+            }
+            if (lane < 16) {
+                double s = 0.0;
+                _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s += f_V[cc * 16 + lane] + f_c[cc] * f_w[cc * 16 + lane];
+                tP1 += s;
+            }
+            if (lane < NX) {
+                double s = 0.0;
+                _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * 16 + lane], s);
+                tPe += s * (il_c[D + lane] + (diag ? il_r[D + lane] : 0.0));
+            }
+            if (lane == 0) {
+                double s = 0.0;
+                _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s += f_c[cc];
+                tW += s;
+            }
+        } else {
+            // other orientation: its column sums are the row sums r_i of the pair; columns here are side-a points (u)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = lane * 4 + k, m_ = e >> 4, n_ = e & 15;
+                double s = 0.0;
+                _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc] * f_w[cc * 16 + m_], f_w[cc * 16 + n_], s);
+                tP2[k] += s;
+            }
+            if (lane < NX) {
+                double s = 0.0;
+                _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * 16 + lane], s);
+                tPe += s * il_c[D + lane];
+            }
+        }
+    };
+    // the column tile's vectors: x_j (16 values per column) and the extra inputs -> fold scratch
+    auto load_columns = [&](int ct, const double* il_c) {
+        for (int k = lane; k < 256; k += 64) {
+            const int cc = k >> 4, d = k & 15;
+            int jj = ct * 16 + cc;
+            jj = jj < N ? jj : N - 1;
+            f_w[k] = (d < D) ? (p.Xt[(size_t)d * N + jj] - s_m[d]) * il_c[d] : 0.0;
+        }
+        for (int k = lane; k < 16 * NX; k += 64) {
+            const int cc = k / NX, x = k - cc * NX;
+            int jj = ct * 16 + cc;
+            jj = jj < N ? jj : N - 1;
+            f_x[cc * 16 + x] = p.Xt[(size_t)(D + x) * N + jj] - s_m[D + x];
+        }
+    };
+
+    if (use_table) {
+        // ---- staged, tabulated form.  E_ij = wr_i wc_j e^{c_ij} with wr_i = beta_ri e^{k_ri} in the row record and wc_j applied to
+        // the column sums (diagonal pairs: (beta_ri beta_cj - iK_ij) e^{k_ri} e^{k_cj} e^{c_ij}); e^c = T[n] P_5(r) as in the forward
+        // kernel.  The four wavefronts walk the rows together: 64-row chunks of row records {wr | beta | u (16)} are staged in LDS
+        // (double-buffered, one barrier per chunk) and shared by the four column tiles in flight; operands of both matrix products
+        // are LDS reads, nothing is fetched from global memory inside the tile loop except iK of a diagonal pair.
+        constexpr int RSW = kWideRS, CHW = kWideStageRows;
+        const int nchunk = (N + CHW - 1) / CHW;
+        const int nsweep = (NT16 + NW - 1) / NW;
+        constexpr double kShift = 52776558133248.0;                                     // 1.5 * 2^45: see block_mfma_table
+        for (int orient = 0; orient < (diag ? 1 : 2); ++orient) {
+            const int rs = orient ? b : a, cs_ = orient ? a : b;
+            const double* il_r = orient ? s_ilb : s_ila;
+            const double* il_c = orient ? s_ila : s_ilb;
+            const double* k_r = orient ? s_kb : s_ka;
+            const double* k_c = orient ? s_ka : s_kb;
+            const double* Zu = s_Z + (orient ? 256 : 0);
+            const double* beta_r = p.beta + (size_t)rs * N;
+            const double* beta_c = p.beta + (size_t)cs_ * N;
+            auto fill = [&](int ch, double* st) {
+                constexpr int TPR = NT / CHW, DPT = 16 / TPR;      // threads per row, dimensions per thread
+                const int row = tid / TPR, part = tid - row * TPR;
+                const int i = ch * CHW + row;
+                const bool in = i < N;
+                const int ic = in ? i : N - 1;
+                double* rec = st + (size_t)row * RSW;
+#pragma unroll
+                for (int k = 0; k < DPT; ++k) {
+                    const int d = part * DPT + k;
+                    rec[2 + d] = (in && d < D) ? (p.Xt[(size_t)d * N + ic] - s_m[d]) * il_r[d] : 0.0;
+                }
+                if (part == 0) {
+                    const double er = in ? fast_exp(k_r[ic], s_exptab) : 0.0;
+                    const double br = beta_r[ic];
+                    rec[0] = diag ? er : er * br;
+                    rec[1] = br;
+                }
+            };
+            for (int sw = 0; sw < nsweep; ++sw) {
+                const int ct = sw * NW + wave;
+                const bool act = ct < NT16;                       // wave-uniform; idle wavefronts still fill and meet the barriers
+                const int j = ct * 16 + col16;
+                const bool jin = act && j < N;
+                const int jc = (act && j < N) ? j : N - 1;
+                double hB[4] = {0.0, 0.0, 0.0, 0.0};
+                if (act) {
+                    load_columns(ct, il_c);
+                    wave_lds_sync();
+#pragma unroll
+                    for (int qd = 0; qd < 4; ++qd) {
+                        const int d = 4 * qd + grp;
+                        double h = 0.0;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) h = fma(Zu[d * 16 + e], f_w[col16 * 16 + e], h);
+                        hB[qd] = h;
+                    }
+                }
+                const double bcj = jin ? beta_c[jc] : 0.0;
+                const double ecj = jin ? fast_exp(k_c[jc], s_exptab) : 0.0;
+                const double colf = diag ? ecj : ecj * bcj;       // column factor of the sums (diagonal pair: beta_cj sits in the weight)
+                double csum0 = 0.0, csum1 = 0.0;
+                mfma_d4 vc = {0.0, 0.0, 0.0, 0.0};
+                __syncthreads();                                   // previous sweep done with the stage
+                fill(0, s_stage);
+                __syncthreads();
+                for (int ch = 0; ch < nchunk; ++ch) {
+                    if (ch + 1 < nchunk) fill(ch + 1, s_stage + ((ch + 1) & 1) * CHW * RSW);
+                    const double* st = s_stage + (ch & 1) * CHW * RSW;
+                    if (act) {
+#pragma unroll 1
+                        for (int rt = 0; rt < CHW / 16; rt += 2) {
+                            // two 16-row tiles per iteration: 8 independent evaluations of the exponential per lane
+                            const double* a0p = st + (size_t)(16 * rt + col16) * RSW + 2 + grp;
+                            const double* a1p = a0p + 16 * RSW;
+                            mfma_d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                            for (int qd = 0; qd < 4; ++qd) {
+                                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0p[4 * qd], hB[qd], c0, 0, 0, 0);
+                                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1p[4 * qd], hB[qd], c1, 0, 0, 0);
+                            }
+                            const double* w0 = st + (size_t)(16 * rt + grp) * RSW;      // row 16 rt + 4 r + grp: + 4 r RSW
+                            double wt[8], cv[8], nv[8], tv[8], qv[8];
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const double* q0 = w0 + (size_t)(4 * r) * RSW;
+                                const double* q1 = q0 + 16 * RSW;
+                                if (diag) {
+                                    const int i0 = ch * CHW + 16 * rt + 4 * r + grp, i1 = i0 + 16;
+                                    const double k0 = p.iK[((size_t)a * N + (i0 < N ? i0 : N - 1)) * N + jc];
+                                    const double k1 = p.iK[((size_t)a * N + (i1 < N ? i1 : N - 1)) * N + jc];
+                                    wt[r] = q0[0] * fma(q0[1], bcj, -k0);
+                                    wt[4 + r] = q1[0] * fma(q1[1], bcj, -k1);
+                                } else {
+                                    wt[r] = q0[0];
+                                    wt[4 + r] = q1[0];
+                                }
+                                cv[r] = c0[r];
+                                cv[4 + r] = c1[r];
+                            }
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) nv[e] = cv[e] + kShift;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) tv[e] = s_etab[(int)__double2loint(nv[e])];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) cv[e] -= nv[e] - kShift;
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) qv[e] = fma(cv[e], 1.0 / 120, 1.0 / 24);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) qv[e] = fma(qv[e], cv[e], 1.0 / 6);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) qv[e] = fma(qv[e], cv[e], 0.5);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) qv[e] = fma(qv[e], cv[e], 1.0);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) qv[e] = fma(qv[e], cv[e], 1.0);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) wt[e] *= tv[e];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) wt[e] *= qv[e];               // E_ij without the column factor
+                            csum0 += (wt[0] + wt[1]) + (wt[2] + wt[3]);
+                            csum1 += (wt[4] + wt[5]) + (wt[6] + wt[7]);
+                            if (orient == 0) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[r], w0[(size_t)(4 * r) * RSW + 2 + col16], vc, 0, 0, 0);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[4 + r], w0[(size_t)(16 + 4 * r) * RSW + 2 + col16], vc, 0, 0, 0);
+                            }
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (act) {
+                    double csum = (csum0 + csum1) * colf;
+                    csum += __shfl_xor(csum, 16, 64);
+                    csum += __shfl_xor(csum, 32, 64);
+                    if (grp == 0) { f_c[col16] = csum; f_cf[col16] = colf; }
+                    wave_lds_sync();
+                    if (orient == 0) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) f_V[(4 * r + grp) * 16 + col16] = vc[r] * f_cf[4 * r + grp];      // V[col = 4 r + grp][dim = col16]
+                    }
+                    wave_lds_sync();
+                    fold_tile(orient, il_r, il_c);
+                    wave_lds_sync();
+                }
+            }
+        }
+    } else
     for (int orient = 0; orient < (diag ? 1 : 2); ++orient) {
         // orient 0: rows are side a (u), columns side b (w), c_ij = u_i . (Z w_j); orient 1: rows side b, columns side a, Z^T
         const int rs = orient ? b : a, cs_ = orient ? a : b;
@@ -218,6 +457,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
             const double bcj = jin ? beta_c[jc] : 0.0;
             double csum = 0.0;
             mfma_d4 vc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
             for (int rt = 0; rt < NT16; ++rt) {
                 // A operand of the c tile: u_row[dim 4 qd + grp], row = rt * 16 + col16
                 const int ir = rt * 16 + col16;
@@ -270,7 +510,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                 for (int k = 0; k < 4; ++k) {
                     const int e = lane * 4 + k, m_ = e >> 4, n_ = e & 15;
                     double s = 0.0;
-                    for (int cc = 0; cc < 16; ++cc) {
+                    _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) {
                         const double cj = f_c[cc], wm = f_w[cc * 16 + m_], wn = f_w[cc * 16 + n_];
                         s = fma(cj * wm, wn, s);
                         s = fma(f_V[cc * 16 + m_], wn, s);
@@ -281,17 +521,17 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                 }
                 if (lane < 16) {
                     double s = 0.0;
-                    for (int cc = 0; cc < 16; ++cc) s += f_V[cc * 16 + lane] + f_c[cc] * f_w[cc * 16 + lane];
+                    _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s += f_V[cc * 16 + lane] + f_c[cc] * f_w[cc * 16 + lane];
                     tP1 += s;
                 }
                 if (lane < NX) {
                     double s = 0.0;
-                    for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * 16 + lane], s);
+                    _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * 16 + lane], s);
                     tPe += s * (il_c[D + lane] + (diag ? il_r[D + lane] : 0.0));
                 }
                 if (lane == 0) {
                     double s = 0.0;
-                    for (int cc = 0; cc < 16; ++cc) s += f_c[cc];
+                    _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s += f_c[cc];
                     tW += s;
                 }
             } else {
@@ -300,12 +540,12 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                 for (int k = 0; k < 4; ++k) {
                     const int e = lane * 4 + k, m_ = e >> 4, n_ = e & 15;
                     double s = 0.0;
-                    for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc] * f_w[cc * 16 + m_], f_w[cc * 16 + n_], s);
+                    _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc] * f_w[cc * 16 + m_], f_w[cc * 16 + n_], s);
                     tP2[k] += s;
                 }
                 if (lane < NX) {
                     double s = 0.0;
-                    for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * 16 + lane], s);
+                    _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * 16 + lane], s);
                     tPe += s * il_c[D + lane];
                 }
             }
@@ -313,6 +553,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
         }
     }
     // per-wavefront totals -> LDS -> fixed-order sum -> HBM
+    __syncthreads();                                   // s_tot shares its space with the stage
     {
         double* tw = s_tot + wave * NSP;
         for (int k = lane; k < NSP; k += 64) tw[k] = 0.0;

@@ -37,7 +37,7 @@ for (N, D, A, H, B, tm, s0) in [(40, 9, 2, 3, 2, False, 1e-6), (70, 12, 3, 2, 2,
 print("WIDE GRADIENT", "OK" if bad == 0 else f"FAILED ({bad})", flush=True)
 if "time" in sys.argv[1:]:
     import torch
-    for (N, B, H) in [(1024, 4, 2), (4096, 2, 2)]:
+    for (N, B, H) in [(1024, 4, 2), (4096, 16, 4)]:
         w = synth.make_workload(N, 16, 4, H, B, seed=81)
         eng.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
         eng.set_cost(w.target, w.W, w.W_T, w.kappa)
@@ -48,5 +48,6 @@ if "time" in sys.argv[1:]:
         torch.cuda.synchronize()
         tg = time.perf_counter() - t0
         ms, _ = eng.rollout_timed(w.actions, w.mu0, w.S0, 1)
-        print(f"N={N} D=16 H={H} B={B}: objective + gradient {tg * 1e3:.1f} ms, forward alone {ms:.1f} ms", flush=True)
+        print(f"N={N} D=16 H={H} B={B}: objective + gradient {tg * 1e3:.1f} ms, forward alone {ms:.1f} ms; moment pass + sweep "
+              f"{(tg * 1e3 - ms) / (B * H):.1f} ms per (candidate, step) item with the whole chip", flush=True)
 eng.close()
