@@ -153,6 +153,15 @@ def main():
 
     eng.prepare(X, Y, ls, osc, nz)
 
+    exchange_note = None
+    if args.exchange == "host" and torch.distributed.is_available() and torch.distributed.is_initialized():
+        # the host-side exchange needs a gloo group beside RCCL's; if this node cannot create one, gather over RCCL instead
+        try:
+            sharding.host_group(None)
+        except Exception as e:   # noqa: BLE001 -- any failure of the side group means: use the device collective
+            args.exchange = "rccl"
+            exchange_note = f"gloo side group unavailable ({type(e).__name__}): RCCL gather on the compute stream"
+
     # One step = rollout launch + cost/objective kernel + keep-the-best kernel (+ RCCL gather) + the winner's record
     # copied to the host.  The host reads the winner of step k after it has enqueued step k + 1 (two pinned buffers,
     # one event per step), so the GPU does not idle while Python prepares the next launches; every step's winner is
@@ -308,7 +317,7 @@ def main():
                        "N": N, "D": D, "A": A, "H": H, "B_per_gpu": Bg, "B_total": B_total,
                        "parallelism": f"candidates sharded x{world}, " + ("host-side exchange of the (J, idx, winner) records after the copy"
                                                                             if args.exchange == "host" else "RCCL gather of (J, idx, winner) only"),
-                       "exchange": args.exchange,
+                       "exchange": args.exchange, "exchange_note": exchange_note,
                        **({"engine_options": engine_options} if engine_options else {})},
             "roofline": {"bound": "valu_f64", "achieved": achieved_tflops, "peak": PEAK_F64_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F64_VECTOR_TFLOPS, "traffic": traffic,
