@@ -189,6 +189,19 @@ def test_device_resident_search_matches_a_host_loop_on_the_same_draws(engine, de
     # (elite means are summed in a different order: the refitted draws differ in the last bits, and so does J)
     assert abs(J_dev - best_J) <= 1e-9 * abs(best_J)
     assert np.max(np.abs(x_dev - best_x)) < 1e-9
+    # independent of the HIP rollout: the objective the numpy oracle gives the returned sequence (through the same action mapper),
+    # and the oracle's ranking of the first iteration's candidates (the draws of iteration 0 do not depend on any objective)
+    from helpers import factors_of
+    from oracle import gpmpc_oracle as orc
+    f = factors_of(w)
+    J_or = orc.evaluate_candidates(f, w, actions=to_model(np.asarray(x_dev)[None]))["J"][0]
+    assert abs(J_dev - J_or) <= 1e-8 * abs(J_or)
+    X0 = noise[0].copy()
+    X0[0] = first
+    J0_or = orc.evaluate_candidates(f, w, actions=to_model(X0))["J"]
+    J0_dev = engine.rollout(to_model(X0), w.mu0, w.S0, trajectories=False, stage_costs=False)["J"].cpu().numpy()
+    assert np.max(np.abs(J0_dev - J0_or)) <= 1e-8 * np.max(np.abs(J0_or))
+    assert J_dev <= np.min(J0_or) * (1 + 1e-8) + 1e-12          # never worse than the best of its own first iteration
     # and with its own Philox draws: reproducible for a seed, different for another, never worse than its warm start
     x1, J1 = engine.cem_search(w.mu0, w.S0, B, H, A, iters, n_elite, seed=11, first_candidate=first, **kw)
     x2, J2 = engine.cem_search(w.mu0, w.S0, B, H, A, iters, n_elite, seed=11, first_candidate=first, **kw)
