@@ -153,6 +153,47 @@ def test_memory_admission_growth_and_dummy_point():
     assert mem.get_mask_model_inputs().shape == (11,)
 
 
+@pytest.mark.parametrize("name", ["memory_trace", "memory_trace_time", "memory_trace_nocheck"])
+@pytest.mark.parametrize("as_numpy", [False, True])
+def test_memory_admission_rule_against_the_reference_trace(name, as_numpy):
+    """The admission rule (reference gp_memory.py:48-63) and the model-memory bookkeeping (:66-111): the package's
+    Memory replays the seeded stream the REFERENCE's Memory was run on (tools/gen_golden.py memory_trace_case) and must
+    admit exactly the same points and hand `prepare_inference` exactly the same (x, y) after every `prepare_for_model`.
+    `as_numpy`: run_env_function.py hands the predictions over as numpy arrays (iter_info.predicted_states[1])."""
+    from gp_mpc_amd.control_objects.memories.gp_memory import Memory
+    from gp_mpc_amd.config_classes import MemoryConfig
+    g = load(name)
+    D, A, it = int(g["D"]), int(g["A"]), bool(g["include_time"])
+    n = len(g["states"])
+    cfg = MemoryConfig(bool(g["check"]), list(g["thresholds_err"]), list(g["thresholds_std"]), points_batch_memory=16)   # grows twice
+    mem = Memory(cfg, dim_input=D + A + int(it), dim_state=D, include_time_model=it)
+    x0, y0 = mem.get()
+    assert np.array_equal(x0.numpy(), g["empty_x"]) and np.array_equal(y0.numpy(), g["empty_y"])
+    conv = (lambda v: np.asarray(v)) if as_numpy else (lambda v: torch.tensor(v, dtype=torch.float64))
+    snaps = []
+    t = lambda v: torch.tensor(v, dtype=torch.float64)
+    for k in range(n):
+        mem.add(t(g["states"][k]), t(g["actions"][k]), t(g["states_next"][k]), float(g["rewards"][k]), iter_ctrl=k,
+                predicted_state=conv(g["predicted"][k]) if g["has_pred"][k] else None,
+                predicted_state_std=conv(g["predicted_std"][k]) if g["has_std"][k] else None)
+        if (k + 1) % int(g["prepare_every"]) == 0:
+            mem.prepare_for_model()
+            x, y = mem.get()
+            snaps.append((mem.len_mem_model, x.numpy().copy(), y.numpy().copy()))
+    assert np.array_equal(mem.active_data_mask[:n], g["admitted"])
+    assert [s[0] for s in snaps] == list(g["snap_len"])
+    assert np.array_equal(snaps[0][1], g["snap_first_x"]) and np.array_equal(snaps[0][2], g["snap_first_y"])
+    assert np.array_equal(snaps[-1][1], g["final_x"]) and np.array_equal(snaps[-1][2], g["final_y"])
+    assert np.array_equal(mem.inputs[:n].numpy(), g["inputs"]) and np.array_equal(mem.iter_ctrls[:n].numpy(), g["iter_ctrls"])
+    if bool(g["check"]):
+        assert np.array_equal(mem.errors[:n].numpy(), g["errors"], equal_nan=True)
+        assert np.array_equal(mem.stds[:n].numpy(), g["stds"], equal_nan=True)
+    xt, yt = mem.get_memory_total()
+    assert np.array_equal(xt.numpy(), g["total_x"]) and np.array_equal(yt.numpy(), g["total_y"])
+    assert np.array_equal(mem.get_mask_model_inputs(), g["mask_model_inputs"])
+    assert mem.len_mem == int(g["len_mem"]) and mem.len_mem_last_processed == int(g["len_mem_last_processed"])
+
+
 def test_single_state_reward_matches_golden_rows():
     """Host get_reward / get_reward_terminal (logging path) vs the reference's trajectory rewards."""
     g = load("traj_c1")

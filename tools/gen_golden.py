@@ -273,6 +273,55 @@ def optimize_trace_case(name, w, restarts, np_seed, limit_action_change=False, m
     print(f"{name}: {len(seen)} evaluations over {restarts} restarts, J first {seen[0][1]:.10g} best {min(s[1] for s in seen):.10g}")
 
 
+def memory_trace_case(name, seed, D, A, include_time, n_add, prepare_every, thresholds_err, thresholds_std, check=True):
+    """The admission rule next to the path (gp_memory.py:31-64) and the model-memory bookkeeping (:66-111), run on the
+    reference's own Memory: a seeded stream of `add` calls -- predictions sometimes absent (the random-action phase,
+    run_env_function.py:26-27 with controller state None), errors / stds straddling the thresholds -- with
+    `prepare_for_model` every `prepare_every` adds.  Records per add the admission flag, errors and stds, and after every
+    prepare the model memory handed to `prepare_inference`."""
+    from rl_gp_mpc.config_classes.memory_config import MemoryConfig
+    from rl_gp_mpc.control_objects.memories.gp_memory import Memory
+    E = D + A + (1 if include_time else 0)
+    cfg = MemoryConfig(check_errors_for_storage=check, min_error_prediction_state_for_memory=list(thresholds_err),
+                       min_prediction_state_std_for_memory=list(thresholds_std), points_batch_memory=n_add + 8)
+    mem = Memory(cfg, dim_input=E, dim_state=D, include_time_model=include_time, step_model=1)
+    rng = np.random.default_rng(seed)
+    states = rng.uniform(0, 1, (n_add, D)); acts = rng.uniform(0, 1, (n_add, A))
+    nxt = states + 0.02 * rng.standard_normal((n_add, D))
+    # prediction = truth + an error whose scale sweeps two decades around the thresholds; stds likewise
+    scale = 10.0 ** rng.uniform(-1.5, 1.0, (n_add, 1))
+    pred = nxt + scale * np.asarray(thresholds_err)[None] * rng.standard_normal((n_add, D))
+    std = np.abs(10.0 ** rng.uniform(-1.0, 1.0, (n_add, 1)) * np.asarray(thresholds_std)[None] * rng.uniform(0.3, 1.0, (n_add, D)))
+    has_pred = rng.uniform(size=n_add) > 0.2
+    has_std = rng.uniform(size=n_add) > 0.2
+    has_pred[:3] = False; has_std[:3] = False            # the first (random) actions carry no prediction
+    rewards = rng.standard_normal(n_add)
+    snap_len, snap_x, snap_y, get_x, get_y = [], [], [], [], []
+    x0, y0 = mem.get()                                   # empty memory: the dummy point
+    for k in range(n_add):
+        mem.add(torch.tensor(states[k]), torch.tensor(acts[k]), torch.tensor(nxt[k]), float(rewards[k]), iter_ctrl=k,
+                predicted_state=torch.tensor(pred[k]) if has_pred[k] else None,
+                predicted_state_std=torch.tensor(std[k]) if has_std[k] else None)
+        if (k + 1) % prepare_every == 0:
+            mem.prepare_for_model()
+            x, y = mem.get()
+            snap_len.append(mem.len_mem_model); get_x.append(x.numpy().copy()); get_y.append(y.numpy().copy())
+    xt, yt = mem.get_memory_total()
+    d = dict(D=np.array(D), A=np.array(A), include_time=np.array(include_time), check=np.array(check),
+             thresholds_err=np.asarray(thresholds_err, float), thresholds_std=np.asarray(thresholds_std, float),
+             prepare_every=np.array(prepare_every), states=states, actions=acts, states_next=nxt, rewards=rewards,
+             predicted=pred, predicted_std=std, has_pred=has_pred, has_std=has_std,
+             empty_x=x0.numpy(), empty_y=y0.numpy(),
+             admitted=np.array(mem.active_data_mask[:n_add], dtype=bool), errors=mem.errors[:n_add].numpy(), stds=mem.stds[:n_add].numpy(),
+             inputs=mem.inputs[:n_add].numpy(), iter_ctrls=mem.iter_ctrls[:n_add].numpy(),
+             snap_len=np.array(snap_len), final_x=get_x[-1], final_y=get_y[-1],
+             snap_first_x=get_x[0], snap_first_y=get_y[0],
+             total_x=xt.numpy(), total_y=yt.numpy(), mask_model_inputs=np.array(mem.get_mask_model_inputs(), dtype=bool),
+             len_mem=np.array(mem.len_mem), len_mem_last_processed=np.array(mem.len_mem_last_processed))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **d)
+    print(f"{name}: {int(d['admitted'].sum())} of {n_add} points admitted, model memory {snap_len}")
+
+
 def factor_case(name, w):
     m = ref_model(w)
     d = inputs_dict(w)
@@ -299,6 +348,10 @@ def main():
             "optimize_trace": lambda: optimize_trace_case("optimize_trace", mk(50, 3, 1, 15, 1, seed=41), restarts=2, np_seed=321, maxfun=8),
             "optimize_trace_deriv": lambda: optimize_trace_case("optimize_trace_deriv", mk(50, 3, 2, 8, 1, seed=42), restarts=2, np_seed=322,
                                                                limit_action_change=True, maxfun=4),
+            # (vii) the memory-admission rule (gp_memory.py:48-63) + model-memory bookkeeping, pendulum thresholds
+            "memory_trace": lambda: memory_trace_case("memory_trace", 60, 3, 1, False, 48, 5, [3e-4] * 3, [3e-3] * 3),
+            "memory_trace_time": lambda: memory_trace_case("memory_trace_time", 61, 2, 2, True, 40, 7, [1e-3, 5e-4], [2e-3, 4e-3]),
+            "memory_trace_nocheck": lambda: memory_trace_case("memory_trace_nocheck", 62, 2, 1, False, 12, 4, [1e-3] * 2, [1e-3] * 2, check=False),
         }
         for name in (args.only if args.only is not None else big):
             big[name]()
