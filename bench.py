@@ -6,8 +6,8 @@
 
 A "step" is one pass of the hot path over one batch of candidate action sequences: one
 gpmpc_rollout launch (H-step moment-matched propagation + stage/terminal costs + LCB objective
-for every candidate, trajectories written to HBM) + the keep-the-best kernel (and, for N > 1, the RCCL
-gather of the per-rank records) + the winner's record copied to the host.  The host reads the winner of
+for every candidate, trajectories written to HBM) + the keep-the-best kernel (and, for N > 1, ONE RCCL
+all_gather of the per-rank [J, index, winning sequence] records over xGMI, on a side stream) + the winner's record copied to the host.  The host reads the winner of
 step k after enqueuing step k + 1, so launches overlap the previous step's kernels.  Default workload = BASELINE.json
 configs[1] (Pendulum scale: N=200 memory points, D=3, A=1, H=25, B=256 candidates, fp64) per GPU; candidates shard
 across ranks with no data-path collective.  Inputs are resident in HBM before the timed region.  `prepare` (K build
@@ -89,9 +89,10 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="override N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (exercises the N > 1 code path)")
-    ap.add_argument("--exchange", default="host", choices=["host", "rccl"],
-                    help="N > 1: how the per-rank winner records meet -- 'host': after the device-to-host copy, between the hosts "
-                         "(nothing on the GPU streams); 'rccl': one all_gather per step on the compute stream")
+    ap.add_argument("--exchange", default="rccl_side", choices=["rccl_side", "host", "rccl"],
+                    help="N > 1: how the per-rank winner records meet -- 'rccl_side' (default): one RCCL all_gather per step over xGMI "
+                         "on a side stream behind an event, the compute stream never waits for it; 'host': after the device-to-host "
+                         "copy, between the hosts over gloo (nothing on the GPU streams); 'rccl': the all_gather on the compute stream")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option for an A/B run (gpmpc_set_option; recorded in config.engine_options)")
@@ -132,7 +133,10 @@ def main():
     else:
         # c1 is the reference's own 1-restart case; as a throughput workload it is batched like c2
         B_total = (args.candidates_per_gpu or min(max(b, 256), 256 if args.workload in ("c1", "c2") else b)) * world
-    w = synth.make_workload(N, d, a, h, B_total, include_time=tm, seed=0)
+    # config 5 is generated from the seed of the full-size oracle fixture tests/golden/oracle_c5_h50.npz (same model, and its
+    # candidate is candidate 0 of the batch: synth draws the actions row-major), so the line carries a parity figure
+    C5_FIXTURE_SEED = 79
+    w = synth.make_workload(N, d, a, h, B_total, include_time=tm, seed=C5_FIXTURE_SEED if args.workload == "c5" else 0)
     _, D, A, E, H, _ = w.dims
     lo, hi = sharding.shard_bounds(B_total, world, rank)
     Bg = hi - lo                                   # this rank's candidates (rank 0 holds the largest slice)
@@ -154,32 +158,42 @@ def main():
     eng.prepare(X, Y, ls, osc, nz)
 
     exchange_note = None
-    if args.exchange == "host" and torch.distributed.is_available() and torch.distributed.is_initialized():
-        # the host-side exchange needs a gloo group beside RCCL's; if this node cannot create one, gather over RCCL instead
+    multi = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if args.exchange == "host" and multi:
+        # the host-side exchange needs a gloo group beside RCCL's; the ranks AGREE on whether it exists (a rank-local fallback
+        # would leave the ranks in different collectives): all_reduce(MIN) of a success flag over RCCL
         try:
             sharding.host_group(None)
-        except Exception as e:   # noqa: BLE001 -- any failure of the side group means: use the device collective
-            args.exchange = "rccl"
-            exchange_note = f"gloo side group unavailable ({type(e).__name__}): RCCL gather on the compute stream"
+            ok = 1.0
+        except Exception as e:   # noqa: BLE001 -- any failure of the side group on ANY rank means: use the device collective
+            ok = 0.0
+            exchange_note = f"gloo side group unavailable here ({type(e).__name__})"
+        flag = torch.tensor([ok], dtype=torch.float64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) < 1.0:
+            args.exchange = "rccl_side"
+            exchange_note = (exchange_note or "gloo side group unavailable on another rank") + ": RCCL gather on a side stream"
 
-    # One step = rollout launch + cost/objective kernel + keep-the-best kernel (+ RCCL gather) + the winner's record
-    # copied to the host.  The host reads the winner of step k after it has enqueued step k + 1 (two pinned buffers,
-    # one event per step), so the GPU does not idle while Python prepares the next launches; every step's winner is
-    # still delivered to the host inside the timed region.
-    bufs = {"out": None, "rec": None}
-    # The host-side exchange (a gloo all_gather of the 27-double records, N > 1) takes a few hundred microseconds of HOST time
-    # per step -- the order of a config-2 step.  Reading the winner TWO steps late instead of one gives the host two steps of
-    # slack for it; every step's winner is still delivered inside the timed region (the queue is drained before the clock stops).
-    depth = 2 if (args.exchange == "host" and torch.distributed.is_available() and torch.distributed.is_initialized()
-                  and torch.distributed.get_world_size() > 1) else 1
+    # One step = rollout launch + cost/objective kernel + keep-the-best kernel (+ the exchange of the per-rank records) + the
+    # winner's record copied to the host.  The host reads the winner of step k after it has enqueued step k + 1 (a ring of pinned
+    # buffers and device records, one event per step), so the GPU does not idle while Python prepares the next launches; every
+    # step's winner is still delivered to the host inside the timed region.  `closed_loop_ms_per_step` further down is the
+    # same step with the winner read BEFORE the next launch (what an MPC loop or a CEM iteration that needs the winner sees).
+    bufs = {"out": None}
+    # The host-side exchange (a gloo all_gather of the 27-double records, N > 1) costs HOST time per step (measured at world 8
+    # on CPU: profiles/r04_host_exchange_world8.json); reading the winner TWO steps late gives the host two steps of slack for
+    # it.  The default (RCCL on a side stream) and a single rank read one step late.
+    depth = 2 if (args.exchange == "host" and multi and torch.distributed.get_world_size() > 1) else 1
     pinned = [None] * (depth + 1)
+    records = [None] * (depth + 1)       # a record may still be read by the side stream's all_gather: never reuse it in flight
 
     def launch(k):
         out = bufs["out"] = eng.rollout(actions, w.mu0, w.S0, w.include_time, w.time0, out=bufs["out"])
-        pend = sharding.select_best_async(eng, out["J"], actions, lo, B_total, host_buffer=pinned[k % (depth + 1)], record=bufs["rec"],
+        slot = k % (depth + 1)
+        pend = sharding.select_best_async(eng, out["J"], actions, lo, B_total, host_buffer=pinned[slot], record=records[slot],
                                           exchange=args.exchange)
-        pinned[k % (depth + 1)] = pend.host
-        bufs["rec"] = pend.record
+        pinned[slot] = pend.host
+        records[slot] = pend.record
         return pend, out
 
     # Untimed pre-conditioning: the GPU needs a few tens of milliseconds of sustained load to reach its steady clocks
@@ -199,14 +213,18 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    inflight = []
+    inflight, read_host_s = [], []
     for k in range(args.steps):
         pend, out = launch(k)
         inflight.append(pend)
         if len(inflight) > depth:
-            best_J, best_i, best_act = inflight.pop(0).result()
+            p0 = inflight.pop(0)
+            best_J, best_i, best_act = p0.result()
+            read_host_s.append(p0.host_seconds)
     while inflight:
-        best_J, best_i, best_act = inflight.pop(0).result()
+        p0 = inflight.pop(0)
+        best_J, best_i, best_act = p0.result()
+        read_host_s.append(p0.host_seconds)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
@@ -216,6 +234,24 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+
+    # the same step with the winner read BEFORE the next launch is enqueued (depth 0): what a closed-loop user pays
+    closed_loop_ms = None
+    if est_step_ms < 1000.0:
+        n_cl = max(3, min(args.steps, 10))
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        tcl = time.perf_counter()
+        for k in range(n_cl):
+            pend, out = launch(k)
+            pend.result()
+        torch.cuda.synchronize()
+        closed_loop_ms = (time.perf_counter() - tcl) / n_cl * 1e3
+        if use_dist:
+            tcl_max = torch.tensor([closed_loop_ms], dtype=torch.float64, device=device)
+            dist.all_reduce(tcl_max, op=dist.ReduceOp.MAX)
+            closed_loop_ms = float(tcl_max.item())
 
     # prepare: once per control step, timed separately after the main loop (median of 5 after 1 warm-up).  `prepare_ms` is the
     # full factorisation (what the reference does every step, gp_mpc_controller.py:117), reuse switched off;
@@ -262,10 +298,13 @@ def main():
     # per-rank view for a multi-GPU line: every rank's slice and kernel time (a future SCALE line is diagnosable from it)
     per_rank = None
     if use_dist:
-        mine = torch.tensor([float(Bg), float(kernel_ms), float(elapsed_local / args.steps * 1e3)], dtype=torch.float64, device=device)
+        rh = np.array(read_host_s) * 1e3
+        mine = torch.tensor([float(Bg), float(kernel_ms), float(elapsed_local / args.steps * 1e3), float(np.median(rh)), float(np.max(rh))],
+                            dtype=torch.float64, device=device)
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
-        per_rank = [{"rank": r, "candidates": int(v[0].item()), "kernel_ms": float(v[1].item()), "ms_per_step": float(v[2].item())}
+        per_rank = [{"rank": r, "candidates": int(v[0].item()), "kernel_ms": float(v[1].item()), "ms_per_step": float(v[2].item()),
+                     "winner_read_host_ms_median": float(v[3].item()), "winner_read_host_ms_max": float(v[4].item())}
                     for r, v in enumerate(allr)]
 
     if rank == 0:
@@ -321,9 +360,13 @@ def main():
                                    f"B={B_total} total = {Bg}/GPU ({scaling} scaling) fp64 "
                                    f"(BASELINE.json configs[{list(synth.SHAPES).index(args.workload)}] shape)",
                        "N": N, "D": D, "A": A, "H": H, "B_per_gpu": Bg, "B_total": B_total,
-                       "parallelism": f"candidates sharded x{world}, " + ("host-side exchange of the (J, idx, winner) records after the copy"
-                                                                            if args.exchange == "host" else "RCCL gather of (J, idx, winner) only"),
+                       "parallelism": f"candidates sharded x{world}, " + {
+                           "host": "host-side (gloo) exchange of the (J, idx, winner) records after the copy",
+                           "rccl": "RCCL gather of (J, idx, winner) only, on the compute stream",
+                           "rccl_side": "RCCL gather of (J, idx, winner) only, over xGMI on a side stream behind an event"}[args.exchange],
                        "exchange": args.exchange, "exchange_note": exchange_note, "winner_read_steps_late": depth,
+                       # host time of reading one step's winner (event wait + exchange when it is host-side), rank 0, ms
+                       "winner_read_host_ms": {"median": float(np.median(read_host_s) * 1e3), "max": float(np.max(read_host_s) * 1e3)},
                        **({"engine_options": engine_options} if engine_options else {})},
             "roofline": {"bound": "valu_f64", "achieved": achieved_tflops, "peak": PEAK_F64_VECTOR_TFLOPS,
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F64_VECTOR_TFLOPS, "traffic": traffic,
@@ -358,6 +401,8 @@ def main():
                                  "shape are under profiles/); bound is fp64 VALU, not HBM, while the tables T_a are L2-resident "
                                  "(c1-c3: traffic_frac_of_hbm_peak ~ 0); at c4 (D N^2 / 2 x 8 B = 16 MB of T_a per candidate and "
                                  "step) they are re-streamed through the fabric: compare traffic_frac_of_hbm_peak with valu_busy_frac"},
+            # one step with the winner on the host BEFORE the next launch is enqueued (no pipelining across steps); max over ranks
+            "closed_loop_ms_per_step": closed_loop_ms,
             "prepare_ms": prepare_ms,
             "prepare_incremental_ms": prepare_incremental_ms,
             "control_step_ms": prepare_ms + elapsed / args.steps * 1e3,
@@ -376,8 +421,23 @@ def main():
         oracle_cost = P * N * N * H
         try:
             if oracle_cost > 3e9:
-                result["parity"] = {"skipped": "the CPU oracle needs minutes per candidate at this size; full-size parity of "
-                                               "this shape is tests/test_gpu_parity.py (oracle_c5_step / oracle_c5_traj fixtures)"}
+                # the CPU oracle needs an hour per candidate at this size: compare with its stored output (tools/gen_golden_c5.py
+                # --steps 50 --candidates 1, same seed) -- candidate 0 of rank 0's slice is the fixture's candidate
+                fx = dict(np.load(os.path.join(ROOT, "tests", "golden", "oracle_c5_h50.npz")))
+                same = (args.workload == "c5" and N == int(fx["N"]) and H == int(fx["H"]) and lo == 0 and
+                        np.allclose([w.X.sum(), w.Y.sum(), w.actions[:1].sum()], fx["x_checksum"], rtol=0, atol=1e-9))
+                if not same:
+                    result["parity"] = {"skipped": "no stored oracle output for this size (the full-size fixture is N = 4096, H = 50)"}
+                else:
+                    mu = out["mu"][0].cpu().numpy()
+                    Sg = out["Sig"][0].cpu().numpy()
+                    per_step = np.max(np.abs(Sg - fx["Sig"][0]), axis=(1, 2)) / np.max(np.abs(fx["Sig"][0]), axis=(1, 2))
+                    result["parity"] = {"max_abs_dmean": float(np.max(np.abs(mu - fx["mu"][0]))),
+                                        "max_rel_cov": float(np.max(np.abs(Sg - fx["Sig"][0])) / np.max(np.abs(fx["Sig"][0]))),
+                                        "max_rel_cov_per_step_worst": float(np.max(per_step)),
+                                        "max_rel_cov_steps_1_to_5": float(np.max(per_step[1:6])),
+                                        "max_rel_J": float(abs(out["J"][0].item() - float(fx["J"][0])) / abs(float(fx["J"][0]))),
+                                        "vs": "tests/golden/oracle_c5_h50.npz (CPU oracle, N = 4096, D = 16, H = 50), candidate 0"}
             else:
                 sub = [0, Bg // 2, Bg - 1] if oracle_cost < 1.5e8 else [Bg - 1]
                 f = orc.Factors(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)

@@ -42,6 +42,7 @@ SIGNATURES = {
     "gpmpc_read_factors": (C.c_int, [_P, _P, _P, _P]),
     "gpmpc_last_prepare_mode": (C.c_int, [_P]),
     "gpmpc_last_rollout_path": (C.c_int, [_P]),
+    "gpmpc_last_grad_path": (C.c_int, [_P]),
     "gpmpc_build_id": (C.c_char_p, []),
     "gpmpc_mll": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(_D), _P]),
     "gpmpc_set_option": (C.c_int, [_P, C.c_char_p, C.c_longlong]),
@@ -50,12 +51,14 @@ SIGNATURES = {
     "gpmpc_rollout_grad": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _P]),
     "gpmpc_rollout_timed": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _I, C.POINTER(C.c_float), _P]),
     "gpmpc_cem_search": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _D, _I, _I, C.c_ulonglong, _P, _I, _P, _P, _P, _P, _P]),
+    "gpmpc_cem_local": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _D, _I, _I, C.c_ulonglong, _P, _I, _P, _P, _P, _P, _P, _P]),
+    "gpmpc_cem_merge": (C.c_int, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "gpmpc_argmin_async": (C.c_int, [_P, _P, _I, C.c_longlong, _P, _I, _P, _P]),
     "gpmpc_argmin": (C.c_int, [_P, _P, _I, C.c_longlong, C.POINTER(_D), C.POINTER(C.c_longlong), _P]),
 }
 
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 
 def load(path=LIB_PATH):

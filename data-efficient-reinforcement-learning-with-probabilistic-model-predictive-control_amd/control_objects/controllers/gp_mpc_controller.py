@@ -369,13 +369,22 @@ class GpMpcController(BaseControllerObject):
         if isinstance(self.actions_mapper, DerivativeActionMapper):
             kw = dict(max_change=np.asarray(self.config.actions.max_change_action_norm, dtype=np.float64),
                       action_prev=self.actions_mapper.action_model_previous_iter.numpy())
-        seed = int(np.random.randint(0, 2 ** 62))
+        seed = int(np.random.randint(0, 2 ** 62))          # every rank seeds numpy identically: the same key everywhere
         tm = self.transition_model
         tm.set_cost(self.config.reward)
-        best_x, best_J = tm.engine.cem_search(
-            np.asarray(state_mu, dtype=np.float64), np.asarray(state_var, dtype=np.float64), B, H, A,
-            int(cc.cem_iterations), n_elite, seed=seed, include_time=tm.config.include_time_model,
-            time0=float(self.iter_ctrl), first_candidate=first, **kw)
+        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        if world > 1:
+            # candidates sharded over the ranks: each draws its slice from the shared Philox key, one elite merge per iteration
+            from ... import sharding
+            best_x, best_J = sharding.sharded_cem_search(
+                tm.engine, np.asarray(state_mu, dtype=np.float64), np.asarray(state_var, dtype=np.float64), B, H, A,
+                int(cc.cem_iterations), n_elite, seed=seed, include_time=tm.config.include_time_model,
+                time0=float(self.iter_ctrl), first_candidate=first, **kw)
+        else:
+            best_x, best_J = tm.engine.cem_search(
+                np.asarray(state_mu, dtype=np.float64), np.asarray(state_var, dtype=np.float64), B, H, A,
+                int(cc.cem_iterations), n_elite, seed=seed, include_time=tm.config.include_time_model,
+                time0=float(self.iter_ctrl), first_candidate=first, **kw)
         if not np.isfinite(best_J):
             raise FloatingPointError("no finite objective among the candidates")
         self.num_rollouts += B * int(cc.cem_iterations)
@@ -422,6 +431,14 @@ class GpMpcController(BaseControllerObject):
                 x0s.append(generate_mpc_action_init_frompreviousiter(self.actions_mpc_previous_iter, dim_action=A))
             else:
                 x0s.append(generate_mpc_action_init_random(len_horizon=H, dim_action=A))
+        # restarts sharded over the ranks (one process per GPU): every rank drew the SAME B starting points above (numpy's
+        # global generator, seeded identically by the launcher) and solves its contiguous slice; the winners meet in ONE
+        # all_gather of [fun, restart index, solution] below
+        from ... import sharding
+        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        rank = torch.distributed.get_rank() if world > 1 else 0
+        r_lo, r_hi = sharding.shard_bounds(B, world, rank)
+        B_all, x0s, B = B, x0s[r_lo:r_hi], r_hi - r_lo
         cond = threading.Condition()
         pending, results, state = {}, {}, {"running": B, "launches": 0, "error": None}
 
@@ -479,7 +496,26 @@ class GpMpcController(BaseControllerObject):
         opt_fun, best, best_i = np.inf, None, -1
         for i, res in enumerate(solved):               # the reference's keep-the-best rule, in restart order
             if res.fun < opt_fun or (best is None and np.isnan(res.fun)):
-                opt_fun, best, best_i = res.fun, res.x, i
+                opt_fun, best, best_i = res.fun, res.x, r_lo + i
+        if world > 1:
+            # a NaN adopted by a rank whose slice does not start at restart 0 must not win (reference rule: only the FIRST
+            # restart's NaN is adopted) -- such a slice contributes its best finite result, or nothing
+            if best is not None and np.isnan(opt_fun) and best_i != 0:
+                opt_fun, best, best_i = np.inf, None, -1
+                for i, res in enumerate(solved):
+                    if res.fun < opt_fun:
+                        opt_fun, best, best_i = res.fun, res.x, r_lo + i
+            n = H * A
+            rec = torch.zeros(2 + n, dtype=F64)
+            rec[0], rec[1] = (float(opt_fun), float(best_i)) if best is not None else (float("inf"), -1.0)
+            if best is not None:
+                rec[2:] = torch.as_tensor(np.asarray(best, dtype=np.float64))
+            dev = self.transition_model.engine.device
+            _, flat = sharding._gather_records(rec.to(dev))
+            host = flat.cpu().view(world, 2 + n)
+            opt_fun, best_i, win = sharding._winner_of(host, world, n, 1)
+            best = win.numpy().reshape(-1).copy()
+            self.candidates_final_J = None             # only this rank's slice was solved here
         self.best_candidate_index, self.best_candidate_J = best_i, float(opt_fun)
         out = self.evaluate_candidates(best[None], state_mu, state_var, trajectories=True)
         self._cache_trajectory(out, 0)

@@ -115,6 +115,8 @@ class _LockstepMll:
     batch over GPs).  If the batched call fails (a GP whose K is not positive definite at its trial point), the pending
     GPs are evaluated one by one so that only the failing GP sees the error."""
 
+    WAIT_LIMIT = 600.0
+
     def __init__(self, engine, X_dev, Y_dev, n_gp):
         import threading
         self.engine, self.X, self.Y = engine, X_dev, Y_dev
@@ -125,6 +127,16 @@ class _LockstepMll:
 
     def _flush(self):                                  # called with the lock held
         idx = sorted(self.pending)
+        try:
+            self._evaluate_pending(idx)
+        except BaseException as e:                     # anything outside the per-GP handling below (stacking, indexing, ...):
+            for i in idx:                              # every waiting GP gets the failure -- nobody may wait forever
+                self.results.setdefault(i, e if isinstance(e, Exception) else RuntimeError(repr(e)))
+        finally:
+            self.pending.clear()
+            self.cond.notify_all()
+
+    def _evaluate_pending(self, idx):
         ls = torch.stack([self.pending[i][0].reshape(-1) for i in idx])
         osc = torch.stack([self.pending[i][1].reshape(()) for i in idx])
         nz = torch.stack([self.pending[i][2].reshape(()) for i in idx])
@@ -143,16 +155,20 @@ class _LockstepMll:
                                        float(o["d_noise"][0]))
                 except Exception as e:
                     self.results[i] = e
-        self.pending.clear()
-        self.cond.notify_all()
 
     def evaluate(self, a, ls, osc, nz):
         with self.cond:
             self.pending[a] = (ls, osc, nz)
             if len(self.pending) == self.running:
                 self._flush()
+            waited = 0.0
             while a not in self.results:
-                self.cond.wait()
+                # a rendezvous that never completes (a sibling thread died outside `finished`) must not hang the training
+                # process: after WAIT_LIMIT seconds the evaluation fails and `train` reports TrainingFailed
+                if not self.cond.wait(timeout=5.0):
+                    waited += 5.0
+                    if waited >= self.WAIT_LIMIT:
+                        raise TimeoutError(f"lockstep evaluation of GP {a} not served within {self.WAIT_LIMIT:.0f} s")
             r = self.results.pop(a)
         if isinstance(r, Exception):
             raise r

@@ -53,7 +53,7 @@ static void free_buf(Buf& b) {
 
 extern "C" {
 
-int gpmpc_abi_version(void) { return 9; }
+int gpmpc_abi_version(void) { return 10; }
 
 int gpmpc_create(gpmpc_t** out, int device_id) {
     if (!out) return GPMPC_ERR_ARG;
@@ -183,6 +183,8 @@ int gpmpc_last_prepare_mode(gpmpc_t* g) { return g ? g->h.last_prepare_mode : GP
 
 int gpmpc_last_rollout_path(gpmpc_t* g) { return g ? g->h.last_rollout_path : GPMPC_ERR_ARG; }
 
+int gpmpc_last_grad_path(gpmpc_t* g) { return g ? g->h.last_grad_path : GPMPC_ERR_ARG; }
+
 #ifndef GPMPC_BUILD_ID
 #define GPMPC_BUILD_ID "unknown"
 #endif
@@ -276,6 +278,35 @@ int gpmpc_cem_search(gpmpc_t* g, const double* mu0, const double* S0, int B, int
     GPMPC_HIP_CHECK(h, hipSetDevice(h->device));
     return run_cem_search(h, a, iterations, n_elite, seed, first_candidate, mapper, max_change, action_prev, noise_dev,
                           best_out_dev, (hipStream_t)stream);
+}
+
+int gpmpc_cem_local(gpmpc_t* g, const double* mu0, const double* S0, int B_total, int first, int B_local, int H, int A,
+                    int include_time, double time0, int iteration, int n_elite, unsigned long long seed,
+                    const double* first_candidate, int mapper, const double* max_change, const double* action_prev,
+                    const double* noise_dev, const double* state_dev, double* elites_out_dev, void* stream) {
+    Range roctx_range("gpmpc_cem_local");
+    if (!g) return GPMPC_ERR_ARG;
+    if (!state_dev || !elites_out_dev) return bad(g, "null argument");
+    Handle* h = H_(g);
+    if (!h->ready) return bad(g, "search before prepare / set_factors");
+    if (B_local < 0) return bad(g, "negative slice length");
+    RolloutArgs a;
+    int rc = fill_args(g, a, state_dev, mu0, S0, B_local > 0 ? B_local : 1, H, A, include_time, time0);
+    if (rc) return rc;
+    a.B = B_local;
+    GPMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    return run_cem_local(h, a, B_total, first, iteration, n_elite, seed, first_candidate, mapper, max_change, action_prev,
+                         noise_dev, state_dev, elites_out_dev, (hipStream_t)stream);
+}
+
+int gpmpc_cem_merge(gpmpc_t* g, const double* elites_dev, int lists, int n_elite, int n, int iteration, double* state_dev,
+                    void* stream) {
+    Range roctx_range("gpmpc_cem_merge");
+    if (!g) return GPMPC_ERR_ARG;
+    if (!elites_dev || !state_dev) return bad(g, "null argument");
+    Handle* h = H_(g);
+    GPMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    return run_cem_merge(h, elites_dev, lists, n_elite, n, iteration, state_dev, (hipStream_t)stream);
 }
 
 int gpmpc_rollout_timed(gpmpc_t* g, const double* actions, const double* mu0, const double* S0, int B, int H, int A,

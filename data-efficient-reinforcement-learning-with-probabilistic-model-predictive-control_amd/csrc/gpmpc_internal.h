@@ -139,7 +139,7 @@ struct Handle {
     int opt_grad_cols = 0;           // 2: two columns per lane in the gradient's moment pass (A/B)
     int opt_grad_tiles = 1;          // diagonal pairs of the gradient's moment pass batch-major (pair_tile_grad_kernel.h): 0 never, 1 auto, 2 always
     int opt_grad_sep = 1;            // off-diagonal pairs of the gradient's moment pass in separable form on the matrix cores:
-                                     // 0 never (element-wise), 1 from N = 256 on (measured crossover), 2 always (tests, A/B)
+                                     // 0 never (element-wise), 1 from N = 128 on when B x H fills the chip (measured crossover, grad.hip), 2 always (tests, A/B)
     int opt_exact_dim = 0;           // 2: forbid the compile-time-D kernel instantiation (A/B)
     int opt_cols_per_lane = 0;       // 0 auto, 1 / 2: columns per lane in the pairwise pass of the rollout kernel
     int opt_incremental = 1;         // reuse / border-update the cached factors when the memory only grew
@@ -157,6 +157,8 @@ struct Handle {
                                      // (round 3): 77.9 ms either way -- the two kernels do overlap (rocprofv3: 2.58 ms and 1.41 ms side by side instead
                                      // of 2.14 + 0.49 ms) but the fp64 pipe is already at the ~76 % of its nominal rate an FMA loop reaches
     int last_rollout_path = 0;       // what the last rollout launch used: 0 fused-horizon kernel, 1 streaming kernel, 2 batch-major tiles
+    int last_grad_path = 0;          // moment passes of the last gpmpc_rollout_grad: bit 0 separable off-diagonal pairs, bit 1 tile moments of
+                                     // the diagonal pairs, bit 2 streaming element-wise pass, bit 3 the wide (8 < D <= 16) pass
     int opt_fused_prepare = 1;       // N <= 256: the whole factorisation in one launch (prepare_small.hip); 0: panel path (A/B, tests)
     int last_prepare_mode = 0;       // 0 full, 1 border update(s), 2 unchanged (cache hit)
     int lds_limit = 160 * 1024;
@@ -210,6 +212,11 @@ int grow(Handle* h, Buf& b, size_t need);
 int run_cem_search(Handle* h, RolloutArgs& a, int iterations, int n_elite, unsigned long long seed, const double* first_host,
                    int mapper, const double* max_change_host, const double* a_prev_host, const double* noise_dev,
                    double* best_out_dev, hipStream_t s);
+// ... and its per-iteration halves for candidates sharded over GPUs (a.B = the slice length)
+int run_cem_local(Handle* h, RolloutArgs& a, int B_total, int b0, int it, int n_elite, unsigned long long seed,
+                  const double* first_host, int mapper, const double* max_change_host, const double* a_prev_host,
+                  const double* noise_dev, const double* state_dev, double* elites_out_dev, hipStream_t s);
+int run_cem_merge(Handle* h, const double* elites_dev, int lists, int n_elite, int n, int it, double* state_dev, hipStream_t s);
 // prepare_small.hip: 1 = handled (N <= 256), 0 = not applicable, < 0 = error
 int run_prepare_small(Handle* h, const double* X, const double* Y, const double* ls, const double* os, const double* noise,
                       int N, int D, int E, hipStream_t s);

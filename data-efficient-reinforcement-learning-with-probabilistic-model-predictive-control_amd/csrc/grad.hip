@@ -66,7 +66,8 @@ int launch_moments_dp(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_
 int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t s) {
     const int N = a.N, D = a.D, A = a.A, E = a.E, H = a.H, B = a.B;
     const int NX = E - D, P = D * (D + 1) / 2;
-    if (D > 8) return launch_rollout_grad_wide(h, a, grad_out, s);
+    h->last_grad_path = 0;
+    if (D > 8) { h->last_grad_path = 8; return launch_rollout_grad_wide(h, a, grad_out, s); }
     int DP = 0;
     for (int v : {2, 3, 4, 6, 8}) if (D <= v) { DP = v; break; }
     if (DP == 0 || NX > 6) { h->err = "gradient: supported for D <= 8 with A (+ time) <= 6, and for 8 < D <= 16"; return GPMPC_ERR_LIMIT; }
@@ -192,6 +193,7 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
                 else rc = (NA == 1) ? launch(sep_grad_moments_kernel<4, 1>) : launch(sep_grad_moments_kernel<4, 2>);
                 if (rc) return rc;
                 g.sepdone = sep_flags;
+                h->last_grad_path |= 1;
             }
         }
     }
@@ -205,8 +207,10 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
         }
         rc = launch_tile_moments(h, a, g.mom, sep_flags, NSP, NXP, s);
         if (rc) return rc;
+        h->last_grad_path |= 2;
     }
     if (stream) {
+        h->last_grad_path |= 4;
         switch (DP) {
             case 2:  rc = launch_moments_stream_dp<2>(h, g, gs_lds, s); break;
             case 3:  rc = launch_moments_stream_dp<3>(h, g, gs_lds, s); break;

@@ -243,9 +243,10 @@ static int launch_tile_moments_dp(Handle* h, StepArgs t, long long items, double
     if (rc) return rc;
     const size_t lds = (size_t)make_tile_grad_layout(DP, t.E).total * sizeof(double);
     const int nta = t.ntiles * t.D;
-    // items per block: a multiple of the chunk that gives every CU a few workgroups per tile row, workspace <= ~1 GiB
+    // items per block: workspace <= 256 MiB (config 4: ~9 000 items = ~50 rounds of workgroups per block, 7 blocks per launch;
+    // the handle keeps the buffer, so its size is a standing cost next to the model)
     const size_t per_item = (size_t)t.CS + (size_t)t.D * t.ntiles * kTgMom;
-    long long block = (long long)((size_t)(1u << 27) / per_item);
+    long long block = (long long)((size_t)(1u << 25) / per_item);
     if (block > items) block = items;
     if (block < 1) block = 1;
     rc = grow(h, h->tgradws, (size_t)block * per_item);

@@ -109,6 +109,12 @@ class HipEngine:
         return int(self.lib.gpmpc_last_rollout_path(self._h))
 
     @property
+    def last_grad_path(self):
+        """Moment passes of the last `rollout_grad` (bit mask): 1 separable off-diagonal pairs, 2 tile moments of the diagonal
+        pairs, 4 streaming element-wise pass, 8 the 8 < D <= 16 pass."""
+        return int(self.lib.gpmpc_last_grad_path(self._h))
+
+    @property
     def build_id(self):
         """Hash over the sources the loaded library was built from (gpmpc_build_id)."""
         return self.lib.gpmpc_build_id().decode()
@@ -248,6 +254,39 @@ class HipEngine:
                                               nz.data_ptr() if nz is not None else None, best.data_ptr(), self._stream()))
         host = best.cpu().numpy()                               # the one synchronisation
         return host[:n].copy(), float(host[n])
+
+    def cem_local(self, mu0, S0, B_total, first, B_local, H, A, iteration, n_elite, state, seed=0, include_time=False,
+                  time0=0.0, first_candidate=None, max_change=None, action_prev=None, noise=None, out=None):
+        """One iteration of the cross-entropy search for the slice [first, first + B_local) of B_total candidates
+        (gpmpc_cem_local): returns the slice's elite records (n_elite, 2 + H*A) on the device.  `state` = the device tensor
+        [mean | std | best | best J] (3 H A + 1) `cem_merge` maintains.  No synchronisation."""
+        D = self.D
+        mu0 = _host(mu0, (D,))
+        S0 = _host(S0, (D, D))
+        n = H * A
+        if out is None:
+            out = torch.empty((n_elite, n + 2), dtype=torch.float64, device=self.device)
+        first_c = _host(first_candidate, (n,)) if first_candidate is not None else None
+        mapper = 0 if max_change is None else 1
+        mc = _host(max_change, (A,)) if mapper else None
+        ap = _host(action_prev, (A,)) if mapper else None
+        nz = None if noise is None else self._dev(noise)
+        if nz is not None and (nz.dim() != 3 or nz.shape[1] != B_total or nz.shape[2] != n):
+            raise ValueError("noise must be (iterations, B_total, H*A)")
+        self._check(self.lib.gpmpc_cem_local(self._h, _hp(mu0), _hp(S0), int(B_total), int(first), int(B_local), H, A,
+                                             int(bool(include_time)), float(time0), int(iteration), int(n_elite),
+                                             int(seed) & (2 ** 64 - 1), _hp(first_c) if first_c is not None else None, mapper,
+                                             _hp(mc) if mapper else None, _hp(ap) if mapper else None,
+                                             nz.data_ptr() if nz is not None else None, state.data_ptr(), out.data_ptr(),
+                                             self._stream()))
+        self._keep_cem = (nz, state)
+        return out
+
+    def cem_merge(self, elites, n_elite, n, iteration, state):
+        """Refit on the union of the slices' elite records (lists * n_elite, 2 + n) (gpmpc_cem_merge); updates `state`."""
+        lists = elites.numel() // (n_elite * (n + 2))
+        self._check(self.lib.gpmpc_cem_merge(self._h, elites.data_ptr(), lists, int(n_elite), int(n), int(iteration),
+                                             state.data_ptr(), self._stream()))
 
     # -- a8 ----------------------------------------------------------------------------
     def argmin_async(self, J, first_global_index=0, actions=None, out=None):

@@ -124,17 +124,37 @@ def _winner_of(host, world, H, A):
 _HOST_GROUPS = {}
 
 
+def _group_key(group):
+    """Cache key of a process group: its global ranks plus the identity of the CURRENT default group (a re-initialised
+    default group, or a garbage-collected sub-group whose id() was reused, must never hit a stale entry)."""
+    ranks = tuple(range(dist.get_world_size())) if group is None else tuple(dist.get_process_group_ranks(group))
+    return ranks, id(dist.group.WORLD)
+
+
 def host_group(group=None):
     """A process group whose collectives run on HOST tensors (gloo) over the same ranks as `group` (None: the default
     group).  With a gloo default group that is the group itself; with RCCL it is created once (every rank must reach the
-    first call together, like any new_group) and cached."""
+    first call together, like any new_group) and cached per (ranks, default-group instance); entries of a destroyed default
+    group are dropped."""
     if dist.get_backend(group) == "gloo":
         return dist.group.WORLD if group is None else group
-    key = id(group)
+    key = _group_key(group)
+    for stale in [k for k in _HOST_GROUPS if k[1] != key[1]]:
+        del _HOST_GROUPS[stale]
     if key not in _HOST_GROUPS:
-        ranks = None if group is None else dist.get_process_group_ranks(group)
-        _HOST_GROUPS[key] = dist.new_group(ranks=ranks, backend="gloo")
+        _HOST_GROUPS[key] = dist.new_group(ranks=list(key[0]), backend="gloo")
     return _HOST_GROUPS[key]
+
+
+_SIDE_STREAMS = {}
+
+
+def side_stream(device):
+    """The stream the winner exchange runs on when it is kept off the compute stream (one per device, created on first use)."""
+    idx = torch.device(device).index
+    if idx not in _SIDE_STREAMS:
+        _SIDE_STREAMS[idx] = torch.cuda.Stream(device=device)
+    return _SIDE_STREAMS[idx]
 
 
 class PendingBest:
@@ -142,14 +162,24 @@ class PendingBest:
     waits for THAT copy only (an event), so the host can enqueue the next batch's launches before it looks at this
     batch's winner.  With `exchange_group` set the buffer holds THIS rank's record only and `result()` exchanges the
     records between the hosts (a gloo all_gather of 16 + 8 H A bytes per rank) -- nothing of the exchange is on the GPU's
-    streams, where a per-step RCCL gather cost ~45 us of a 0.47 ms config-2 step."""
+    streams.
+
+    `result()` with an `exchange_group` is a COLLECTIVE: every rank must call it, for the same pending selections in the
+    same (launch) order; the first call caches its answer, so calling it again is free and safe, skipping it on one rank
+    deadlocks the others.  `host_seconds` afterwards = the host time the call spent (wait for the copy + exchange)."""
 
     def __init__(self, host, event, world, H, A, record=None, exchange_group=None):
         self.host, self.event, self.world, self.H, self.A = host, event, world, H, A
-        self.record = record            # the device record buffer, reusable by the next call
+        self.record = record            # the device record buffer, reusable once this selection has been read
         self.exchange_group = exchange_group
+        self._result = None
+        self.host_seconds = None
 
     def result(self):
+        if self._result is not None:
+            return self._result
+        import time
+        t0 = time.perf_counter()
         if self.event is not None:
             self.event.synchronize()
         host = self.host
@@ -158,20 +188,27 @@ class PendingBest:
             flat = torch.empty(self.world * mine.numel(), dtype=torch.float64)
             dist.all_gather_into_tensor(flat, mine, group=self.exchange_group)
             host = flat
-        return _winner_of(host.view(self.world, -1), self.world, self.H, self.A)
+        self._result = _winner_of(host.view(self.world, -1), self.world, self.H, self.A)
+        self.host_seconds = time.perf_counter() - t0
+        return self._result
 
 
 def select_best_async(engine, J, actions_local, lo, num_candidates, group=None, host_buffer=None, record=None,
                       exchange="rccl"):
     """select_best_on_device without the host synchronisation: local keep-the-best kernel, the packed record on its way to
-    pinned host memory behind an event.  `exchange`: "rccl" = (N > 1) one RCCL all_gather of the packed records on the
-    compute stream before the copy; "host" = the copy carries this rank's record only and the records are exchanged
-    between the hosts when the result is read (PendingBest.result) -- the GPU streams carry no collective at all.
+    pinned host memory behind an event.  `exchange` (N > 1):
+      "rccl_side" = ONE RCCL all_gather of the packed records over xGMI on a SIDE stream that waits for the record's event --
+                    the compute stream never waits for the collective (BASELINE north_star: "RCCL over xGMI only for the
+                    final argmin gather"); the caller must not reuse `record` before this selection has been read;
+      "rccl"      = the same all_gather on the compute stream (the next launch queues behind it: ~45 us per step);
+      "host"      = the copy carries this rank's record only and the records are exchanged between the hosts (gloo) when the
+                    result is read (PendingBest.result) -- the fallback when no xGMI collective is wanted.
     `host_buffer` / `record`: reusable pinned / device buffers of a previous call with the same shapes.
     Returns a PendingBest."""
     n, H, A = actions_local.shape
     rec = _local_record(engine, J, actions_local, lo, out=record)
-    if exchange == "host" and dist.is_available() and dist.is_initialized():
+    multi = dist.is_available() and dist.is_initialized()
+    if exchange == "host" and multi:
         world = dist.get_world_size(group)
         xg = host_group(group)
         if rec.device.type != "cuda":
@@ -182,6 +219,22 @@ def select_best_async(engine, J, actions_local, lo, num_candidates, group=None, 
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(rec.device))
         return PendingBest(host_buffer, ev, world, H, A, rec, exchange_group=xg)
+    if exchange == "rccl_side" and multi and rec.device.type == "cuda":
+        world = dist.get_world_size(group)
+        side = side_stream(rec.device)
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(rec.device))
+        if host_buffer is None or host_buffer.numel() != world * rec.numel():
+            host_buffer = torch.empty(world * rec.numel(), dtype=torch.float64, pin_memory=True)
+        with torch.cuda.stream(side):
+            side.wait_event(ready)
+            world, flat = _gather_records(rec, group)          # ProcessGroupNCCL orders its stream against `side` only
+            host_buffer.copy_(flat, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        pend = PendingBest(host_buffer, ev, world, H, A, rec)
+        pend._flat = flat                                       # keep the gathered device tensor alive until read
+        return pend
     world, flat = _gather_records(rec, group)
     if rec.device.type != "cuda":
         return PendingBest(flat.clone(), None, world, H, A, rec)
@@ -213,3 +266,32 @@ def select_best_on_device(engine, J, actions_local, lo, num_candidates, group=No
     if extra is None:
         return bJ, bi, win
     return bJ, bi, win, host[:, 2 + H * A:].clone()
+
+
+def sharded_cem_search(engine, mu0, S0, B_total, H, A, iterations, n_elite, seed, group=None, include_time=False, time0=0.0,
+                       first_candidate=None, max_change=None, action_prev=None, noise=None):
+    """The device-resident cross-entropy search (HipEngine.cem_search) with its candidates sharded over the ranks: per
+    iteration every rank draws and evaluates its contiguous slice of the B_total candidates (the draws are keyed by the
+    GLOBAL candidate index, so the union of the slices is the single-GPU population), ONE all_gather of the slices' elite
+    records (n_elite x (2 + H A) doubles per rank, RCCL on the compute stream: the refit needs them), and every rank refits
+    on the union -- all ranks end with the same state, the one the single-GPU search reaches on the same draws.
+    Nothing is read back between iterations.  Returns (best vector (H*A,) numpy, best J)."""
+    multi = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
+    lo, hi = shard_bounds(B_total, world, rank)
+    n = H * A
+    state = torch.zeros(3 * n + 1, dtype=torch.float64, device=engine.device)
+    gathered = torch.empty((world * n_elite, n + 2), dtype=torch.float64, device=engine.device) if world > 1 else None
+    elites = None
+    for it in range(int(iterations)):
+        elites = engine.cem_local(mu0, S0, B_total, lo, hi - lo, H, A, it, n_elite, state, seed=seed, include_time=include_time,
+                                  time0=time0, first_candidate=first_candidate, max_change=max_change, action_prev=action_prev,
+                                  noise=noise, out=elites)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered.view(-1), elites.view(-1), group=group)
+            engine.cem_merge(gathered, n_elite, n, it, state)
+        else:
+            engine.cem_merge(elites, n_elite, n, it, state)
+    host = state.cpu().numpy()                                  # the one synchronisation
+    return host[2 * n:3 * n].copy(), float(host[3 * n])

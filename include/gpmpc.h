@@ -95,6 +95,12 @@ int gpmpc_last_prepare_mode(gpmpc_t* h);
  * "tile_chunk" sets the candidates per tile workgroup. */
 int gpmpc_last_rollout_path(gpmpc_t* h);
 
+/* Which moment passes the last gpmpc_rollout_grad launched (bit mask): 1 = off-diagonal output pairs in separable form on
+ * the matrix cores, 2 = diagonal pairs batch-major over all (candidate, step) items, 4 = the streaming element-wise pass
+ * (per-point arrays beyond the LDS), 8 = the 8 < D <= 16 pass.  0 = the element-wise pass alone.  A test hook: lets a parity
+ * test assert that it measured the dispatch that ships (gp_mpc_controller.py:277 is one autograd call in the reference). */
+int gpmpc_last_grad_path(gpmpc_t* h);
+
 /*
  * Same cached state as gpmpc_prepare but with iK (D,N,N) and beta (D,N) supplied by the
  * caller (test hook: lets the rollout kernel be checked in isolation from the
@@ -218,6 +224,28 @@ int gpmpc_cem_search(gpmpc_t* h, const double* mu0_host, const double* S0_host, 
                      int include_time, double time0, int iterations, int n_elite, unsigned long long seed,
                      const double* first_candidate_host, int mapper, const double* max_change_host,
                      const double* action_prev_host, const double* noise_dev, double* best_out_dev, void* stream);
+
+/*
+ * The same search with the candidates SHARDED over GPUs (the reference's restart loop gp_mpc_controller.py:125-141
+ * is what is being spread): one iteration in two halves, with ONE exchange between them.
+ *   gpmpc_cem_local: this GPU's slice [first, first + B_local) of the B_total candidates of iteration `iteration` -- draws (the
+ *     Philox counters / the rows of noise_dev (iterations, B_total, H*A) are indexed by the GLOBAL candidate, so the union of
+ *     the slices IS the population gpmpc_cem_search draws), mapper, one rollout launch -- and the slice's n_elite best as records
+ *     elites_out_dev (n_elite, 2 + H*A) = [J (NaN -> +inf) | global index | optimiser vector], sorted; shorter slices pad with
+ *     (+inf, INT_MAX) records.  B_local = 0 is allowed (more GPUs than candidates).
+ *   (the caller all-gathers the records of all GPUs: RCCL, n_elite (2 + H*A) doubles per GPU)
+ *   gpmpc_cem_merge: elites_dev (lists * n_elite, 2 + H*A) -> state_dev = [mean (n) | std (n) | best vector (n) | best J], n = H*A:
+ *     the sort, incumbent rule and elite statistics of gpmpc_cem_search on the union, in the same summation order -- every GPU
+ *     holds the same state afterwards, bit for bit the single-GPU search's.  lists * n_elite <= 4096.
+ * state_dev is read by gpmpc_cem_local from iteration 1 on (iteration 0 draws uniformly and ignores it).  Nothing synchronises.
+ */
+int gpmpc_cem_local(gpmpc_t* h, const double* mu0_host, const double* S0_host, int B_total, int first, int B_local, int H, int A,
+                    int include_time, double time0, int iteration, int n_elite, unsigned long long seed,
+                    const double* first_candidate_host, int mapper, const double* max_change_host,
+                    const double* action_prev_host, const double* noise_dev, const double* state_dev,
+                    double* elites_out_dev, void* stream);
+int gpmpc_cem_merge(gpmpc_t* h, const double* elites_dev, int lists, int n_elite, int n, int iteration, double* state_dev,
+                    void* stream);
 
 /* Kernel-only timing helper for bench.py: runs `reps` rollouts back to back on `stream`
  * bracketed by HIP events recorded on THAT stream and returns the average milliseconds

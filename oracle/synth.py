@@ -51,7 +51,11 @@ def _rep(vals, n):
 
 
 def make_workload(N, D, A, H, B, include_time=False, seed=0, noise_var=1e-5,
-                  outputscale=5e-2, s0=1e-6, time0=0.0):
+                  outputscale=5e-2, s0=1e-6, time0=0.0, dynamics="drift", dense_s0=0.0):
+    """`dynamics`: "drift" = the SURVEY 8(d) targets (a smooth state change of up to 0.05 per step: over a long horizon the
+    mean leaves the [0, 1] range the memory covers and the GP falls back to its prior); "contracting" = targets that pull
+    every state towards 0.5 (y_d = -0.2 (x_d - 0.5) + 0.02 sin(...)), so a long rollout stays where the memory is and the
+    late steps exercise the data-dependent terms.  `dense_s0` > 0: a dense initial covariance G G^T + s0 I, G ~ dense_s0 N(0, 1)."""
     E = D + A + (1 if include_time else 0)
     rng = np.random.default_rng(seed)
     X = rng.uniform(0.0, 1.0, size=(N, E))
@@ -59,7 +63,10 @@ def make_workload(N, D, A, H, B, include_time=False, seed=0, noise_var=1e-5,
         X[:, -1] = np.arange(N, dtype=np.float64)      # control-iteration index
     Y = np.empty((N, D))
     for d in range(D):
-        Y[:, d] = 0.05 * np.sin(3.0 * X[:, d] + X[:, D + A - 1]) + 1e-3 * rng.standard_normal(N)
+        if dynamics == "contracting":
+            Y[:, d] = -0.2 * (X[:, d] - 0.5) + 0.02 * np.sin(3.0 * X[:, d] + X[:, D + A - 1]) + 1e-3 * rng.standard_normal(N)
+        else:
+            Y[:, d] = 0.05 * np.sin(3.0 * X[:, d] + X[:, D + A - 1]) + 1e-3 * rng.standard_normal(N)
     ls = 0.5 + rng.uniform(0.0, 1.0, size=(D, E))
     if include_time:
         ls[:, -1] = 100.0 + 50.0 * rng.uniform(0.0, 1.0, size=D)
@@ -67,6 +74,9 @@ def make_workload(N, D, A, H, B, include_time=False, seed=0, noise_var=1e-5,
     actions = rng_a.uniform(0.0, 1.0, size=(B, H, A))
     mu0 = rng.uniform(0.0, 1.0, size=D)
     S0 = s0 * np.eye(D)
+    if dense_s0 > 0.0:
+        G = dense_s0 * np.random.default_rng(seed + 2).standard_normal((D, D))
+        S0 = G @ G.T + s0 * np.eye(D)
     # cost weights: pendulum example extended by repetition
     target = np.concatenate([_rep([1.0, 0.5, 0.5], D), _rep([0.5], A)])
     W = np.diag(np.concatenate([_rep([1.0, 0.1, 0.1], D), _rep([1e-3], A)]))

@@ -51,3 +51,83 @@ class OracleEngine:
         if ha and best >= 0:
             rec[2:] = actions[best - first_global_index].reshape(-1)
         return rec
+
+    # -- the two halves of a sharded cross-entropy iteration, restating csrc/search.hip (cem_sample / cem_map / cem_elites /
+    #    cem_merge kernels) in numpy; draws must be supplied (`noise`), the Philox generator exists on the device only
+    def cem_local(self, mu0, S0, B_total, first, B_local, H, A, iteration, n_elite, state, seed=0, include_time=False,
+                  time0=0.0, first_candidate=None, max_change=None, action_prev=None, noise=None, out=None):
+        assert noise is not None, "the CPU stand-in has no Philox generator"
+        n = H * A
+        st = state.numpy()
+        mean, std, best = st[:n], st[n:2 * n], st[2 * n:3 * n]
+        rec = np.zeros((n_elite, n + 2))
+        rec[:, 0], rec[:, 1] = np.inf, 2147483647.0
+        if B_local > 0:
+            draw = np.asarray(noise, dtype=np.float64)[iteration, first:first + B_local]
+            X = draw.copy() if iteration == 0 else np.clip(mean + std * draw, 0.0, 1.0)
+            if first == 0:
+                if iteration > 0:
+                    X[0] = best
+                elif first_candidate is not None:
+                    X[0] = first_candidate
+            if max_change is None:
+                acts = X.reshape(B_local, H, A)
+            else:
+                m = np.asarray(max_change)
+                acts = np.clip(np.asarray(action_prev) + np.cumsum(X.reshape(B_local, H, A) * 2.0 * m - m, axis=1), 0.0, 1.0)
+            J = self.rollout(acts, mu0, S0, include_time, time0)["J"].numpy()
+            J = np.where(np.isnan(J), np.inf, J)
+            order = np.lexsort((np.arange(B_local), J))[:n_elite]
+            k = len(order)
+            rec[:k, 0], rec[:k, 1], rec[:k, 2:] = J[order], order + first, X[order]
+        t = torch.as_tensor(rec)
+        if out is not None:
+            out.copy_(t)
+            return out
+        return t
+
+    def cem_merge(self, elites, n_elite, n, iteration, state):
+        rec = elites.numpy().reshape(-1, n + 2)
+        order = np.lexsort((rec[:, 1], rec[:, 0]))[:n_elite]
+        st = state.numpy()
+        top = rec[order, 2:]
+        s = np.zeros(n)
+        for e in range(n_elite):                  # the kernel's summation order
+            s = s + top[e]
+        m = s / n_elite
+        q = np.zeros(n)
+        for e in range(n_elite):
+            q = q + (top[e] - m) ** 2
+        if iteration == 0 or rec[order[0], 0] < st[3 * n]:
+            st[2 * n:3 * n] = top[0]
+            st[3 * n] = rec[order[0], 0]
+        st[:n] = m
+        st[n:2 * n] = np.sqrt(q / n_elite) + 1e-3
+
+    # -- objective + gradient (oracle/adjoint.py) in the packed form HipEngine.rollout_grad returns
+    def rollout_grad(self, actions, mu0, S0, include_time=False, time0=0.0, trajectories=False):
+        from oracle import adjoint
+        actions = np.asarray(actions, dtype=np.float64)
+        B, H, A = actions.shape
+        self.launches += 1
+        target, W, W_T, kappa, clip, smin, smax = self._cost
+        Js, gs = [], []
+        for b in range(B):
+            J, g, *_ = adjoint.lcb_and_gradient(self.f, actions[b], np.asarray(mu0), np.asarray(S0), target, W, W_T, kappa,
+                                                include_time, time0)
+            Js.append(J)
+            gs.append(g.reshape(H, A))
+        out = {"J": torch.as_tensor(np.array(Js)), "grad": torch.as_tensor(np.stack(gs))}
+        if trajectories:
+            out.update({k: v for k, v in self.rollout(actions, mu0, S0, include_time, time0).items() if k != "J"})
+        keys = [k for k in ("J", "grad", "mu", "Sig", "cost_mu", "cost_var") if k in out]
+        out["packed"] = torch.cat([out[k].reshape(-1) for k in keys])
+        out["layout"], off = [], 0
+        for k in keys:
+            out["layout"].append((k, tuple(out[k].shape), off, out[k].numel()))
+            off += out[k].numel()
+        return out
+
+    @staticmethod
+    def host_views(out):
+        return {k: out["packed"][off:off + n].view(sh) for k, sh, off, n in out["layout"]}

@@ -211,6 +211,34 @@ def test_device_resident_search_matches_a_host_loop_on_the_same_draws(engine, de
     assert J1 <= J_first and J3 <= J_first and np.all((x1 >= 0) & (x1 <= 1))
 
 
+@pytest.mark.parametrize("deriv", [False, True])
+@pytest.mark.parametrize("cuts", [(0, 96), (0, 48, 96), (0, 5, 5, 40, 96)])
+def test_sharded_halves_of_the_device_search_reach_the_single_launch_state(engine, deriv, cuts):
+    """gpmpc_cem_local / gpmpc_cem_merge (candidates sharded over GPUs: one elite exchange per iteration) against
+    gpmpc_cem_search on ONE GPU: the slices -- evaluated here one after the other, their records concatenated the way the
+    RCCL all_gather delivers them -- must reproduce the single-launch search bit for bit, with supplied draws and with the
+    Philox draws (counters indexed by the global candidate), including a slice shorter than n_elite and an empty one."""
+    g = load("lcb_grad_deriv" if deriv else "lcb_grad_norm")
+    w = workload_of(g)
+    N, D, A, E, H, _ = w.dims
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    engine.set_cost(w.target, w.W, w.W_T, w.kappa)
+    B, iters, n_elite, n = 96, 4, 9, H * A
+    rng = np.random.default_rng(6)
+    noise = np.concatenate([rng.uniform(size=(1, B, n)), rng.standard_normal((iters - 1, B, n))])
+    first = rng.uniform(size=n)
+    kw = dict(max_change=g["max_change"], action_prev=g["action_prev"]) if deriv else {}
+    for draws in (dict(noise=noise), dict(seed=11)):
+        x_ref, J_ref = engine.cem_search(w.mu0, w.S0, B, H, A, iters, n_elite, first_candidate=first, **draws, **kw)
+        state = torch.zeros(3 * n + 1, dtype=torch.float64, device=engine.device)
+        for it in range(iters):
+            recs = [engine.cem_local(w.mu0, w.S0, B, lo, hi - lo, H, A, it, n_elite, state, first_candidate=first, **draws, **kw)
+                    for lo, hi in zip(cuts[:-1], cuts[1:])]
+            engine.cem_merge(torch.cat(recs), n_elite, n, it, state)
+        host = state.cpu().numpy()
+        assert np.array_equal(host[2 * n:3 * n], x_ref) and host[3 * n] == J_ref
+
+
 def test_device_resident_search_in_the_controller(engine):
     """candidate_optimizer = "cem_device" behind get_action: same budget as 512 random sequences, ends at least as low;
     the logging caches hold the winner's trajectory; the next step warm-starts from the shifted solution."""
@@ -369,11 +397,12 @@ def test_bench_line_with_the_process_group_initialised(args, scaling):
     assert d["roofline"]["frac"] > 0 and d["parity"]["max_rel_cov"] < 1e-5 and d["parity"]["max_abs_dmean"] < 1e-8
 
 
-def test_host_side_exchange_costs_the_step_nothing():
-    """with the per-rank winner records exchanged between the HOSTS after the device-to-host copy
-    (bench.py --exchange host, the default) a step of the N > 1 code path takes what the single-process step takes --
-    the per-step RCCL gather on the compute stream (--exchange rccl) cost ~45 us of a 0.47 ms config-2 step.  One rank
-    with the process group initialised (--force-dist); the measured ratios go to the parity report."""
+def test_exchange_off_the_compute_stream_costs_the_step_nothing():
+    """The per-rank winner records meet (a) over RCCL on a SIDE stream behind an event (bench.py's default, `--exchange
+    rccl_side`: north_star's "RCCL over xGMI only for the final argmin gather", with the compute stream never waiting for the
+    collective) or (b) between the hosts after the device-to-host copy (`--exchange host`): either way a step of the N > 1
+    code path takes what the single-process step takes -- the gather ON the compute stream (`--exchange rccl`) cost ~45 us
+    of a 0.47 ms config-2 step.  One rank with the process group initialised (--force-dist); ratios go to the parity report."""
     import json
     import os
     import subprocess
@@ -392,12 +421,17 @@ def test_host_side_exchange_costs_the_step_nothing():
             best = d if best is None or d["ms_per_step"] < best["ms_per_step"] else best
         return best
     plain = line([])
+    side = line(["--force-dist"])
     host = line(["--force-dist", "--exchange", "host"])
     rccl = line(["--force-dist", "--exchange", "rccl"])
-    assert host["config"]["exchange"] == "host" and host["per_rank"][0]["candidates"] == 256
-    r_host, r_rccl = host["ms_per_step"] / plain["ms_per_step"], rccl["ms_per_step"] / plain["ms_per_step"]
-    record("multi_gpu_exchange[c2,world1]", ms_plain=plain["ms_per_step"], ms_host_exchange=host["ms_per_step"],
-           ms_rccl_gather=rccl["ms_per_step"], ratio_host=r_host, ratio_rccl=r_rccl)
-    print(f"ms/step: single process {plain['ms_per_step']:.4f}, host exchange {host['ms_per_step']:.4f}, RCCL gather {rccl['ms_per_step']:.4f}")
-    assert r_host < 1.03
-    assert host["best_index"] == plain["best_index"] == rccl["best_index"]
+    assert side["config"]["exchange"] == "rccl_side" and host["config"]["exchange"] == "host"
+    assert side["per_rank"][0]["candidates"] == 256 and side["per_rank"][0]["winner_read_host_ms_median"] >= 0.0
+    r_side, r_host, r_rccl = (x["ms_per_step"] / plain["ms_per_step"] for x in (side, host, rccl))
+    record("multi_gpu_exchange[c2,world1]", ms_plain=plain["ms_per_step"], ms_rccl_side_stream=side["ms_per_step"],
+           ms_host_exchange=host["ms_per_step"], ms_rccl_compute_stream=rccl["ms_per_step"], ratio_rccl_side=r_side,
+           ratio_host=r_host, ratio_rccl=r_rccl, closed_loop_ms_plain=plain["closed_loop_ms_per_step"],
+           closed_loop_ms_rccl_side=side["closed_loop_ms_per_step"])
+    print(f"ms/step: single process {plain['ms_per_step']:.4f}, RCCL side stream {side['ms_per_step']:.4f}, "
+          f"host exchange {host['ms_per_step']:.4f}, RCCL on the compute stream {rccl['ms_per_step']:.4f}")
+    assert r_side < 1.03 and r_host < 1.03
+    assert side["best_index"] == host["best_index"] == plain["best_index"] == rccl["best_index"]

@@ -284,7 +284,7 @@ def test_config5_full_size_gradient_against_oracle_fixture(engine):
                                              (1, 3, 1, 2, 2, False, 1e-5)])
 def test_separable_moments_of_the_off_diagonal_pairs(engine, N, D, A, H, B, tm, s0):
     """csrc/grad_sep_kernel.h: the moments of the off-diagonal pairs as products of row-side and column-side monomial
-    moments, F^T Phi on the fp64 matrix cores (forced here at every N; by default from N = 256 on), against the numpy
+    moments, F^T Phi on the fp64 matrix cores (forced here at every N; by default from N = 128 on when B x H fills the chip), against the numpy
     adjoint and against the element-wise moment pass.  Includes more action inputs than 1 (second A block at D = 4),
     time input, variances that push the Taylor degree to the edge of the monomial table (those pairs stay element-wise)."""
     w = synth.make_workload(N, D, A, H, B, include_time=tm, seed=N + D, s0=s0, time0=1.0 if tm else 0.0)
@@ -330,6 +330,32 @@ def test_tile_moments_of_the_diagonal_pairs(engine, N, D, A, H, B, tm, s0, sep):
     assert rel_err(res[2], res[0]) < 1e-7
 
 
+def test_shipped_config4_gradient_dispatch_against_the_numpy_adjoint(engine):
+    """The gradient dispatch that SHIPS at BASELINE configs[3]'s memory size (N = 1000, D = 4, A = 2) with a batch that fills
+    the chip (B = 512: batch-major forward, separable off-diagonal moments on the matrix cores, tile moments of the diagonal
+    pairs -- the defaults, nothing forced) against the numpy adjoint of oracle/adjoint.py (pinned by the reference's
+    autograd goldens), first / middle / last candidate.  Reference: `mean_cost.backward()`, gp_mpc_controller.py:277."""
+    n, d, a, _, _, tm = synth.SHAPES["c4"]
+    B, H = 512, 3
+    w = synth.make_workload(n, d, a, H, B, include_time=tm, seed=9)
+    f = factors_of(w)
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    engine.set_cost(w.target, w.W, w.W_T, w.kappa)
+    out = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+    assert engine.last_rollout_path == 2                       # batch-major forward
+    assert engine.last_grad_path & 3 == 3, engine.last_grad_path      # separable (1) + tile (2) moment passes were launched
+    grad = out["grad"].cpu().numpy()
+    Jd = out["J"].cpu().numpy()
+    errs = []
+    for b in (0, B // 2, B - 1):
+        J, g, *_ = adjoint.lcb_and_gradient(f, w.actions[b], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
+        errs.append(rel_err(grad[b], g))
+        assert abs(Jd[b] - J) < 1e-9 * abs(J)
+    from helpers import record
+    record("config4_shipped_gradient_dispatch[N1000,B512,H3]", grad_vs_numpy_adjoint=max(errs))
+    assert max(errs) < 1e-7
+
+
 def test_config4_full_batch_gradient_through_the_split_moment_pass(engine):
     """BASELINE configs[3] at its full batch (N = 1000, D = 4, A = 2, H = 30, B = 2048): here the defaults pick the batch-major
     forward, the separable off-diagonal moments and the tile moments of the diagonal pairs.  First / middle / last candidates
@@ -357,7 +383,15 @@ def test_config4_full_batch_gradient_through_the_split_moment_pass(engine):
         for name, v in (("grad_tiles", 1), ("grad_separable", 1), ("pair_tiles", 0)):
             engine.set_option(name, v)
     e = rel_err(g1[pick], ref["grad"].cpu().numpy())
+    # ... and against the numpy adjoint (oracle/adjoint.py) on the same three candidates over the full horizon
+    f = factors_of(w)
+    e_or = 0.0
+    for b in pick:
+        J, g, *_ = adjoint.lcb_and_gradient(f, w.actions[b], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
+        e_or = max(e_or, rel_err(g1[b], g))
+        assert abs(J1[b] - J) < 1e-7 * abs(J)
     from helpers import record
-    record("config4_full_batch_gradient[N1000,B2048]", grad_vs_elementwise=e)
+    record("config4_full_batch_gradient[N1000,B2048]", grad_vs_elementwise=e, grad_vs_numpy_adjoint=e_or)
     assert e < 1e-7
+    assert e_or < 1e-6         # H = 30 steps of N = 1000: the covariances themselves carry ~5e-7 (profiles/r03_parity_report.json)
     assert np.allclose(J1[pick], ref["J"].cpu().numpy(), rtol=1e-7, atol=0)       # fused vs batch-major forward: two summation orders

@@ -204,3 +204,97 @@ def test_controller_random_shooting_sharded_over_ranks(world, restarts):
     lo_hi = [(__import__("gp_mpc_amd").sharding.shard_bounds(restarts, world, r)) for r in range(world)]
     for r, (lo, hi) in enumerate(lo_hi):          # a rank with an empty slice never launched
         assert (ret[r][0]["launches"] > 0) == (hi > lo)
+
+
+# ------------------------------------------------------------------- the device cross-entropy search, sharded
+def _cem_run(B, iters, n_elite, first):
+    from gp_mpc_amd import sharding
+    from oracle import synth
+    from stub_engine import OracleEngine
+    w = synth.make_workload(N=30, D=2, A=1, H=3, B=1, seed=4)
+    eng = OracleEngine()
+    eng.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    eng.set_cost(w.target, w.W, w.W_T, w.kappa)
+    rng = np.random.default_rng(12)
+    noise = np.concatenate([rng.uniform(size=(1, B, 3)), rng.standard_normal((iters - 1, B, 3))])
+    fc = np.full(3, 0.25) if first else None
+    x, J = sharding.sharded_cem_search(eng, w.mu0, w.S0, B, 3, 1, iters, n_elite, seed=0, first_candidate=fc, noise=noise)
+    return x, J, eng.launches
+
+
+def _cem_worker(rank, world, port, B, iters, n_elite, first, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = _cem_run(B, iters, n_elite, first)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,B,n_elite,first", [(2, 13, 4, False), (3, 16, 5, True), (2, 5, 4, True), (3, 2, 2, False)])
+def test_sharded_cross_entropy_search_reaches_the_single_rank_state(world, B, n_elite, first):
+    """Each rank draws its slice of the population from the shared key, one elite merge per iteration: every rank ends with
+    exactly the winner (vector and objective, bitwise) the single-rank search reaches on the same draws -- including slices
+    shorter than n_elite and empty slices (B < world)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    want = _cem_run(B, 4, n_elite, first)
+    port = 35500 + (os.getpid() + world * 19 + B) % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_cem_worker, args=(world, port, B, 4, n_elite, first, ret), nprocs=world, join=True)
+    for r in range(world):
+        x, J, launches = ret[r]
+        assert np.array_equal(x, want[0]) and J == want[1], (r, x, want[0], J, want[1])
+
+
+# ------------------------------------------------------------------- lockstep L-BFGS restarts, sharded (VERDICT r3, missing 3)
+def _lbfgs_step(restarts, seed):
+    from helpers import make_controller
+    from oracle import synth
+    from stub_engine import OracleEngine
+    w = synth.make_workload(N=25, D=2, A=1, H=3, B=1, seed=6)
+    eng = OracleEngine()
+    c = make_controller(w, optimize=True, restarts=restarts, engine=eng,
+                        optimizer_params={"disp": None, "maxcor": 4, "ftol": 1e-15, "gtol": 1e-15, "eps": 1e-2, "maxfun": 4,
+                                          "maxiter": 4, "iprint": -1, "maxls": 4, "finite_diff_rel_step": None})
+    c.config.controller.candidate_optimizer = "lbfgs"
+    c.config.controller.lbfgs_candidates = restarts
+    np.random.seed(seed)
+    out = []
+    for step in range(2):
+        a = c.get_action(w.mu0)
+        out.append(dict(action=np.asarray(a), best=int(c.best_candidate_index), J=float(c.best_candidate_J),
+                        prev=c.actions_mpc_previous_iter.copy(), states=np.asarray(c.get_iter_info().predicted_states)))
+    return out
+
+
+def _lbfgs_worker(rank, world, port, restarts, seed, ret):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = _lbfgs_step(restarts, seed)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,restarts", [(2, 3), (3, 2)])
+def test_lockstep_lbfgs_restarts_sharded_over_ranks(world, restarts):
+    """candidate_optimizer = "lbfgs" with torch.distributed initialised: each rank solves its slice of the restarts (the
+    reference's loop gp_mpc_controller.py:125-141, spread), one all_gather of [fun, restart, solution]; every rank returns
+    the single-process winner -- also a rank whose slice is empty (restarts < world)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    want = _lbfgs_step(restarts, seed=8)
+    port = 37500 + (os.getpid() + world * 23 + restarts) % 2000
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_lbfgs_worker, args=(world, port, restarts, 8, ret), nprocs=world, join=True)
+    for r in range(world):
+        for step, (g, e) in enumerate(zip(ret[r], want)):
+            assert g["best"] == e["best"] and g["J"] == e["J"], (r, step, g["best"], e["best"], g["J"], e["J"])
+            for k in ("action", "prev", "states"):
+                assert np.array_equal(g[k], e[k]), (r, step, k)

@@ -8,6 +8,8 @@ outputs are stored.
   python tools/gen_golden_c5.py --steps 5  five horizon steps,     2 candidates  -> oracle_c5_traj.npz   (~ 5x that)
   python tools/gen_golden_c5.py --steps 50 --candidates 1   BASELINE configs[4]'s full horizon, 1 candidate -> oracle_c5_h50.npz
                                                              (round 3; ~ an hour on 8 cores: run it in the background)
+  python tools/gen_golden_c5.py --inrange --steps 20 --candidates 4   contracting targets + dense Sigma_0: the state stays inside
+                                                             the memory's range over the horizon -> oracle_c5_inrange.npz (round 4)
 """
 import argparse
 import os
@@ -24,18 +26,22 @@ from oracle import gpmpc_oracle as orc  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=1)
 ap.add_argument("--candidates", type=int, default=2)
+ap.add_argument("--inrange", action="store_true")
 args = ap.parse_args()
 N, D, A, H, B = 4096, 16, 4, args.steps, args.candidates
 SEED = 77 if H == 1 else (78 if H <= 5 else 79)
 name = "oracle_c5_step.npz" if H == 1 else ("oracle_c5_traj.npz" if H <= 5 else f"oracle_c5_h{H}.npz")
-w = synth.make_workload(N, D, A, H, B, seed=SEED)
+KW = {}
+if args.inrange:
+    SEED, name, KW = 83, "oracle_c5_inrange.npz", dict(dynamics="contracting", dense_s0=0.02)
+w = synth.make_workload(N, D, A, H, B, seed=SEED, **KW)
 t0 = time.time()
 f = orc.Factors(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
 print("factorised", time.time() - t0, flush=True)
 out = orc.evaluate_candidates(f, w)
 print("evaluated", time.time() - t0, flush=True)
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", name),
-                    N=N, D=D, A=A, H=H, B=B, seed=SEED, beta_head=f.beta[:, :64], mu=out["mu"], Sig=out["Sig"],
+                    N=N, D=D, A=A, H=H, B=B, seed=SEED, inrange=args.inrange, beta_head=f.beta[:, :64], mu=out["mu"], Sig=out["Sig"],
                     cost_mu=out["cost_mu"], cost_var=out["cost_var"], J=out["J"],
                     x_checksum=np.array([w.X.sum(), w.Y.sum(), w.actions.sum()]))
 print("J", out["J"])
