@@ -88,6 +88,7 @@ def main():
                     help="auto: weak for c1-c3 (B per GPU fixed), strong for the sharded configs c4 / c5 (B total fixed)")
     ap.add_argument("--points", type=int, default=0, help="override N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gradient", action="store_true", help="skip the objective + gradient leg (config 5: ~2 minutes per launch)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (exercises the N > 1 code path)")
     ap.add_argument("--exchange", default="rccl_side", choices=["rccl_side", "host", "rccl"],
                     help="N > 1: how the per-rank winner records meet -- 'rccl_side' (default): one RCCL all_gather per step over xGMI "
@@ -278,6 +279,8 @@ def main():
     # dJ/d(actions) of every candidate = forward rollout + pairwise moment pass + reverse sweep
     grad_ms = None
     try:
+        if args.no_gradient:
+            raise gp_mpc_amd.GpmpcError(0, "gradient leg skipped on request")
         g_reps = 5 if est_step_ms < 200.0 else 1   # config 5: one forward is ~28 s, so ONE timed launch and no warm-up
         if g_reps > 1:
             eng.rollout_grad(actions, w.mu0, w.S0, w.include_time, w.time0)

@@ -50,11 +50,19 @@ def _has(cur, table, col):
 
 
 def pmc(paths):
+    import os
     for path in paths:
+        if not os.path.exists(path):
+            print(f"# (no output: {path} -- that counter pass failed)")
+            continue
         cur = sqlite3.connect(path).cursor()
         acc = defaultdict(lambda: defaultdict(float))
-        for kname, disp, cname, val in cur.execute(
-                "select kernel_name, dispatch_id, counter_name, value from counters_collection"):
+        try:
+            rows = cur.execute("select kernel_name, dispatch_id, counter_name, value from counters_collection").fetchall()
+        except sqlite3.Error as e:
+            print(f"# (unreadable: {path}: {e})")
+            continue
+        for kname, disp, cname, val in rows:
             acc[(kname, cname)][disp] += val            # sum over dimensions (XCC / SE / instances)
         print(f"# PMC per-dispatch averages (summed over hardware instances)  ({path})")
         print(f"{'kernel':70s} {'counter':22s} {'dispatches':>10s} {'avg_per_dispatch':>18s} {'max':>16s}")
