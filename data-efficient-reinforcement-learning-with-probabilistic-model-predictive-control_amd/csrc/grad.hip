@@ -72,7 +72,7 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     for (int v : {2, 3, 4, 6, 8}) if (D <= v) { DP = v; break; }
     if (DP == 0 || NX > 6) { h->err = "gradient: supported for D <= 8 with A (+ time) <= 6, and for 8 < D <= 16"; return GPMPC_ERR_LIMIT; }
     const int NXP = NX <= 1 ? 1 : (NX <= 2 ? 2 : 6);
-    const int RS = 2 + 2 * DP + NXP;
+    const int RS = grad_row_stride(DP, NXP);
     const int NSP = 1 + DP + DP * (DP + 1) / 2 + NXP;
 
     GradArgs g;

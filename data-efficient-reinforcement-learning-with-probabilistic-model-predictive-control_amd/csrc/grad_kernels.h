@@ -81,6 +81,11 @@ __device__ inline void decode_mean_moment(int comp, int D, int NX, int& i1, int&
     i2 = D + (comp - i1 * NX);
 }
 
+// Row record of the gradient's moment pass: ka'_i | ra_i | g_i (DP) | u_i (DP) | nu_ie / l_ae^2 (NXP), padded to an EVEN number of
+// doubles so that every record is 16-byte aligned and the compiler can read it as ds_read_b128 (4 LDS cycles per 16 bytes; an
+// odd stride leaves it pairs of 8-byte reads, ds_read2_b64, at 8) -- the pass is within 25 % of the LDS return rate.
+__host__ __device__ constexpr int grad_row_stride(int DP, int NXP) { return (2 + 2 * DP + NXP + 1) & ~1; }
+
 struct MomLayout {
     int c_ils2, c_xr, c_logvar, c_tab, m, Sig, aug, ints, nu, xe, lb, kb, rows, part, total;
 };
@@ -112,7 +117,7 @@ template <int DP, int NXP, int NT, int NC>
 __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NT / kWave;
-    constexpr int RS = 2 + 2 * DP + NXP;     // row record: ka'_i, beta_ai, g_i (DP), u_i (DP), nu_ie / l_ae^2 (NXP)
+    constexpr int RS = grad_row_stride(DP, NXP);     // row record: ka'_i, beta_ai, g_i (DP), u_i (DP), nu_ie / l_ae^2 (NXP), pad
     constexpr int NH = DP * (DP + 1) / 2;
     constexpr int NSP = 1 + DP + NH + NXP;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -432,7 +437,7 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
             if (nrows > 0) {
                 const double* rec = a_rows + ((size_t)gq * NR + i0) * RS;
                 const double* Tp = p.Tm + ((size_t)a * (N + kTPad) + i0) * N + j;
-                auto accumulate = [&](int q, double e, const double* rr) {
+                auto accumulate = [&](int q, double e, const double (&rr)[RS]) {
                     cs[q] += e;
                     int k = 0;
 #pragma unroll
@@ -456,9 +461,12 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
                         for (int q = 0; q < NC; ++q) tn[u][q] = diag ? Tp[(size_t)u * N + q] : 1.0;
                     for (int it = 0; it < nrows; it += 2) {
                         double e[2][NC];
+                        double rv[2][RS];                      // the two row records, read as ds_read_b128 (grad_row_stride)
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) lds_load_pairs<2 + 2 * DP + NXP>(rec + u * RS, rv[u]);
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
-                            const double* rr = rec + u * RS;
+                            const double(&rr)[RS] = rv[u];
 #pragma unroll
                             for (int q = 0; q < NC; ++q) {
                                 const double tv = tn[u][q];
@@ -479,7 +487,7 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
 #pragma unroll
                         for (int u = 0; u < 2; ++u)
 #pragma unroll
-                            for (int q = 0; q < NC; ++q) accumulate(q, e[u][q], rec + u * RS);
+                            for (int q = 0; q < NC; ++q) accumulate(q, e[u][q], rv[u]);
                         rec += 2 * RS;
                         Tp += (size_t)2 * N;
                     }

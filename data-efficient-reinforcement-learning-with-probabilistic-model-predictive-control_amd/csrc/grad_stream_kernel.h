@@ -51,7 +51,7 @@ __global__ __launch_bounds__(kGsThreads) void pair_moments_stream_kernel(const G
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NT = kGsThreads;
     constexpr int NW = NT / kWave;
-    constexpr int RS = 2 + 2 * DP + NXP;     // row record: ka'_i, beta_ai, g_i (DP), u_i (DP), nu_ie / l_ae^2 (NXP)
+    constexpr int RS = grad_row_stride(DP, NXP);     // row record: ka'_i, beta_ai, g_i (DP), u_i (DP), nu_ie / l_ae^2 (NXP), pad
     constexpr int NH = DP * (DP + 1) / 2;
     constexpr int NSP = 1 + DP + NH + NXP;
     constexpr int CBW = (DP <= 4) ? 2 : 1;   // column blocks per wavefront and pass (accumulators in registers)

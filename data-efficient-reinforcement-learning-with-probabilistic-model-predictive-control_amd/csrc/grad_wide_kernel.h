@@ -345,8 +345,8 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                             mfma_d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                             for (int qd = 0; qd < 4; ++qd) {
-                                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0p[4 * qd], hB[qd], c0, 0, 0, 0);
-                                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1p[4 * qd], hB[qd], c1, 0, 0, 0);
+                                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lds_b64(a0p + 4 * qd), hB[qd], c0, 0, 0, 0);
+                                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lds_b64(a1p + 4 * qd), hB[qd], c1, 0, 0, 0);
                             }
                             const double* w0 = st + (size_t)(16 * rt + grp) * RSW;      // row 16 rt + 4 r + grp: + 4 r RSW
                             double wt[8], cv[8], nv[8], tv[8], qv[8];
@@ -358,11 +358,11 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                                     const int i0 = ch * CHW + 16 * rt + 4 * r + grp, i1 = i0 + 16;
                                     const double k0 = p.iK[((size_t)a * N + (i0 < N ? i0 : N - 1)) * N + jc];
                                     const double k1 = p.iK[((size_t)a * N + (i1 < N ? i1 : N - 1)) * N + jc];
-                                    wt[r] = q0[0] * fma(q0[1], bcj, -k0);
-                                    wt[4 + r] = q1[0] * fma(q1[1], bcj, -k1);
+                                    wt[r] = lds_b64(q0) * fma(lds_b64(q0 + 1), bcj, -k0);
+                                    wt[4 + r] = lds_b64(q1) * fma(lds_b64(q1 + 1), bcj, -k1);
                                 } else {
-                                    wt[r] = q0[0];
-                                    wt[4 + r] = q1[0];
+                                    wt[r] = lds_b64(q0);
+                                    wt[4 + r] = lds_b64(q1);
                                 }
                                 cv[r] = c0[r];
                                 cv[4 + r] = c1[r];
@@ -391,9 +391,9 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                             csum1 += (wt[4] + wt[5]) + (wt[6] + wt[7]);
                             if (orient == 0) {
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[r], w0[(size_t)(4 * r) * RSW + 2 + col16], vc, 0, 0, 0);
+                                for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[r], lds_b64(w0 + (size_t)(4 * r) * RSW + 2 + col16), vc, 0, 0, 0);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[4 + r], w0[(size_t)(16 + 4 * r) * RSW + 2 + col16], vc, 0, 0, 0);
+                                for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[4 + r], lds_b64(w0 + (size_t)(16 + 4 * r) * RSW + 2 + col16), vc, 0, 0, 0);
                             }
                         }
                     }

@@ -46,6 +46,55 @@
 
 namespace gpmpc_hip {
 
+// An 8-byte LDS read that stays ONE ds_read_b64.  The compiler pairs neighbouring 8-byte LDS reads of one base register into
+// ds_read2_b64, which gfx950 services as two accesses of four 16-lane groups each with banks taken mod 32: 8 LDS cycles for
+// 16 bytes per lane even for a broadcast (two ds_read_b64: 2 + 2), and for the A operand of the fp64 matrix instruction (row
+// l & 15 of a stage with an 18-double row stride) rows r and r + 8 of a group collide on top (16 cycles against 4); measured:
+// profiles/r04_lds_read_forms.txt.  An opaque copy of the address gives the read a base register of its own, which the
+// load/store optimiser cannot pair.  (-DGPMPC_LDS_MERGED: the compiler's pairing, kept for the A/B build `make ab`.)
+typedef const __attribute__((address_space(3))) double* lds_cptr;
+__device__ inline double lds_b64(const double* p) {
+#if defined(GPMPC_LDS_MERGED)
+    return *p;
+#else
+    lds_cptr q = (lds_cptr)p;
+    asm volatile("" : "+v"(q));
+    return *q;
+#endif
+}
+
+// Row records of the pairwise pass (one per memory point and output pair, broadcast from LDS to every lane of a wavefront).
+//   RowRecPacked<DP>  : ea_i | ra_i | g_i (DP), stride DP + 2 -- the staged records of rollout_stream_kernel.h;
+//   RowRecAligned<DP> : g_i (DP) | ea_i | ra_i | pad, stride rounded up to an EVEN number of doubles, records 16-byte aligned and
+//                       read as ds_read_b128: 4 LDS cycles per 16 bytes where the compiler's pairing of 8-byte reads
+//                       (ds_read2_b64) takes 8 -- at D <= 4 the fused-horizon kernel is as close to the LDS return rate as to
+//                       the fp64 issue rate, and a diagonal pair needs only the leading DP + 1 doubles (DP = 3: two reads).
+typedef double lds_d2 __attribute__((ext_vector_type(2)));
+// the leading NL doubles of a 16-byte aligned LDS record as ds_read_b128 (NV >= NL rounded up to even)
+template <int NL, int NV>
+__device__ inline void lds_load_pairs(const double* rec, double (&v)[NV]) {
+    static_assert(NV >= ((NL + 1) & ~1), "destination too short");
+    const lds_d2* r2 = reinterpret_cast<const lds_d2*>(rec);
+#pragma unroll
+    for (int k = 0; k < (NL + 1) / 2; ++k) { const lds_d2 t = r2[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+}
+
+template <int DP>
+struct RowRecPacked {
+    static constexpr int RS = DP + 2, EA = 0, RA = 1, G = 2;
+    // the leading `NL` doubles of a record into v
+    template <int NL>
+    static __device__ inline void load(const double* rec, double (&v)[RS]) {
+#pragma unroll
+        for (int k = 0; k < NL; ++k) v[k] = rec[k];
+    }
+};
+template <int DP>
+struct RowRecAligned {
+    static constexpr int RS = (DP + 3) & ~1, EA = DP, RA = DP + 1, G = 0;
+    template <int NL>
+    static __device__ inline void load(const double* rec, double (&v)[RS]) { lds_load_pairs<NL>(rec, v); }
+};
 
 constexpr int kMaxTaylor = 14;     // highest Taylor degree of exp(g.w); beyond that: direct exp path
 constexpr int kMaxMono = 256;      // most monomials of the separable (off-diagonal) evaluation
@@ -94,7 +143,7 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     int q = o;
     L.nu = q;   q += rnd2(D * N);
     L.lb = q;   q += rnd2(D * N);
-    L.rows = q; q += G * (N + CH) * (DP + 2);       // + CH zero rows per pair (lanes of a wave share the trip count)
+    L.rows = q; q += G * (N + CH) * ((DP + 3) & ~1);   // RowRecAligned<DP>::RS; + CH zero rows per pair (lanes of a wave share the trip count)
     L.kb = q;   q += rnd2(G * N);
     L.lds_total = q;
     L.pp_total = q - o;
@@ -306,9 +355,9 @@ constexpr int kTPad = 72;      // zero rows appended to every T_a: a wave may ru
 // body carries no predication (scalar loop, loads issue ahead of the math).
 //   diagonal pair : sum_i T[i][j] * ea_i * P_K(g_i . w_j)            (row record [0] = ea_i)
 //   off-diagonal  : sum_i ra_i * P_K(g_i . w_j)                      (row record [1] = beta_ai ea_i)
-template <int DP, int K>
+template <int DP, int K, class REC = RowRecPacked<DP>>
 __device__ inline double item_taylor(const double* rec, int nrows, const double (&w)[DP], bool diag, const double* Tp, int N) {
-    constexpr int RS = DP + 2;
+    constexpr int RS = REC::RS;
     constexpr int U = 4;
     double acc = 0.0;
     if (diag) {
@@ -324,12 +373,13 @@ __device__ inline double item_taylor(const double* rec, int nrows, const double 
             double cc[U], ev[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const double* r = rec + u * RS;
-                double c = r[2] * w[0];
+                double r[RS];
+                REC::template load<(REC::EA > REC::G ? REC::EA + 1 : REC::G + DP)>(rec + u * RS, r);
+                double c = r[REC::G] * w[0];
 #pragma unroll
-                for (int d = 1; d < DP; ++d) c = fma(r[2 + d], w[d], c);
+                for (int d = 1; d < DP; ++d) c = fma(r[REC::G + d], w[d], c);
                 cc[u] = c;
-                ev[u] = r[0];
+                ev[u] = r[REC::EA];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) acc = fma(taylor_exp<K>(cc[u]) * ev[u], tv[u], acc);
@@ -343,12 +393,13 @@ __device__ inline double item_taylor(const double* rec, int nrows, const double 
             double cc[U], rv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const double* r = rec + u * RS;
-                double c = r[2] * w[0];
+                double r[RS];
+                REC::template load<RS>(rec + u * RS, r);
+                double c = r[REC::G] * w[0];
 #pragma unroll
-                for (int d = 1; d < DP; ++d) c = fma(r[2 + d], w[d], c);
+                for (int d = 1; d < DP; ++d) c = fma(r[REC::G + d], w[d], c);
                 cc[u] = c;
-                rv[u] = r[1];
+                rv[u] = r[REC::RA];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) acc = fma(taylor_exp<K>(cc[u]), rv[u], acc);
@@ -394,10 +445,10 @@ __device__ inline double fast_exp(double x, const double* tab /* kExp2Tab copied
 }
 
 // Same item, direct form exp(ka'_i + kb'_j + g_i . w_j)  (row record [0] = ka'_i, [1] = beta_ai).
-template <int DP>
+template <int DP, class REC = RowRecPacked<DP>>
 __device__ inline double item_exp(const double* rec, int nrows, const double (&w)[DP], double kbj, bool diag,
                                   const double* Tp, int N, const double* tab) {
-    constexpr int RS = DP + 2;
+    constexpr int RS = REC::RS;
     constexpr int U = 4;
     double acc = 0.0;
     if (diag) {
@@ -407,10 +458,11 @@ __device__ inline double item_exp(const double* rec, int nrows, const double (&w
             for (int u = 0; u < U; ++u) tv[u] = Tp[(size_t)u * N];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const double* r = rec + u * RS;
-                double arg = r[0] + kbj;
+                double r[RS];
+                REC::template load<(REC::EA > REC::G ? REC::EA + 1 : REC::G + DP)>(rec + u * RS, r);
+                double arg = r[REC::EA] + kbj;
 #pragma unroll
-                for (int d = 0; d < DP; ++d) arg = fma(r[2 + d], w[d], arg);
+                for (int d = 0; d < DP; ++d) arg = fma(r[REC::G + d], w[d], arg);
                 aa[u] = arg;
             }
 #pragma unroll
@@ -423,12 +475,13 @@ __device__ inline double item_exp(const double* rec, int nrows, const double (&w
             double aa[U], bv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const double* r = rec + u * RS;
-                double arg = r[0] + kbj;
+                double r[RS];
+                REC::template load<RS>(rec + u * RS, r);
+                double arg = r[REC::EA] + kbj;
 #pragma unroll
-                for (int d = 0; d < DP; ++d) arg = fma(r[2 + d], w[d], arg);
+                for (int d = 0; d < DP; ++d) arg = fma(r[REC::G + d], w[d], arg);
                 aa[u] = arg;
-                bv[u] = r[1];
+                bv[u] = r[REC::RA];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) acc = fma(fast_exp(aa[u], tab), bv[u], acc);
@@ -444,10 +497,10 @@ __device__ inline double item_exp(const double* rec, int nrows, const double (&w
 // U = rows per trip = depth of the T prefetch.  With the tables in L2 (configs 1-3) two rows ahead are enough and the
 // shorter trip is 2 % faster; at config 4 (N = 1000, D = 4) the loads come from the Infinity Cache and four rows ahead gain
 // 5 % (115.2 -> 109.2 ms); eight rows spill and lose.
-template <int DP, int K, int U>
+template <int DP, int K, int U, class REC = RowRecAligned<DP>>
 __device__ inline void item_taylor2(const double* rec, int nrows, const double (&w0)[DP], const double (&w1)[DP], bool diag,
                                     const double* Tp, int N, double& acc0, double& acc1) {
-    constexpr int RS = DP + 2;
+    constexpr int RS = REC::RS;
     acc0 = 0.0;
     acc1 = 0.0;
     if (diag) {
@@ -461,12 +514,13 @@ __device__ inline void item_taylor2(const double* rec, int nrows, const double (
             double c0[U], c1[U], ev[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const double* r = rec + u * RS;
-                double a = r[2] * w0[0], b = r[2] * w1[0];
+                double r[RS];
+                REC::template load<(REC::EA > REC::G ? REC::EA + 1 : REC::G + DP)>(rec + u * RS, r);
+                double a = r[REC::G] * w0[0], b = r[REC::G] * w1[0];
 #pragma unroll
-                for (int d = 1; d < DP; ++d) { a = fma(r[2 + d], w0[d], a); b = fma(r[2 + d], w1[d], b); }
+                for (int d = 1; d < DP; ++d) { a = fma(r[REC::G + d], w0[d], a); b = fma(r[REC::G + d], w1[d], b); }
                 c0[u] = a; c1[u] = b;
-                ev[u] = r[0];
+                ev[u] = r[REC::EA];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -483,12 +537,13 @@ __device__ inline void item_taylor2(const double* rec, int nrows, const double (
             double c0[U], c1[U], rv[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
-                const double* r = rec + u * RS;
-                double a = r[2] * w0[0], b = r[2] * w1[0];
+                double r[RS];
+                REC::template load<RS>(rec + u * RS, r);
+                double a = r[REC::G] * w0[0], b = r[REC::G] * w1[0];
 #pragma unroll
-                for (int d = 1; d < DP; ++d) { a = fma(r[2 + d], w0[d], a); b = fma(r[2 + d], w1[d], b); }
+                for (int d = 1; d < DP; ++d) { a = fma(r[REC::G + d], w0[d], a); b = fma(r[REC::G + d], w1[d], b); }
                 c0[u] = a; c1[u] = b;
-                rv[u] = r[1];
+                rv[u] = r[REC::RA];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -500,10 +555,10 @@ __device__ inline void item_taylor2(const double* rec, int nrows, const double (
     }
 }
 
-template <int DP>
+template <int DP, class REC = RowRecAligned<DP>>
 __device__ inline void item_exp2(const double* rec, int nrows, const double (&w0)[DP], const double (&w1)[DP], double kb0,
                                  double kb1, bool diag, const double* Tp, int N, const double* tab, double& acc0, double& acc1) {
-    constexpr int RS = DP + 2;
+    constexpr int RS = REC::RS;
     constexpr int U = 2;
     acc0 = 0.0;
     acc1 = 0.0;
@@ -511,13 +566,14 @@ __device__ inline void item_exp2(const double* rec, int nrows, const double (&w0
         double a0[U], a1[U], wt0[U], wt1[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const double* r = rec + u * RS;
-            double x = r[0] + kb0, y = r[0] + kb1;
+            double r[RS];
+            REC::template load<RS>(rec + u * RS, r);
+            double x = r[REC::EA] + kb0, y = r[REC::EA] + kb1;
 #pragma unroll
-            for (int d = 0; d < DP; ++d) { x = fma(r[2 + d], w0[d], x); y = fma(r[2 + d], w1[d], y); }
+            for (int d = 0; d < DP; ++d) { x = fma(r[REC::G + d], w0[d], x); y = fma(r[REC::G + d], w1[d], y); }
             a0[u] = x; a1[u] = y;
-            wt0[u] = diag ? Tp[(size_t)u * N] : r[1];
-            wt1[u] = diag ? Tp[(size_t)u * N + 1] : r[1];
+            wt0[u] = diag ? Tp[(size_t)u * N] : r[REC::RA];
+            wt1[u] = diag ? Tp[(size_t)u * N + 1] : r[REC::RA];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -680,8 +736,11 @@ __device__ inline void sep3_band(int lane, int N, int side, const double* rec0, 
         for (int pt = lane; pt < N; pt += 64) {
             double x0, x1, x2, wt;
             if (side == 0) {
-                const double* rec = rec0 + (size_t)pt * RS;
-                wt = rec[1]; x0 = rec[2]; x1 = rec[3]; x2 = rec[4];
+                // lanes own points: per-lane 16-byte reads at the record stride of 48 bytes are conflict-free (the start banks of
+                // a 16-lane group are the 16 multiples of 4)
+                double r[RowRecAligned<3>::RS];
+                RowRecAligned<3>::load<RowRecAligned<3>::RS>(rec0 + (size_t)pt * RS, r);
+                wt = r[RowRecAligned<3>::RA]; x0 = r[0]; x1 = r[1]; x2 = r[2];
             } else {
                 wt = kb[pt];
                 x0 = nu[pt] * il[0]; x1 = nu[N + pt] * il[1]; x2 = nu[2 * N + pt] * il[2];
@@ -760,7 +819,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
         if (p.slow[blockIdx.x] != p.t_begin + 1) return;
     }
     constexpr int NW = NT / kWave;
-    constexpr int RS = DP + 2;              // row record: [0] ea_i | ka'_i, [1] ra_i | beta_ai, [2..] g_i
+    using REC = RowRecAligned<DP>;          // row record: g_i (DP) | ea_i or ka'_i | ra_i or beta_ai | pad, 16-byte aligned
+    constexpr int RS = REC::RS;
     const int tid = threadIdx.x;
     const int c = blockIdx.x;
     const int D = (DX > 0) ? DX : p.D;
@@ -1128,17 +1188,18 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     if (rowside) {
                         double* rec = a_rows + ((size_t)gq * NR + pt) * RS;
 #pragma unroll
-                        for (int d = 0; d < DP; ++d) rec[2 + d] = g[d];
+                        for (int d = 0; d < DP; ++d) rec[REC::G + d] = g[d];
                         if (K > 0) {
                             const double ea = fast_exp(kk, c_exptab);
-                            rec[0] = ea;
-                            rec[1] = ea * bc;
+                            rec[REC::EA] = ea;
+                            rec[REC::RA] = ea * bc;
                             if (a == b) a_kb[gq * N + pt] = ea;
                         } else {
-                            rec[0] = kk;
-                            rec[1] = bc;
+                            rec[REC::EA] = kk;
+                            rec[REC::RA] = bc;
                             if (a == b) a_kb[gq * N + pt] = kk;
                         }
+                        if constexpr (REC::RS > DP + 2) rec[DP + 2] = 0.0;          // the pad travels with the 16-byte reads
                     } else {
                         a_kb[gq * N + pt] = (K > 0) ? fast_exp(kk, c_exptab) * bc : kk;
                     }
@@ -1213,10 +1274,11 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                             double x[DP];
                             double wt;
                             if (side == 0) {
-                                const double* rec = a_rows + ((size_t)gq * NR + pt) * RS;
-                                wt = rec[1];
+                                double r[RS];
+                                REC::template load<RS>(a_rows + ((size_t)gq * NR + pt) * RS, r);
+                                wt = r[REC::RA];
 #pragma unroll
-                                for (int d = 0; d < DP; ++d) x[d] = rec[2 + d];
+                                for (int d = 0; d < DP; ++d) x[d] = r[REC::G + d];
                             } else {
                                 wt = a_kb[gq * N + pt];
 #pragma unroll
@@ -1302,19 +1364,19 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                             acc = fma(acc0, kbj, acc1 * kb1) * (diag ? 2.0 : 1.0);
                         }
                     } else if (K == 0) {
-                        acc = item_exp<DP>(rec, nrows, w, kbj, diag, Tp, N, c_exptab);
+                        acc = item_exp<DP, REC>(rec, nrows, w, kbj, diag, Tp, N, c_exptab);
                         acc *= diag ? 2.0 : p.beta[b * N + j];
                     } else {
-                        if (K <= 2) acc = item_taylor<DP, 2>(rec, nrows, w, diag, Tp, N);
-                        else if (K == 3) acc = item_taylor<DP, 3>(rec, nrows, w, diag, Tp, N);
-                        else if (K == 4) acc = item_taylor<DP, 4>(rec, nrows, w, diag, Tp, N);
-                        else if (K == 5) acc = item_taylor<DP, 5>(rec, nrows, w, diag, Tp, N);
-                        else if (K == 6) acc = item_taylor<DP, 6>(rec, nrows, w, diag, Tp, N);
-                        else if (K == 7) acc = item_taylor<DP, 7>(rec, nrows, w, diag, Tp, N);
-                        else if (K == 8) acc = item_taylor<DP, 8>(rec, nrows, w, diag, Tp, N);
-                        else if (K <= 10) acc = item_taylor<DP, 10>(rec, nrows, w, diag, Tp, N);
-                        else if (K <= 12) acc = item_taylor<DP, 12>(rec, nrows, w, diag, Tp, N);
-                        else acc = item_taylor<DP, 14>(rec, nrows, w, diag, Tp, N);
+                        if (K <= 2) acc = item_taylor<DP, 2, REC>(rec, nrows, w, diag, Tp, N);
+                        else if (K == 3) acc = item_taylor<DP, 3, REC>(rec, nrows, w, diag, Tp, N);
+                        else if (K == 4) acc = item_taylor<DP, 4, REC>(rec, nrows, w, diag, Tp, N);
+                        else if (K == 5) acc = item_taylor<DP, 5, REC>(rec, nrows, w, diag, Tp, N);
+                        else if (K == 6) acc = item_taylor<DP, 6, REC>(rec, nrows, w, diag, Tp, N);
+                        else if (K == 7) acc = item_taylor<DP, 7, REC>(rec, nrows, w, diag, Tp, N);
+                        else if (K == 8) acc = item_taylor<DP, 8, REC>(rec, nrows, w, diag, Tp, N);
+                        else if (K <= 10) acc = item_taylor<DP, 10, REC>(rec, nrows, w, diag, Tp, N);
+                        else if (K <= 12) acc = item_taylor<DP, 12, REC>(rec, nrows, w, diag, Tp, N);
+                        else acc = item_taylor<DP, 14, REC>(rec, nrows, w, diag, Tp, N);
                         acc *= diag ? 2.0 * kbj : kbj;
                     }
                     acc = valid ? acc : 0.0;

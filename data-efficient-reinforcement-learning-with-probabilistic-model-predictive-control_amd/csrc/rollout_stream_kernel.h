@@ -89,7 +89,7 @@ __device__ inline void mfma_c_tiles(const double* st, int t0, const double (&bw)
     const double* a1p = a0p + 16 * RS;
     double a0[DP / 4], a1[DP / 4];
 #pragma unroll
-    for (int q = 0; q < DP / 4; ++q) { a0[q] = a0p[4 * q]; a1[q] = a1p[4 * q]; }
+    for (int q = 0; q < DP / 4; ++q) { a0[q] = lds_b64(a0p + 4 * q); a1[q] = lds_b64(a1p + 4 * q); }
     c0 = {0.0, 0.0, 0.0, 0.0};
     c1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -126,7 +126,7 @@ __device__ inline double block_mfma_taylor(const double* st, int ntiles, const d
         for (int r = 0; r < 4; ++r) {
             const double* w0 = wrow + (size_t)(16 * t + 4 * r) * RS;
             const double* w1 = w0 + 16 * RS;
-            if (DIAG) { wt[r] *= w0[0]; wt[4 + r] *= w1[0]; } else { wt[r] = w0[1]; wt[4 + r] = w1[1]; }
+            if (DIAG) { wt[r] *= lds_b64(w0); wt[4 + r] *= lds_b64(w1); } else { wt[r] = lds_b64(w0 + 1); wt[4 + r] = lds_b64(w1 + 1); }
         }
         double cv[8], pv[8];
 #pragma unroll
@@ -188,7 +188,7 @@ __device__ inline double block_mfma_table(const double* st, int ntiles, const do
         for (int r = 0; r < 4; ++r) {
             const double* w0 = wrow + (size_t)(16 * t + 4 * r) * RS;
             const double* w1 = w0 + 16 * RS;
-            if (DIAG) { wt[r] *= w0[0]; wt[4 + r] *= w1[0]; } else { wt[r] = w0[1]; wt[4 + r] = w1[1]; }
+            if (DIAG) { wt[r] *= lds_b64(w0); wt[4 + r] *= lds_b64(w1); } else { wt[r] = lds_b64(w0 + 1); wt[4 + r] = lds_b64(w1 + 1); }
         }
         // the 8 evaluations of table_exp stage by stage: written as 8 calls the compiler emits 8 serial chains of 11 dependent
         // instructions (a dependent fp64 instruction issues every ~40 cycles: 16 cycles per instruction and SIMD even with

