@@ -61,7 +61,8 @@ struct WideArgs {
 __host__ __device__ inline int wide_nsp(int D, int NX) { return rnd2(1 + D + D * D + NX); }
 
 constexpr int kWideStageRows = 64;     // rows per staged chunk (two buffers)
-constexpr int kWideRS = 18;            // row record: factor | beta | u (16)
+constexpr int kWideRS = 19;            // row record: factor | beta | u (16) | pad -- an ODD stride: the A-operand reads (ds_read2_b64, banks
+                                       // mod 32 per 16-lane group) of rows r and r + 8 collide at 18 (rollout_stream_kernel.h: stream_row_stride)
 constexpr int kWideFold = 2 * 256 + 16 + 16 * 16 + 16;     // per wavefront: V tile | w tile | c_j | extra inputs of the 16 columns | column factors
 
 struct WideMomLayout {
@@ -345,8 +346,8 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                             mfma_d4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                             for (int qd = 0; qd < 4; ++qd) {
-                                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(lds_b64(a0p + 4 * qd), hB[qd], c0, 0, 0, 0);
-                                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(lds_b64(a1p + 4 * qd), hB[qd], c1, 0, 0, 0);
+                                c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0p[4 * qd], hB[qd], c0, 0, 0, 0);
+                                c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1p[4 * qd], hB[qd], c1, 0, 0, 0);
                             }
                             const double* w0 = st + (size_t)(16 * rt + grp) * RSW;      // row 16 rt + 4 r + grp: + 4 r RSW
                             double wt[8], cv[8], nv[8], tv[8], qv[8];
@@ -358,11 +359,11 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                                     const int i0 = ch * CHW + 16 * rt + 4 * r + grp, i1 = i0 + 16;
                                     const double k0 = p.iK[((size_t)a * N + (i0 < N ? i0 : N - 1)) * N + jc];
                                     const double k1 = p.iK[((size_t)a * N + (i1 < N ? i1 : N - 1)) * N + jc];
-                                    wt[r] = lds_b64(q0) * fma(lds_b64(q0 + 1), bcj, -k0);
-                                    wt[4 + r] = lds_b64(q1) * fma(lds_b64(q1 + 1), bcj, -k1);
+                                    wt[r] = q0[0] * fma(q0[1], bcj, -k0);
+                                    wt[4 + r] = q1[0] * fma(q1[1], bcj, -k1);
                                 } else {
-                                    wt[r] = lds_b64(q0);
-                                    wt[4 + r] = lds_b64(q1);
+                                    wt[r] = q0[0];
+                                    wt[4 + r] = q1[0];
                                 }
                                 cv[r] = c0[r];
                                 cv[4 + r] = c1[r];
@@ -391,9 +392,9 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                             csum1 += (wt[4] + wt[5]) + (wt[6] + wt[7]);
                             if (orient == 0) {
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[r], lds_b64(w0 + (size_t)(4 * r) * RSW + 2 + col16), vc, 0, 0, 0);
+                                for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[r], w0[(size_t)(4 * r) * RSW + 2 + col16], vc, 0, 0, 0);
 #pragma unroll
-                                for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[4 + r], lds_b64(w0 + (size_t)(16 + 4 * r) * RSW + 2 + col16), vc, 0, 0, 0);
+                                for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[4 + r], w0[(size_t)(16 + 4 * r) * RSW + 2 + col16], vc, 0, 0, 0);
                             }
                         }
                     }

@@ -81,15 +81,25 @@ __device__ inline double wave_gauss_solve(double* aug, int D, int nrhs, int ld, 
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
+// Row stride of the staged records.  Matrix-core pass (DP = 8, 16): an ODD number of doubles.  The compiler reads the A operand
+// (lane l: component 4 q + (l >> 4) of row l & 15, q = 0 .. DP / 4 - 1) as ds_read2_b64 pairs, which gfx950 services per 16-lane
+// group with banks taken mod 32: at the natural stride DP + 2 = 18 doubles (36 dwords = 4 mod 32) rows r and r + 8 of a group
+// collide -- 16 LDS cycles per instruction where 8 suffice, 31 % of the kernel's LDS cycles by the counters
+// (profiles/r04_c5_late_pmc_t0.txt: SQ_LDS_BANK_CONFLICT 3.44e10 = 4 reads x 8 extra cycles x 1.07e9 tile pairs, to the digit).
+// At 19 doubles (38 dwords = 6 mod 32) the 16 rows of a group fall on 16 distinct even banks.  Separate ds_read_b64 would need
+// half the cycles again (profiles/r04_lds_read_forms.txt) but cost an address instruction each on the shared fp64 / integer
+// issue port, and the kernel is bound there: measured 5 - 7 % SLOWER (profiles/r04b_ab_c5_late_*.txt).
+__host__ __device__ constexpr int stream_row_stride(int DP) { return (DP % 4 == 0 && DP >= 8) ? DP + 3 : DP + 2; }
+
 // c tiles of TWO 16-row tiles (rows 16 t0 .., 16 t0 + 16 ..) of the stage against the wave's 16 columns.
 template <int DP>
 __device__ inline void mfma_c_tiles(const double* st, int t0, const double (&bw)[DP / 4], int lane, mfma_d4& c0, mfma_d4& c1) {
-    constexpr int RS = DP + 2;
+    constexpr int RS = stream_row_stride(DP);
     const double* a0p = st + (size_t)(16 * t0 + (lane & 15)) * RS + 2 + (lane >> 4);
     const double* a1p = a0p + 16 * RS;
     double a0[DP / 4], a1[DP / 4];
 #pragma unroll
-    for (int q = 0; q < DP / 4; ++q) { a0[q] = lds_b64(a0p + 4 * q); a1[q] = lds_b64(a1p + 4 * q); }
+    for (int q = 0; q < DP / 4; ++q) { a0[q] = a0p[4 * q]; a1[q] = a1p[4 * q]; }
     c0 = {0.0, 0.0, 0.0, 0.0};
     c1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -108,7 +118,7 @@ __device__ inline void mfma_c_tiles(const double* st, int t0, const double (&bw)
 // to save registers) cost 8 (K + 1) x 40 cycles per iteration against 512 cycles of matrix-core work.
 template <int DP, int K, bool DIAG>
 __device__ inline double block_mfma_taylor(const double* st, int ntiles, const double (&bw)[DP / 4], const double* Tp, int N, int lane) {
-    constexpr int RS = DP + 2;
+    constexpr int RS = stream_row_stride(DP);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const double* wrow = st + (size_t)(lane >> 4) * RS;
     for (int t = 0; t < ntiles; t += 2) {
@@ -126,7 +136,7 @@ __device__ inline double block_mfma_taylor(const double* st, int ntiles, const d
         for (int r = 0; r < 4; ++r) {
             const double* w0 = wrow + (size_t)(16 * t + 4 * r) * RS;
             const double* w1 = w0 + 16 * RS;
-            if (DIAG) { wt[r] *= lds_b64(w0); wt[4 + r] *= lds_b64(w1); } else { wt[r] = lds_b64(w0 + 1); wt[4 + r] = lds_b64(w1 + 1); }
+            if (DIAG) { wt[r] *= w0[0]; wt[4 + r] *= w1[0]; } else { wt[r] = w0[1]; wt[4 + r] = w1[1]; }
         }
         double cv[8], pv[8];
 #pragma unroll
@@ -170,7 +180,7 @@ __device__ inline double table_exp(double c, const double* tab /* centre of the 
 template <int DP, bool DIAG>
 __device__ inline double block_mfma_table(const double* st, int ntiles, const double (&bw)[DP / 4], const double* Tp, int N, int lane,
                                           const double* tab) {
-    constexpr int RS = DP + 2;
+    constexpr int RS = stream_row_stride(DP);
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const double* wrow = st + (size_t)(lane >> 4) * RS;
     for (int t = 0; t < ntiles; t += 2) {
@@ -188,7 +198,7 @@ __device__ inline double block_mfma_table(const double* st, int ntiles, const do
         for (int r = 0; r < 4; ++r) {
             const double* w0 = wrow + (size_t)(16 * t + 4 * r) * RS;
             const double* w1 = w0 + 16 * RS;
-            if (DIAG) { wt[r] *= lds_b64(w0); wt[4 + r] *= lds_b64(w1); } else { wt[r] = lds_b64(w0 + 1); wt[4 + r] = lds_b64(w1 + 1); }
+            if (DIAG) { wt[r] *= w0[0]; wt[4 + r] *= w1[0]; } else { wt[r] = w0[1]; wt[4 + r] = w1[1]; }
         }
         // the 8 evaluations of table_exp stage by stage: written as 8 calls the compiler emits 8 serial chains of 11 dependent
         // instructions (a dependent fp64 instruction issues every ~40 cycles: 16 cycles per instruction and SIMD even with
@@ -227,7 +237,7 @@ __device__ inline double block_mfma_table(const double* st, int ntiles, const do
 template <int DP, bool DIAG>
 __device__ inline double block_mfma_exp(const double* st, int ntiles, const double (&bw)[DP / 4], double kbj, const double* Tp, int N,
                                         int lane, const double* tab) {
-    constexpr int RS = DP + 2;
+    constexpr int RS = stream_row_stride(DP);
     double acc[2] = {0.0, 0.0};
     const double* wrow = st + (size_t)(lane >> 4) * RS;
     for (int t = 0; t < ntiles; t += 2) {
@@ -277,7 +287,7 @@ __host__ __device__ inline StreamLayout make_stream_layout(int N, int D, int A, 
     L.aug = o;      o += 2 * D * D;
     L.red = o;      o += rnd2(16 * (DP + 1));
     L.kb = o;       o += rnd2(N);
-    L.stage = o;    o += 2 * (CH + 16) * (DP + 2);      // + 16 rows: the matrix-core items take row tiles two at a time
+    L.stage = o;    o += rnd2(2 * (CH + 16) * stream_row_stride(DP));      // + 16 rows: the matrix-core items take row tiles two at a time
     L.ints = o;     o += 4;
     L.c_ils2 = o;   o += rnd2(D * E);
     L.c_logvar = o; o += rnd2(D);
@@ -295,7 +305,7 @@ template <int DP, int NT>
 __global__ __launch_bounds__(NT) void rollout_stream_kernel(const RolloutArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NT / kWave;
-    constexpr int RS = DP + 2;
+    constexpr int RS = stream_row_stride(DP);
     constexpr int DPC = DP <= 2 ? 2 : (DP <= 4 ? 4 : (DP <= 8 ? 8 : 16));     // lanes that share one row record
     static_assert(NT == 1024, "stage fill maps 64 rows x 16 components onto 1024 threads");
     constexpr bool kMfma = (DP % 4 == 0) && DP >= 8;          // pairwise pass on the fp64 matrix cores
