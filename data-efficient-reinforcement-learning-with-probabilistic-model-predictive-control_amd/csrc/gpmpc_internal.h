@@ -66,6 +66,11 @@ struct RolloutArgs {
     int ntiles;
     const double* tile_part;
     const int* slow;         // (B) t + 1: the candidate's step t is this kernel's (off-diagonal pair outside the separable range)
+    // gradient launches: when the forward takes the batch-major path, its tile pass forms the moments of the diagonal pairs as
+    // well (pair_tile_grad_kernel.h, FUSED) instead of being repeated by a separate moment pass over the stored trajectory
+    double* grad_mom;        // (B, H, P, NSP) moment array, or NULL
+    int* grad_done;          // (B, H, P) flags
+    int grad_NSP, grad_NXP;
     // initial state distribution
     double mu0[kMaxD];
     double S0[kMaxD * kMaxD];
@@ -157,8 +162,11 @@ struct Handle {
                                      // (round 3): 77.9 ms either way -- the two kernels do overlap (rocprofv3: 2.58 ms and 1.41 ms side by side instead
                                      // of 2.14 + 0.49 ms) but the fp64 pipe is already at the ~76 % of its nominal rate an FMA loop reaches
     int last_rollout_path = 0;       // what the last rollout launch used: 0 fused-horizon kernel, 1 streaming kernel, 2 batch-major tiles
+    int last_fused_tiles = 0;        // 1: the last batch-major forward also formed the gradient's tile moments (RolloutArgs::grad_mom)
+    int opt_grad_fuse = 1;           // gradient: form the diagonal pairs' tile moments inside the batch-major forward (0: separate pass, A/B)
     int last_grad_path = 0;          // moment passes of the last gpmpc_rollout_grad: bit 0 separable off-diagonal pairs, bit 1 tile moments of
                                      // the diagonal pairs, bit 2 streaming element-wise pass, bit 3 the wide (8 < D <= 16) pass
+    int opt_prepare_overlap = 1;     // 32-wide panel path: the inverse's launches on a side stream beside the factorisation's (0: one stream, A/B)
     int opt_fused_prepare = 1;       // N <= 256: the whole factorisation in one launch (prepare_small.hip); 0: panel path (A/B, tests)
     int last_prepare_mode = 0;       // 0 full, 1 border update(s), 2 unchanged (cache hit)
     int lds_limit = 160 * 1024;
@@ -192,6 +200,7 @@ bool tile_path_supported(Handle* h, const RolloutArgs& a);
 int tile_workspace(Handle* h, RolloutArgs& a);
 int launch_tile_state_init(Handle* h, const RolloutArgs& a, hipStream_t s);
 int launch_pair_tiles(Handle* h, const RolloutArgs& a, int t, hipStream_t s);
+bool tile_moments_fusable(Handle* h, const RolloutArgs& a);
 bool tile_moments_supported(Handle* h, const RolloutArgs& a, int NSP);
 int launch_tile_moments(Handle* h, const RolloutArgs& a, double* mom, int* done, int NSP, int NXP, hipStream_t s);
 // grad.hip

@@ -133,8 +133,18 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     int* sep_flags = reinterpret_cast<int*>(g.msum + n_ms + n_cv);
     if (!a.cv_out) a.cv_out = g.msum + n_ms;
 
-    rc = launch_rollout(h, a, s);            // forward: trajectory, costs, J
+    // Diagonal pairs batch-major (pair_tile_grad_kernel.h) once the tables T_a are large and the batch fills the chip.  When the
+    // forward itself takes the batch-major path, its tile pass forms these moments on the way (the same E_ij would otherwise be
+    // evaluated twice: once for the forward's sums, once for the moments) -- the flags are then written DURING the forward.
+    const bool want_tiles = h->opt_grad_tiles != 0 && D >= 2 && D <= 4 && tile_moments_supported(h, a, NSP) &&
+                            (h->opt_grad_tiles == 2 || (4.0 * D * (double)N * N >= 6e6 && (long long)B * H >= 2LL * h->num_cu));
+    if (want_tiles && tile_moments_fusable(h, a)) {
+        GPMPC_HIP_CHECK(h, hipMemsetAsync(sep_flags, 0, (size_t)B * H * P * sizeof(int), s));
+        a.grad_mom = g.mom; a.grad_done = sep_flags; a.grad_NSP = NSP; a.grad_NXP = NXP;
+    }
+    rc = launch_rollout(h, a, s);            // forward: trajectory, costs, J (+ the fused tile moments)
     if (rc) return rc;
+    const bool fused = h->last_fused_tiles != 0;
 
     g.Xt = a.Xt; g.beta = a.beta; g.Tm = a.Tm; g.ils2 = a.ils2; g.var = a.var; g.logvar = a.logvar; g.cost = a.cost;
     g.kappa = a.kappa; g.use_constraints = a.use_constraints;
@@ -170,6 +180,7 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
             for (int k = 0; k < 16; ++k) sg.mono_cum[k] = h->mono_cum[k];
             sg.N = N; sg.D = D; sg.A = A; sg.E = E; sg.H = H; sg.B = B; sg.include_time = a.include_time; sg.time0 = a.time0;
             sg.NSP = NSP; sg.NXP = NXP; sg.kmax = kmax; sg.force_path = h->opt_force_path;
+            sg.keep_diag_flags = fused ? 1 : 0;          // the fused forward already wrote the diagonal pairs' flags
             // weightings beyond a multiple of 16 (one or two) are accumulated on the VALU instead of opening another A block
             const int NE = (nWt > 16 && nWt % 16 != 0 && nWt % 16 <= 2) ? nWt % 16 : 0;
             const int NA = NE ? nWt / 16 : (nWt + 15) / 16;
@@ -197,10 +208,12 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
             }
         }
     }
-    // Diagonal pairs batch-major over all (candidate, step) items (pair_tile_grad_kernel.h) once the tables T_a are large
-    // and the batch fills the chip; the element-wise pass below keeps the mean sums and whatever is flagged 0.
-    if (h->opt_grad_tiles != 0 && D >= 2 && D <= 4 && tile_moments_supported(h, a, NSP) &&
-        (h->opt_grad_tiles == 2 || (4.0 * D * (double)N * N >= 6e6 && (long long)B * H >= 2LL * h->num_cu))) {
+    // Diagonal pairs batch-major over all (candidate, step) items of the stored trajectory when the forward did not form them;
+    // the element-wise pass below keeps the mean sums and whatever is flagged 0.
+    if (fused) {
+        g.sepdone = sep_flags;
+        h->last_grad_path |= 2 | 16;
+    } else if (want_tiles) {
         if (!g.sepdone) {
             GPMPC_HIP_CHECK(h, hipMemsetAsync(sep_flags, 0, (size_t)B * H * P * sizeof(int), s));
             g.sepdone = sep_flags;

@@ -53,6 +53,7 @@ struct SepGradArgs {
     int NSP, NXP;
     int kmax;               // highest degree this kernel takes (mono_cum[kmax] <= 16 kSepGradBlocks)
     int force_path;
+    int keep_diag_flags;    // 1: the diagonal pairs' flags were written by the fused forward: leave them
     int PS;                 // doubles per point in the LDS tables
     int wave_words;         // doubles of LDS per wavefront
 };
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
     }
     __syncthreads();
     // diagonal pairs are never taken here (their weights do not factor): say so, the flag array is not initialised otherwise
-    if (tid >= 64 && tid < 64 + D) p.done[((size_t)c * H + t) * P + (tid - 64) * D - ((tid - 64) * (tid - 65)) / 2] = 0;
+    if (tid >= 64 && tid < 64 + D && !p.keep_diag_flags) p.done[((size_t)c * H + t) * P + (tid - 64) * D - ((tid - 64) * (tid - 65)) / 2] = 0;
     // ---- D x D algebra of the off-diagonal pairs: Z = R^-1 Sigma, Taylor degree (phase P1 of rollout_kernel) -------------
     if (tid < Poff) {
         int a = 0, b = 0, k = tid, q = 0;

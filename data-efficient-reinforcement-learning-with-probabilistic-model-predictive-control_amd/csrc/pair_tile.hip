@@ -169,8 +169,15 @@ int launch_tile_state_init(Handle* h, const RolloutArgs& a, hipStream_t s) {
 // each fits a CU together: registers and LDS).  They do run concurrently, but the step takes the same time (config 4: 77.9 ms per
 // batch both ways): the tile kernel already keeps the fp64 pipe at 77 % of its nominal issue rate (2.27 GHz measured), which is
 // what an 8-chain FMA loop reaches on this part (profiles/fma_loop_microbench.txt: 58.6 of 78.6 TFLOP/s), so the default is one stream.
+struct TileFuse {          // gradient launch: where the fused tile pass leaves the diagonal pairs' moments
+    double* tmom;          // (B, D, ntiles, kTgMom) per-tile partial moments of this step (workspace)
+    double* mom;           // (B, H, P, NSP)
+    int* done;             // (B, H, P)
+    int NSP, NXP;
+};
+
 template <int DP>
-static int launch_step_dp(Handle* h, const StepArgs& t, hipStream_t s) {
+static int launch_step_dp(Handle* h, const StepArgs& t, const TileFuse* fuse, hipStream_t s) {
     const int P = t.D * (t.D + 1) / 2;
     const bool overlap = h->opt_tile_overlap != 0;
     hipStream_t sp = overlap ? h->side_stream : s;
@@ -191,7 +198,36 @@ static int launch_step_dp(Handle* h, const StepArgs& t, hipStream_t s) {
         GPMPC_HIP_CHECK(h, hipGetLastError());
     }
     if (overlap) GPMPC_HIP_CHECK(h, hipEventRecord(h->ev_points, sp));
-    {
+    if (fuse) {
+        // gradient launch: the tile pass of this step forms the diagonal pairs' moments too (pair_tile_moments_kernel<DP, true>):
+        // its W partials ARE the tile sums step_combine_kernel adds, written to t.part by the same kernel
+        auto kern = pair_tile_moments_kernel<DP, true>;
+        int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+        if (rc) return rc;
+        StepArgs tg = t;
+        // one workgroup per CU here (2 wavefronts per SIMD): chunk = rounds x (chunk + prologue) over num_cu slots
+        int cch = h->opt_tile_chunk;
+        const int nta = t.ntiles * t.D;
+        if (cch <= 0) {
+            long long best = -1;
+            for (int c = 16; c <= 128; c += 2) {
+                const long long wgs = (long long)nta * ((t.B + c - 1) / c);
+                const long long cost = ((wgs + h->num_cu - 1) / h->num_cu) * (c + 8);
+                if (best < 0 || cost < best) { best = cost; cch = c; }
+            }
+        }
+        cch = (cch + 1) & ~1;
+        tg.cch = cch;
+        tg.nchunk = (t.B + cch - 1) / cch;
+        const size_t lds = (size_t)make_tile_grad_layout(DP, t.E).total * sizeof(double);
+        if (lds > (size_t)h->lds_limit) { h->err = "pair tiles: input dimension too large for the LDS layout"; return GPMPC_ERR_LIMIT; }
+        const int per_xcd = (nta + 7) / 8;
+        hipLaunchKernelGGL(kern, dim3(8 * per_xcd * tg.nchunk), dim3(kTileWaves * 64), lds, s, tg, fuse->tmom);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+        hipLaunchKernelGGL(tile_moments_reduce_kernel<DP>, dim3(t.B), dim3(64), 0, s, tg, (const double*)fuse->tmom, fuse->mom, fuse->done,
+                           fuse->NSP, fuse->NXP);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+    } else {
         auto kern = pair_tile_kernel<DP>;
         int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
         if (rc) return rc;
@@ -224,11 +260,30 @@ int launch_pair_tiles(Handle* h, const RolloutArgs& a, int step, hipStream_t s) 
     t.N = a.N; t.D = a.D; t.A = a.A; t.E = a.E; t.H = a.H; t.B = a.B; t.t = step;
     t.include_time = a.include_time; t.time0 = a.time0;
     t.force_path = a.force_path;
-    switch (tile_dp(a.D)) {
-        case 2:  return launch_step_dp<2>(h, t, s);
-        case 3:  return launch_step_dp<3>(h, t, s);
-        default: return launch_step_dp<4>(h, t, s);
+    t.compact = 0;
+    t.fused_t = -1;
+    TileFuse fz{};
+    const TileFuse* fuse = nullptr;
+    if (a.grad_mom) {
+        // per-tile partial moments of one step's candidates (B x D x ntiles x 24 doubles: 28 MB at config 4)
+        int rc = grow(h, h->tgradws, (size_t)a.B * a.D * t.ntiles * kTgMom);
+        if (rc) return rc;
+        fz.tmom = h->tgradws.p; fz.mom = a.grad_mom; fz.done = a.grad_done; fz.NSP = a.grad_NSP; fz.NXP = a.grad_NXP;
+        fuse = &fz;
+        t.fused_t = step;
     }
+    switch (tile_dp(a.D)) {
+        case 2:  return launch_step_dp<2>(h, t, fuse, s);
+        case 3:  return launch_step_dp<3>(h, t, fuse, s);
+        default: return launch_step_dp<4>(h, t, fuse, s);
+    }
+}
+
+// Whether a gradient launch may leave the diagonal pairs' moments to the batch-major forward (launch_rollout decides whether the
+// forward takes that path at all; h->last_fused_tiles says afterwards whether it did).
+bool tile_moments_fusable(Handle* h, const RolloutArgs& a) {
+    if (h->opt_grad_fuse == 0 || a.D < 2 || a.D > 4) return false;
+    return (size_t)make_tile_grad_layout(tile_dp(a.D), a.E).total * sizeof(double) <= (size_t)h->lds_limit;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -294,6 +349,8 @@ int launch_tile_moments(Handle* h, const RolloutArgs& a, double* mom, int* done,
     const int DP = tile_dp(a.D);
     t.off_pair = t.off_mean;                       // compact records: inputs | the D diagonal pair problems
     t.CS = t.off_pair + a.D * t.PRP;
+    t.compact = 1;
+    t.fused_t = -1;
     t.Xt = a.Xt; t.beta = a.beta; t.Tm = a.Tm; t.ils2 = a.ils2; t.var = a.var; t.logvar = a.logvar; t.xrange = a.xrange;
     t.actions = a.actions;
     t.mu = a.mu_out; t.Sig = a.Sig_out;

@@ -91,7 +91,12 @@ __device__ inline void tile_rows_moments(const double* rec, const double (&tv)[k
     }
 }
 
-template <int DP>
+// FUSED: launched by the batch-major FORWARD of a gradient call, once per horizon step (items = the candidates, records = the
+// step's own records): the tile sums the forward needs (p.part, as pair_tile_kernel writes them) are the W moment, so the
+// forward's tile pass is not repeated by a separate moment pass over the stored trajectory -- the same E_ij would otherwise be
+// evaluated twice.  Direct-exp items (degree 0) get their forward sum here too (tile_rows_exp) and stay with the element-wise
+// moment kernel for their moments.
+template <int DP, bool FUSED = false>
 __global__ __launch_bounds__(kTileWaves * 64, 2) void pair_tile_moments_kernel(const StepArgs p, double* __restrict__ tmom) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int RSG = 2 * DP + 2;
@@ -153,7 +158,8 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void pair_tile_moments_kernel(c
     const double* il = p.ils2 + (size_t)a * E;
     const double lv = p.logvar[a];
     const int ngroups = (ncand + kTileGC - 1) / kTileGC;
-    const double* __restrict__ tpar = p.crec + p.off_pair + a * p.PRP;        // compact records: the D diagonal pairs
+    // compact records hold the D diagonal pairs only; the forward's step records all P pairs
+    const double* __restrict__ tpar = p.crec + p.off_pair + (p.compact ? a : pair_index(a, a, p.D)) * p.PRP;
     auto degrees = [&](int g, int (&K)[kTileGC]) {
 #pragma unroll
         for (int kk = 0; kk < kTileGC; ++kk) {
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void pair_tile_moments_kernel(c
         const int kk = wave >> 2;
         const int cl = g * kTileGC + kk;
         const int K = kk ? Kg[1] : Kg[0];
-        if (cl >= ncand || K == 0) return;
+        if (cl >= ncand || (K == 0 && !FUSED)) return;
         const double* par = tpar + (size_t)(c0 + cl) * p.CS;
         const double* mo = p.crec + (size_t)(c0 + cl) * p.CS;
         const int side = (wave >> 1) & 1;
@@ -196,7 +202,8 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void pair_tile_moments_kernel(c
             qf = fma(nu[i], r, qf);
             g_[i] = gi;
         }
-        const double f = fast_exp(fma(-0.5, qf, lv), s_tab);
+        const double kkv = fma(-0.5, qf, lv);
+        const double f = (K > 0) ? fast_exp(kkv, s_tab) : kkv;       // degree 0 (FUSED only): the log-factor, as pair_tile_kernel
         const int buf = g & 1;
         if (side == 0) {
             double* rec = s_rows + ((size_t)(buf * kTileGC + kk) * kTileW + pt) * RSG;
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void pair_tile_moments_kernel(c
             if (cl >= ncand) break;
             const int K = kk ? Kg[1] : Kg[0];
             double* wout = s_wsum + (size_t)((buf * kTileGC + kk) * kTileWaves + wave) * kTgMom;
-            if (K == 0) continue;                                   // direct-exp item: the element-wise kernel's
+            if (K == 0 && !FUSED) continue;                         // direct-exp item: the element-wise kernel's
             const double* mo = p.crec + (size_t)(c0 + cl) * p.CS;
             const double* col = s_cols + (size_t)(buf * kTileGC + kk) * (DP + 1) * kTileW + 2 * lane;
             const double f0 = col[0], f1 = col[1];
@@ -227,6 +234,16 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void pair_tile_moments_kernel(c
 #pragma unroll
             for (int d = 0; d < DP; ++d) { u0[d] = col[(1 + d) * kTileW]; u1[d] = col[(1 + d) * kTileW + 1]; }
             const double* rec = s_rows + ((size_t)(buf * kTileGC + kk) * kTileW + wave * kTileRW) * RSG;
+            if constexpr (FUSED) {
+                if (K == 0) {
+                    // forward sum only (slot 0 of the wavefront's partial moments = what pair_tile_kernel writes); moments: element-wise
+                    double s0, s1;
+                    tile_rows_exp<DP, RSG>(rec, tv, u0, u1, f0, f1, s_tab, s0, s1);
+                    const double v = wave_sum(s0 + s1);
+                    if (lane == 0) wout[0] = v;
+                    continue;
+                }
+            }
             double cs0 = 0.0, cs1 = 0.0, v0[DP], v1[DP], racc[kTileRW];
 #pragma unroll
             for (int d = 0; d < DP; ++d) { v0[d] = 0.0; v1[d] = 0.0; }
@@ -313,12 +330,13 @@ __global__ __launch_bounds__(kTileWaves * 64, 2) void pair_tile_moments_kernel(c
             const int K = kk ? Kg[1] : Kg[0];
             if (cl < ncand) {
                 double v = 0.0;
-                if (K > 0) {
+                if (K > 0 || (FUSED && k == 0)) {
                     const double* w = s_wsum + (size_t)(((g & 1) * kTileGC + kk) * kTileWaves) * kTgMom + k;
 #pragma unroll
                     for (int wv = 0; wv < kTileWaves; ++wv) v += w[wv * kTgMom];
                 }
-                tmom[(((size_t)(c0 + cl) * D + a) * p.ntiles + tile) * kTgMom + k] = v;
+                if (FUSED && k == 0) p.part[((size_t)(c0 + cl) * D + a) * p.ntiles + tile] = v;      // the forward's tile sum (step_combine_kernel)
+                tmom[(((size_t)(c0 + cl) * D + a) * p.ntiles + tile) * kTgMom + k] = (K > 0) ? v : 0.0;
             }
         }
     };
@@ -347,10 +365,10 @@ __global__ __launch_bounds__(64) void tile_moments_reduce_kernel(const StepArgs 
     constexpr int NH = DP * (DP + 1) / 2;
     const int it = blockIdx.x, lane = threadIdx.x;          // item of this launch; p.item0 + it in the batch
     const int D = p.D, E = p.E, NX = E - D, P = D * (D + 1) / 2;
-    const size_t git = (size_t)p.item0 + it;
+    const size_t git = p.fused_t >= 0 ? (size_t)it * p.H + p.fused_t : (size_t)p.item0 + it;      // FUSED: item = candidate, this step
     for (int a = 0; a < D; ++a) {
         const int q = pair_index(a, a, D);
-        const int K = (int)p.crec[(size_t)it * p.CS + p.off_pair + a * p.PRP + DP * DP + 1] & 63;
+        const int K = (int)p.crec[(size_t)it * p.CS + p.off_pair + (p.compact ? a : q) * p.PRP + DP * DP + 1] & 63;
         if (lane == 0) done[git * P + q] = K > 0 ? 1 : 0;
         if (K == 0) continue;
         if (lane < NSP) {

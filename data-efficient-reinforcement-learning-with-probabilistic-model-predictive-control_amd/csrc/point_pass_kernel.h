@@ -69,6 +69,8 @@ struct StepArgs {
     int mom_stride;         // doubles per (pair, side) moment array in LDS
     int PO;                 // doubles per candidate in pout
     int item0;              // TRAJ records: first (candidate, step) item of this launch
+    int compact;            // 1: records hold the D diagonal pair problems only (TRAJ); 0: the forward step's full records
+    int fused_t;            // >= 0: the gradient's tile moments are formed inside the forward's step `fused_t` (items = candidates)
 };
 
 __host__ __device__ inline int pair_index(int a, int b, int D) { return a * D - (a * (a - 1)) / 2 + (b - a); }

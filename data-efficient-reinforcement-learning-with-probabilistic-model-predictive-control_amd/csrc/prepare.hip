@@ -1132,6 +1132,16 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
         GPMPC_HIP_CHECK(h, hipGetLastError());
         return GPMPC_OK;
     };
+    // 32-wide panel path (256 < N < outer_min_n): row block k of Y = L^-1 needs rows <= k of L and the earlier rows of Y only --
+    // not the panel solve and trailing update of step k -- so the inverse's chain of launches runs on a side stream BESIDE the
+    // factorisation's (one event per step; every kernel here fills a few CUs).  N = 500: the factorisation chain is 16 x
+    // (8.9 + 4.7 + 5.0) us, the inverse chain 15 x 14.3 us (profiles/r04_c3_kernel_trace_stats.txt); in sequence 0.59 ms.
+    const bool overlap_inv = !OW && !factored && h->opt_prepare_overlap != 0 && N > NB;
+    if (overlap_inv && !h->side_stream) {
+        GPMPC_HIP_CHECK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
+        GPMPC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
+        GPMPC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_points, hipEventDisableTiming));
+    }
     for (int k0 = 0; k0 < N; k0 += NB) {
         const int nb = (N - k0 < NB) ? (N - k0) : NB;
         const bool blk128 = OW && tile128 && h->opt_block128 != 0;
@@ -1158,6 +1168,12 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
             const int left = ll ? k0 % OW : 0;
             if (fast) hipLaunchKernelGGL(potrf_diag_fast_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info, left);
             else hipLaunchKernelGGL(potrf_diag_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
+            if (overlap_inv && k0 > 0) {
+                // rows <= k of L and Y_kk are final: row block k of the inverse starts now, beside this step's solve and update
+                GPMPC_HIP_CHECK(h, hipEventRecord(h->ev_params, s));
+                GPMPC_HIP_CHECK(h, hipStreamWaitEvent(h->side_stream, h->ev_params, 0));
+                hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, h->side_stream, h->gram.p, h->linv.p, N, k0, nb, 0, 0, 0);
+            }
             const int M = N - k0 - nb;
             if (M > 0) {
                 if (fast && left > 0) hipLaunchKernelGGL(trsm_panel_ll_kernel, dim3((M + 63) / 64, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb, left);
@@ -1179,9 +1195,13 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
                 }
             }
         }
-        if (k0 > 0 && !OW && !factored) {
+        if (k0 > 0 && !OW && !factored && !overlap_inv) {
             hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb, 0, 0, 0);
         }
+    }
+    if (overlap_inv) {                                    // join: what follows reads all of Y
+        GPMPC_HIP_CHECK(h, hipEventRecord(h->ev_points, h->side_stream));
+        GPMPC_HIP_CHECK(h, hipStreamWaitEvent(s, h->ev_points, 0));
     }
     if (OW && tile128) {
         // Y = L^-1 by recursive doubling.  All diagonal 128-blocks Y_KK at once (the 32-row recursion restricted to the columns

@@ -331,6 +331,8 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     h->last_rollout_path = gs ? 1 : (tiled ? 2 : 0);
     // the batch-major state of a (possibly re-used) argument block is set on EVERY call, never inherited from an earlier one
     a.tiled = tiled ? 1 : 0;
+    if (!tiled) a.grad_mom = nullptr;                      // only the batch-major forward can form the gradient's tile moments
+    h->last_fused_tiles = (tiled && a.grad_mom) ? 1 : 0;
     if (!tiled) { a.t_begin = 0; a.t_end = 0; a.slow = nullptr; a.tile_part = nullptr; a.ntiles = 0; }
     if (tiled) {
         // per horizon step: parameters + batch-major tiles of the diagonal pairs, then the per-candidate rest of the step

@@ -111,7 +111,7 @@ class HipEngine:
     @property
     def last_grad_path(self):
         """Moment passes of the last `rollout_grad` (bit mask): 1 separable off-diagonal pairs, 2 tile moments of the diagonal
-        pairs, 4 streaming element-wise pass, 8 the 8 < D <= 16 pass."""
+        pairs, 4 streaming element-wise pass, 8 the 8 < D <= 16 pass, 16 tile moments formed inside the batch-major forward."""
         return int(self.lib.gpmpc_last_grad_path(self._h))
 
     @property

@@ -97,7 +97,9 @@ int gpmpc_last_rollout_path(gpmpc_t* h);
 
 /* Which moment passes the last gpmpc_rollout_grad launched (bit mask): 1 = off-diagonal output pairs in separable form on
  * the matrix cores, 2 = diagonal pairs batch-major over all (candidate, step) items, 4 = the streaming element-wise pass
- * (per-point arrays beyond the LDS), 8 = the 8 < D <= 16 pass.  0 = the element-wise pass alone.  A test hook: lets a parity
+ * (per-point arrays beyond the LDS), 8 = the 8 < D <= 16 pass, 16 (with 2) = the diagonal pairs' moments were formed by the
+ * batch-major FORWARD's own tile pass (one evaluation of the pairwise weights serves the forward sums and the moments; option
+ * "grad_fuse" 0 switches that off).  0 = the element-wise pass alone.  A test hook: lets a parity
  * test assert that it measured the dispatch that ships (gp_mpc_controller.py:277 is one autograd call in the reference). */
 int gpmpc_last_grad_path(gpmpc_t* h);
 
@@ -134,7 +136,9 @@ int gpmpc_read_factors(gpmpc_t* h, double* iK_dst_dev, double* beta_dst_dev, voi
  * Round 3: "pair_tiles" (0 auto / 1 always / 2 never: the batch-major rollout path -- one set of launches per horizon
  * step, workgroups own 128 x 128 tiles of T_a and loop over candidates; auto: D <= 4, 4 D N^2 >= 6e6, B >= 2 x CUs),
  * "tile_chunk" (candidates per tile workgroup, 0 = chosen to fill the last round), "tile_overlap" (1: point pass on a side
- * stream), "grad_separable" and "grad_tiles" (0 never / 1 auto / 2 always: see gpmpc_rollout_grad). */
+ * stream), "grad_separable" and "grad_tiles" (0 never / 1 auto / 2 always: see gpmpc_rollout_grad).
+ * Round 4: "grad_fuse" (1 / 0: gradient launches whose forward takes the batch-major path form the diagonal pairs' tile moments
+ * inside the forward's tile pass). */
 int gpmpc_set_option(gpmpc_t* h, const char* name, long long value);
 
 /*

@@ -307,23 +307,30 @@ def test_separable_moments_of_the_off_diagonal_pairs(engine, N, D, A, H, B, tm, 
                                              (257, 2, 1, 4, 2, False, 3e-3), (128, 4, 2, 3, 5, False, 1e-3), (129, 3, 1, 3, 2, False, 1e-5),
                                              (1, 3, 1, 2, 2, False, 1e-5), (400, 4, 3, 2, 3, True, 1e-2)])
 @pytest.mark.parametrize("sep", [0, 2])
-def test_tile_moments_of_the_diagonal_pairs(engine, N, D, A, H, B, tm, s0, sep):
+@pytest.mark.parametrize("fuse", [False, True])
+def test_tile_moments_of_the_diagonal_pairs(engine, N, D, A, H, B, tm, s0, sep, fuse):
     """csrc/pair_tile_grad_kernel.h: the moments of the diagonal pairs batch-major over all (candidate, step) items (a
     workgroup keeps a 128 x 128 tile of T_a in registers), forced here at every N (by default where the forward takes its
     batch-major path), against the numpy adjoint and the element-wise moment pass; with and without the separable pass for
     the off-diagonal pairs, one to three tile rows, ragged last tiles, time input, large state variance (direct-exp items
-    stay element-wise)."""
+    stay element-wise).  `fuse`: with the batch-major FORWARD forced as well the tile pass of each horizon step forms the
+    moments on the way (pair_tile_moments_kernel<DP, FUSED>, round 4) -- including the forward sums of direct-exp items."""
     w = synth.make_workload(N, D, A, H, B, include_time=tm, seed=N + D, s0=s0, time0=1.0 if tm else 0.0)
     f = _load_model(engine, w)
     res = {}
     engine.set_option("grad_separable", sep)
+    engine.set_option("pair_tiles", 1 if fuse else 2)
     try:
         for tiles in (2, 0):
             engine.set_option("grad_tiles", tiles)
             res[tiles] = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)["grad"].cpu().numpy()
+            if tiles == 2:
+                assert bool(engine.last_grad_path & 16) == fuse and engine.last_grad_path & 2
+                assert (engine.last_rollout_path == 2) == fuse
     finally:
         engine.set_option("grad_separable", 1)
         engine.set_option("grad_tiles", 1)
+        engine.set_option("pair_tiles", 0)
     for b in range(B):
         J, g, *_ = adjoint.lcb_and_gradient(f, w.actions[b], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
         assert rel_err(res[2][b], g) < 1e-7
