@@ -48,6 +48,7 @@ struct GradArgs {
     int G, CH, RC, wpp;
     int gz;                 // workgroups per (candidate, step) in the moment pass (pair groups spread over blockIdx.z)
     const int* sepdone;     // (B, H, P) or NULL: 1 = the pair's moments were written by sep_grad_moments_kernel (skip it here)
+    int mean_done;          // 1: msum was written by mean_moments_kernel (grad_stream_kernel.h): the streaming pass skips its mean part
     unsigned magic_N, magic_wpp;
 };
 

@@ -96,7 +96,8 @@ __global__ __launch_bounds__(kGsThreads) void pair_moments_stream_kernel(const G
     __syncthreads();
 
     // ---- mean part (gp_model.py:140-153): A_a^-1, then lb_ai and the moments of nu under lb_a, chunk by chunk ------------
-    if (blockIdx.z == 0) {
+    // (p.mean_done: written by mean_moments_kernel below)
+    if (blockIdx.z == 0 && !p.mean_done) {
         if (tid < D) {
             const int a = tid;
             double* aug = s_aug + a * (D * LD);
@@ -379,6 +380,122 @@ __global__ __launch_bounds__(kGsThreads) void pair_moments_stream_kernel(const G
             p.mom[((((size_t)c * H + t) * P) + q) * NSP + k] = v;
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// The mean part of the moment pass on its own (D <= 4): per (candidate, step) and output a the sums over the memory points of
+// lb_ai x {1, nu_d, nu_d nu_e, nu_k nu_d nu_e, nu_x, nu_k nu_x} (mean_moment_count: 65 numbers at D = 4 with two action inputs).
+// pair_moments_stream_kernel forms them component by component -- one wavefront per component, four LDS reads per point and
+// term, a wave reduction per component and 512-point chunk: 22 ms of a config-4 gradient launch whose pairs are all handled by
+// the matrix-core and tile kernels (profiles/r04c_c4_gradient_kernel_trace_stats.txt), 20 x what the arithmetic needs.  Here a
+// wavefront owns one output a, LANES OWN POINTS: nu, lb and every product stay in registers, the components accumulate in
+// registers over the lane's N / 64 points, and ONE round of wave reductions (16 values per 57 instructions: wave_reduce16) ends
+// the item.  Grid (H, B), D wavefronts per workgroup.
+template <int DP, int NXP>
+__global__ __launch_bounds__(64 * DP) void mean_moments_kernel(const GradArgs p) {
+    __shared__ double s_tab[64];
+    constexpr int T2 = DP * (DP + 1) / 2;
+    constexpr int NC = 1 + DP + T2 + DP * T2 + NXP + DP * NXP;       // components in the compile-time (DP, NXP) layout
+    constexpr int NG = (NC + 15) / 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int a = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int t = blockIdx.x, c = blockIdx.y;
+    const int N = p.N, D = p.D, A = p.A, E = p.E, H = p.H, NX = E - D;
+    if (tid < 64) s_tab[tid] = kExp2Tab[tid];
+    __syncthreads();
+    if (a >= D) return;
+    // input mean of the step and A_a^-1 = (Sigma + diag(l_a^2))^-1 (every lane redundantly: wave-uniform operands)
+    double md[DP], mx[NXP], ilx[NXP];
+#pragma unroll
+    for (int d = 0; d < DP; ++d) md[d] = (d < D) ? p.mu[((size_t)c * (H + 1) + t) * D + d] : 0.0;
+#pragma unroll
+    for (int x = 0; x < NXP; ++x) {
+        const int e = D + x;
+        mx[x] = (x >= NX) ? 0.0 : (e < D + A ? p.actions[((size_t)c * H + t) * A + (e - D)] : p.time0 + (double)t);
+        ilx[x] = (x < NX) ? p.ils2[(size_t)a * E + e] : 0.0;
+    }
+    double m[DP][2 * DP];
+    {
+        const double* Sg = p.Sig + ((size_t)c * (H + 1) + t) * D * D;
+#pragma unroll
+        for (int i = 0; i < DP; ++i)
+#pragma unroll
+            for (int j = 0; j < DP; ++j) {
+                const bool in = (i < D && j < D);
+                m[i][j] = (in ? Sg[i * D + j] : 0.0) + (i == j ? (i < D ? 1.0 / p.ils2[(size_t)a * E + i] : 1.0) : 0.0);
+                m[i][DP + j] = (i == j) ? 1.0 : 0.0;
+            }
+        (void)small_solve<DP>(m);
+    }
+    double acc[NG * 16];
+#pragma unroll
+    for (int k = 0; k < NG * 16; ++k) acc[k] = 0.0;
+    const double* beta = p.beta + (size_t)a * N;
+    for (int pt = lane; pt < N; pt += 64) {
+        double nu[DP], xe[NXP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) nu[d] = (d < D) ? p.Xt[(size_t)d * N + pt] - md[d] : 0.0;
+#pragma unroll
+        for (int x = 0; x < NXP; ++x) xe[x] = (x < NX) ? p.Xt[(size_t)(D + x) * N + pt] - mx[x] : 0.0;
+        double q = 0.0;
+#pragma unroll
+        for (int i = 0; i < DP; ++i) {
+            double r = 0.0;
+#pragma unroll
+            for (int j = 0; j < DP; ++j) r = fma((i < D && j < D) ? m[i][DP + j] : 0.0, nu[j], r);
+            q = fma(nu[i], r, q);
+        }
+#pragma unroll
+        for (int x = 0; x < NXP; ++x) q = fma(xe[x] * xe[x], ilx[x], q);
+        const double lb = fast_exp(-0.5 * q, s_tab) * beta[pt];                  // gp_model.py:148
+        int n = 0;
+        acc[n++] += lb;
+        double l1[DP];
+#pragma unroll
+        for (int d = 0; d < DP; ++d) { l1[d] = lb * nu[d]; acc[n++] += l1[d]; }
+        double l2[T2];
+        {
+            int k = 0;
+#pragma unroll
+            for (int d1 = 0; d1 < DP; ++d1)
+#pragma unroll
+                for (int d2 = d1; d2 < DP; ++d2) { l2[k] = l1[d1] * nu[d2]; acc[n++] += l2[k]; ++k; }
+        }
+#pragma unroll
+        for (int k = 0; k < DP; ++k)
+#pragma unroll
+            for (int tt = 0; tt < T2; ++tt) { acc[n] = fma(l2[tt], nu[k], acc[n]); ++n; }
+#pragma unroll
+        for (int x = 0; x < NXP; ++x) { acc[n] = fma(lb, xe[x], acc[n]); ++n; }
+#pragma unroll
+        for (int k = 0; k < DP; ++k)
+#pragma unroll
+            for (int x = 0; x < NXP; ++x) { acc[n] = fma(l1[k], xe[x], acc[n]); ++n; }
+    }
+    // one round of reductions: lane 4 m of group g holds the total of component 16 g + m of the (DP, NXP) layout; its slot in the
+    // (D, NX) layout of msum comes from the component's factors
+    const int NM = mean_moment_count(D, NX);
+    double* out = p.msum + (((size_t)c * H + t) * D + a) * NM;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const double(&grp)[16] = *reinterpret_cast<const double(*)[16]>(&acc[16 * g]);
+        const double tot = wave_reduce16(grp);
+        const int comp = 16 * g + (lane >> 2);
+        if ((lane & 3) == 0 && comp < NC) {
+            int i1, i2, i3;
+            decode_mean_moment(comp, DP, NXP, i1, i2, i3);                 // factors: < DP a state dimension, DP + x an extra input
+            auto state_ok = [&](int i) { return i < 0 || (i < DP ? i < D : i - DP < NX); };
+            if (state_ok(i1) && state_ok(i2) && state_ok(i3)) {
+                const int T2r = tri_count(D);
+                int slot;
+                if (i1 < 0) slot = 0;
+                else if (i2 < 0) slot = (i1 < DP) ? 1 + i1 : 1 + D + T2r + D * T2r + (i1 - DP);
+                else if (i3 < 0) slot = (i2 < DP) ? 1 + D + tri_index(i1, i2, D) : 1 + D + T2r + D * T2r + NX + i1 * NX + (i2 - DP);
+                else slot = 1 + D + T2r + i1 * T2r + tri_index(i2, i3, D);
+                out[slot] = tot;
+            }
+        }
     }
 }
 

@@ -99,7 +99,8 @@ int gpmpc_last_rollout_path(gpmpc_t* h);
  * the matrix cores, 2 = diagonal pairs batch-major over all (candidate, step) items, 4 = the streaming element-wise pass
  * (per-point arrays beyond the LDS), 8 = the 8 < D <= 16 pass, 16 (with 2) = the diagonal pairs' moments were formed by the
  * batch-major FORWARD's own tile pass (one evaluation of the pairwise weights serves the forward sums and the moments; option
- * "grad_fuse" 0 switches that off).  0 = the element-wise pass alone.  A test hook: lets a parity
+ * "grad_fuse" 0 switches that off), 32 = the mean part of the streaming pass by its own kernel (lanes over points; option
+ * "grad_mean" 0: inside the pass).  0 = the element-wise pass alone.  A test hook: lets a parity
  * test assert that it measured the dispatch that ships (gp_mpc_controller.py:277 is one autograd call in the reference). */
 int gpmpc_last_grad_path(gpmpc_t* h);
 

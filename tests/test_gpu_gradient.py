@@ -180,12 +180,18 @@ def test_streaming_moment_pass_matches_numpy_adjoint(engine, N, D, A, H, B, tm, 
     engine.set_option("force_path", path)
     try:
         out = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+        assert bool(engine.last_grad_path & 32) == (D <= 4)           # D <= 4: the mean part by mean_moments_kernel (round 4)
         again = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+        engine.set_option("grad_mean", 0)                             # ... and inside the streaming pass, as before
+        inpass = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+        assert not engine.last_grad_path & 32
     finally:
         engine.set_option("grad_stream", 0)
         engine.set_option("force_path", 0)
+        engine.set_option("grad_mean", 1)
     grad = out["grad"].cpu().numpy()
     assert torch.equal(out["grad"], again["grad"])                    # fixed summation order
+    assert rel_err(grad, inpass["grad"].cpu().numpy()) < 1e-9
     J, gr, *_ = adjoint.lcb_and_gradient(f, w.actions[0], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
     assert abs(float(out["J"][0]) - J) < 1e-7 * abs(J)
     assert rel_err(grad[0], gr) < 1e-7
