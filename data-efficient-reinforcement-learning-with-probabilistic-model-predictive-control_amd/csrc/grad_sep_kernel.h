@@ -16,9 +16,10 @@
 // That is O(N (#weightings x #monomials)) per pair and side instead of O(N^2), and G = F^T Phi is a genuine matrix product
 // with the POINTS as the inner dimension: 16 weightings x 16 monomials per v_mfma_f64_16x16x4_f64, four points per
 // instruction, no cross-lane reduction anywhere (the element-wise form of this idea needed 4 x 16 accumulators per lane
-// and spilled: DESIGN.md section 8 item 3).  A wavefront owns one (pair, side): per 64 points it writes wt_i, the
-// weighting vector (1, u, nu_x) and the powers x_d^e of the monomial variables to LDS (lane = point), then 16 k-steps of
-// MFMAs whose operands every lane assembles from those tables with its own (weighting | monomial) selectors.
+// and spilled: DESIGN.md section 8 item 3).  A wavefront owns one (pair, side): per 32 points it writes, per point, the
+// weightings wt_i f(v_i) themselves and two small tables of products of the monomial variables (x_0^i x_1^j | x_2^i x_3^j) to
+// LDS (two lanes per point), then 8 k-steps of MFMAs whose A operand is ONE table read and whose B operand is the product of
+// two (sep_grad_point_words).
 //
 // Pairs whose degree is outside the table (direct-exp form, K beyond kSepGradBlocks x 16 monomials) are left to the
 // element-wise kernels: `done[(c, t, pair)]` says which pairs this kernel wrote.
@@ -58,11 +59,23 @@ struct SepGradArgs {
     int wave_words;         // doubles of LDS per wavefront
 };
 
-__host__ __device__ inline int sep_grad_point_words(int D, int NX, int K) {
-    // wt | v = (1, u_0 .., nu_x ..) | powers x_d^e, e = 0 .. K;  odd stride: the four points of a k-step fall on distinct banks
-    const int n = 1 + (1 + D + NX) + D * (K + 1) + 1;          // ... | one zero (what masked-out lanes multiply by)
-    return n | 1;
+// Per-point table of a 32-point chunk (round 4): the FW = 16 NA + NE weightings wt f(v) themselves | the products x_a^i x_b^j of
+// the first two monomial variables (i + j <= K, triangular) | those of the last two (one variable: its powers).  A k-step then reads ONE value per weighting block and TWO per monomial block where
+// the first version read 3 and D of them (wt, two factors; one power per variable) -- 17 individually addressed reads per
+// lane and 4-point step at config 4, two thirds of whose LDS cycles were bank conflicts (profiles/r03_c4_gradient_pmc.txt:
+// 3.29e9 conflict cycles against 4.90e9 active), next to ~25 multiplies that formed the operands.
+// Stride = 16 (mod 32) doubles: the two points a 32-lane half reads (kq = 0 / 1, 2 / 3) sit 32 banks apart, and within a point
+// the 16 lanes read 16 consecutive doubles (weightings) or entries of a table of <= 15 doubles (monomial factors): conflict-free.
+__host__ __device__ inline int sep_grad_tri(int K1, int nv) { return nv == 2 ? K1 * (K1 + 1) / 2 : K1; }
+__host__ __device__ inline int sep_grad_nv0(int D) { return D >= 3 ? 2 : 1; }        // variables of the first group
+__host__ __device__ inline int sep_grad_point_words(int D, int FW, int K) {
+    const int nv0 = sep_grad_nv0(D), nv1 = D - nv0;
+    const int n = FW + sep_grad_tri(K + 1, nv0) + sep_grad_tri(K + 1, nv1);
+    int ps = 16;
+    while (ps < n) ps += 32;
+    return ps;
 }
+constexpr int kSepGradChunk = 32;      // points per chunk (two lanes per point in the table pass)
 
 // ------------------------------------------------------------------------------------------
 // NA: blocks of 16 weightings on the matrix cores; NE: weightings 16 NA .. 16 NA + NE - 1 accumulated by plain FMAs instead (a 17th
@@ -77,7 +90,6 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
     const int t = blockIdx.x, c = blockIdx.y;
     const int N = p.N, D = p.D, A = p.A, E = p.E, H = p.H;
     const int NX = E - D, P = D * (D + 1) / 2, Poff = P - D;
-    const int NV = 1 + D + NX;                           // weighting vector (1, u, nu_x)
     const int nW = 1 + D + D * (D + 1) / 2 + NX;         // weightings: 1 | u_d | u_d u_e (d <= e) | nu_x
     const int PS = p.PS;
     // LDS: shared small data, then one region per wavefront (point tables during the pass, its moment matrix afterwards)
@@ -150,38 +162,7 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
     }
     __syncthreads();
 
-    // per-lane selectors.  A operand: weighting r = 16 ia + (lane & 15) -> two indices into the weighting vector;
-    // B operand: monomial n = 16 ib + (lane & 15) -> packed exponents (read per block below)
     const int r16 = lane & 15, kq = lane >> 4;
-    int selA[NA][2];
-#pragma unroll
-    for (int ia = 0; ia < NA; ++ia) {
-        const int r = ia * 16 + r16;
-        int s1 = 0, s2 = 0;
-        if (r >= 1 && r <= D) s1 = r;
-        else if (r > D && r < 1 + D + D * (D + 1) / 2) {
-            int k = r - 1 - D, d = 0;
-            while (k >= D - d) { k -= D - d; ++d; }
-            s1 = 1 + d; s2 = 1 + d + k;
-        } else if (r >= 1 + D + D * (D + 1) / 2 && r < nW) s1 = 1 + D + (r - 1 - D - D * (D + 1) / 2);
-        selA[ia][0] = (r < nW) ? s1 : -1;
-        selA[ia][1] = s2;
-    }
-    // the extra weightings (wave-uniform selectors)
-    int selE[NE > 0 ? NE : 1][2];
-#pragma unroll
-    for (int e = 0; e < NE; ++e) {
-        const int r = NA * 16 + e;
-        int s1 = 0, s2 = 0;
-        if (r >= 1 && r <= D) s1 = r;
-        else if (r > D && r < 1 + D + D * (D + 1) / 2) {
-            int k = r - 1 - D, d = 0;
-            while (k >= D - d) { k -= D - d; ++d; }
-            s1 = 1 + d; s2 = 1 + d + k;
-        } else if (r >= 1 + D + D * (D + 1) / 2 && r < nW) s1 = 1 + D + (r - 1 - D - D * (D + 1) / 2);
-        selE[e][0] = (r < nW) ? s1 : -1;
-        selE[e][1] = s2;
-    }
 
     // ---- tasks (off-diagonal pair, side): two rounds of wavefronts per pair pair, then the combination ----------------
     for (int pq0 = 0; pq0 < Poff; pq0 += NW / 2) {
@@ -200,24 +181,26 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
             const double* il = s_ils2 + co * E;
             const double lv = p.logvar[co];
             const int K1 = K + 1;
-            // word offsets of the lane's monomial factors inside a point's table (loop-invariant: one address add per LDS read in
-            // the k-steps; forming them from the packed exponents there cost 3 - 4 integer instructions per read, 122 VALU
-            // instructions per 4-point step by the counters against ~16 matrix instructions)
-            const int zslot = 1 + NV + D * K1;                 // the zero of a point's table
-            int offB[NB][DP];
+            constexpr int FW = 16 * NA + NE;                   // weightings kept per point
+            constexpr int NV0 = DP >= 3 ? 2 : 1, NV1 = DP - NV0;          // monomial variables of the two factor tables (D == DP here)
+            const int n0 = sep_grad_tri(K1, NV0);
+            // word offsets of the lane's two monomial factors inside a point's table (loop-invariant)
+            auto tri_off = [&](int ea, int eb) { return ea * K1 - (ea * (ea - 1)) / 2 + eb; };      // ea + eb <= K
+            int offB[NB][2];
 #pragma unroll
             for (int ib = 0; ib < NB; ++ib) {
                 const int ex = s_me[ib * 16 + r16];
-#pragma unroll
-                for (int d = 0; d < DP; ++d) offB[ib][d] = 1 + NV + d * K1 + ((ex >> (8 * d)) & 255);
-                if (ib * 16 + r16 >= C) offB[ib][0] = zslot;      // monomial slots past the degree's count contribute nothing
+                const int e0 = ex & 255, e1 = (ex >> 8) & 255, e2 = (ex >> 16) & 255, e3 = (ex >> 24) & 255;
+                int o0, o1;
+                if (DP == 2) { o0 = e0; o1 = e1; }
+                else if (DP == 3) { o0 = tri_off(e0, e1); o1 = e2; }
+                else { o0 = tri_off(e0, e1); o1 = tri_off(e2, e3); }
+                // monomial slots past the degree's count are never read by the combination (it stops at C): any finite value will do
+                // -- the weighting wt itself (their exponents may exceed K: the factor tables have no such entry)
+                const bool in = ib * 16 + r16 < C;
+                offB[ib][0] = in ? FW + o0 : 0;
+                offB[ib][1] = in ? FW + n0 + o1 : 0;
             }
-            // weightings: wt * v[s1] * v[s2]; rows past the last weighting read the zero
-            int offA[NA][2], offE[NE > 0 ? NE : 1][2];
-#pragma unroll
-            for (int ia = 0; ia < NA; ++ia) { offA[ia][0] = selA[ia][0] >= 0 ? 1 + selA[ia][0] : zslot; offA[ia][1] = 1 + selA[ia][1]; }
-#pragma unroll
-            for (int e = 0; e < NE; ++e) { offE[e][0] = selE[e][0] >= 0 ? 1 + selE[e][0] : zslot; offE[e][1] = 1 + selE[e][1]; }
             mfma_d4 acc[NA][NB];
 #pragma unroll
             for (int ia = 0; ia < NA; ++ia)
@@ -228,14 +211,17 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
             for (int e = 0; e < NE; ++e)
 #pragma unroll
                 for (int ib = 0; ib < NB; ++ib) accE[e][ib] = 0.0;
-            for (int c0 = 0; c0 < N; c0 += 64) {
-                // -- per-point tables (lane = point) --
+            // table pass roles: two lanes per point -- both form the weightings (the lower one stores them), each one of the two
+            // factor tables (uniform code, the variables chosen by data)
+            const int tpt = lane & (kSepGradChunk - 1), half = lane >> 5;
+            for (int c0 = 0; c0 < N; c0 += kSepGradChunk) {
+                // -- per-point tables --
                 {
-                    const int pt0 = c0 + lane;
+                    const int pt0 = c0 + tpt;
                     const bool live = pt0 < N;
                     const int pt = live ? pt0 : N - 1;
-                    double* tp = tabw + (size_t)lane * PS;
-                    double nu[DP], x[DP], zx[DP];
+                    double* tp = tabw + (size_t)tpt * PS;
+                    double nu[DP], x[DP], zx[DP], xe[8];
                     double ks = 0.0;
 #pragma unroll
                     for (int d = 0; d < DP; ++d) {
@@ -243,14 +229,10 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
                         x[d] = (d < D) ? nu[d] * il[d] : 0.0;          // u (rows) or w (columns)
                         ks = fma(nu[d], x[d], ks);
                     }
-                    tp[1] = 1.0;
-                    tp[zslot] = 0.0;
 #pragma unroll
-                    for (int d = 0; d < DP; ++d) if (d < D) tp[2 + d] = x[d];
-                    for (int xx = 0; xx < NX; ++xx) {
-                        const double v = p.Xt[(size_t)(D + xx) * N + pt] - s_m[D + xx];
-                        ks = fma(v * v, il[D + xx], ks);
-                        tp[2 + D + xx] = v;
+                    for (int xx = 0; xx < 8; ++xx) {
+                        xe[xx] = (xx < NX) ? p.Xt[(size_t)(D + (xx < NX ? xx : 0)) * N + pt] - s_m[D + (xx < NX ? xx : 0)] : 0.0;
+                        ks = fma(xe[xx] * xe[xx], (xx < NX) ? il[D + xx] : 0.0, ks);
                     }
                     double qq = 0.0;
                     double g[DP];
@@ -267,39 +249,60 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
                         qq = fma(x[i], zx[i], qq);
                     }
                     const double kk = lv - 0.5 * ks + 0.5 * qq;
-                    tp[0] = live ? fast_exp(kk, s_tab) * p.beta[(size_t)co * N + pt] : 0.0;
-                    // monomial variables: g = Z^T u on the row side, w itself on the column side
-                    double* pw = tp + 1 + NV;
+                    const double wt = live ? fast_exp(kk, s_tab) * p.beta[(size_t)co * N + pt] : 0.0;
+                    // weightings wt f(v), f in {1, v_d, v_d v_e (d <= e), nu_x}: compile-time positions (D == DP)
+                    if (half == 0) {
+                        constexpr int T2c = DP * (DP + 1) / 2;
+                        tp[0] = wt;
+                        double wv[DP];
 #pragma unroll
-                    for (int d = 0; d < DP; ++d) {
-                        if (d < D) {
-                            const double xv = side ? x[d] : g[d];
-                            double pv = 1.0;
-                            for (int e = 0; e < K1; ++e) { pw[d * K1 + e] = pv; pv *= xv; }
+                        for (int d = 0; d < DP; ++d) { wv[d] = wt * x[d]; if (1 + d < FW) tp[1 + d] = wv[d]; }
+                        int r = 1 + DP;
+#pragma unroll
+                        for (int d = 0; d < DP; ++d)
+#pragma unroll
+                            for (int e = d; e < DP; ++e) { if (r < FW) tp[r] = wv[d] * x[e]; ++r; }
+#pragma unroll
+                        for (int xx = 0; xx < 8; ++xx) { if (1 + DP + T2c + xx < FW) tp[1 + DP + T2c + xx] = wt * xe[xx]; }     // zero past NX
+#pragma unroll
+                        for (int r2 = 1 + DP + T2c + 8; r2 < FW; ++r2) tp[r2] = 0.0;
+                    }
+                    // factor table of this lane's variable group: x_a^i x_b^j, i + j <= K (monomial variables: g = Z^T u on the row
+                    // side, w itself on the column side)
+                    {
+                        double mv[DP];
+#pragma unroll
+                        for (int d = 0; d < DP; ++d) mv[d] = side ? x[d] : g[d];
+                        double xa, xb;
+                        if (DP == 2) { xa = half ? mv[1] : mv[0]; xb = 0.0; }
+                        else if (DP == 3) { xa = half ? mv[2] : mv[0]; xb = half ? 0.0 : mv[1]; }
+                        else { xa = half ? mv[DP >= 4 ? 2 : 0] : mv[0]; xb = half ? mv[DP >= 4 ? 3 : 0] : mv[1]; }
+                        const bool two = half ? (NV1 == 2) : (NV0 == 2);
+                        double* tq = tp + FW + (half ? n0 : 0);
+                        double pa = 1.0;
+                        int o = 0;
+                        for (int ea = 0; ea < K1; ++ea) {
+                            double pab = pa;
+                            const int nbj = two ? K1 - ea : 1;
+                            for (int eb = 0; eb < nbj; ++eb) { tq[o++] = pab; pab *= xb; }
+                            pa *= xa;
                         }
                     }
                 }
                 wave_lds_sync();
-                // -- 16 k-steps of 4 points: F^T Phi on the matrix cores.  Branch-free for a compile-time block count: every LDS
-                //    read of a step can be in flight before the first product (the first version branched per block and per
-                //    factor, each read followed by its wait: 15 % matrix-pipe and 32 % vector utilisation by the counters) --
+                // -- 8 k-steps of 4 points: F^T Phi on the matrix cores; branch-free for a compile-time block count --
                 auto ksteps = [&](auto nbc) {
                     constexpr int NBK = decltype(nbc)::value;
 #pragma unroll 1
-                    for (int ks4 = 0; ks4 < 16; ++ks4) {
+                    for (int ks4 = 0; ks4 < kSepGradChunk / 4; ++ks4) {
                         const double* tp = tabw + (size_t)(ks4 * 4 + kq) * PS;
-                        const double wt = tp[0];
                         double aF[NA], aE[NE > 0 ? NE : 1], phi[NBK];
 #pragma unroll
-                        for (int ia = 0; ia < NA; ++ia) aF[ia] = wt * tp[offA[ia][0]] * tp[offA[ia][1]];
+                        for (int ia = 0; ia < NA; ++ia) aF[ia] = tp[16 * ia + r16];
 #pragma unroll
-                        for (int e = 0; e < NE; ++e) aE[e] = wt * tp[offE[e][0]] * tp[offE[e][1]];
+                        for (int e = 0; e < NE; ++e) aE[e] = tp[16 * NA + e];
 #pragma unroll
-                        for (int ib = 0; ib < NBK; ++ib) {
-                            phi[ib] = tp[offB[ib][0]];
-#pragma unroll
-                            for (int d = 1; d < DP; ++d) phi[ib] *= tp[offB[ib][d]];
-                        }
+                        for (int ib = 0; ib < NBK; ++ib) phi[ib] = tp[offB[ib][0]] * tp[offB[ib][1]];
 #pragma unroll
                         for (int ib = 0; ib < NBK; ++ib) {
 #pragma unroll

@@ -61,8 +61,8 @@ struct WideArgs {
 __host__ __device__ inline int wide_nsp(int D, int NX) { return rnd2(1 + D + D * D + NX); }
 
 constexpr int kWideStageRows = 64;     // rows per staged chunk (two buffers)
-constexpr int kWideRS = 19;            // row record: factor | beta | u (16) | pad -- an ODD stride: the A-operand reads (ds_read2_b64, banks
-                                       // mod 32 per 16-lane group) of rows r and r + 8 collide at 18 (rollout_stream_kernel.h: stream_row_stride)
+constexpr int kWideRS = 18;            // row record: factor | beta | u (16)  (an odd stride removes the A-operand bank conflicts and is 3 % slower:
+                                       // rollout_stream_kernel.h stream_row_stride, profiles/r04c_ab_c5_grad_*.txt)
 constexpr int kWideFold = 2 * 256 + 16 + 16 * 16 + 16;     // per wavefront: V tile | w tile | c_j | extra inputs of the 16 columns | column factors
 
 struct WideMomLayout {

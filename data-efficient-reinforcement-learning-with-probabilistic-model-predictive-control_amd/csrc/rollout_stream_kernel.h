@@ -81,15 +81,19 @@ __device__ inline double wave_gauss_solve(double* aug, int D, int nrhs, int ld, 
 
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 
-// Row stride of the staged records.  Matrix-core pass (DP = 8, 16): an ODD number of doubles.  The compiler reads the A operand
-// (lane l: component 4 q + (l >> 4) of row l & 15, q = 0 .. DP / 4 - 1) as ds_read2_b64 pairs, which gfx950 services per 16-lane
-// group with banks taken mod 32: at the natural stride DP + 2 = 18 doubles (36 dwords = 4 mod 32) rows r and r + 8 of a group
-// collide -- 16 LDS cycles per instruction where 8 suffice, 31 % of the kernel's LDS cycles by the counters
-// (profiles/r04_c5_late_pmc_t0.txt: SQ_LDS_BANK_CONFLICT 3.44e10 = 4 reads x 8 extra cycles x 1.07e9 tile pairs, to the digit).
-// At 19 doubles (38 dwords = 6 mod 32) the 16 rows of a group fall on 16 distinct even banks.  Separate ds_read_b64 would need
-// half the cycles again (profiles/r04_lds_read_forms.txt) but cost an address instruction each on the shared fp64 / integer
-// issue port, and the kernel is bound there: measured 5 - 7 % SLOWER (profiles/r04b_ab_c5_late_*.txt).
-__host__ __device__ constexpr int stream_row_stride(int DP) { return (DP % 4 == 0 && DP >= 8) ? DP + 3 : DP + 2; }
+// Row stride of the staged records: DP + 2 doubles.  Round-4 experiments on the A-operand reads of the matrix-core pass (lane l:
+// component 4 q + (l >> 4) of row l & 15), which the compiler emits as ds_read2_b64 pairs -- serviced per 16-lane group with
+// banks taken mod 32, so that at a stride of 18 doubles (36 dwords = 4 mod 32) rows r and r + 8 collide: 16 LDS cycles per
+// instruction where 8 suffice, the whole of the 3.44e10 bank-conflict cycles of an N = 4096 launch (= 4 reads x 8 cycles x
+// 1.07e9 tile pairs, profiles/r04_c5_late_pmc_t0.txt), 31 % of the kernel's LDS cycles:
+//   * an ODD stride (19 doubles: the 16 rows of a group on 16 distinct even banks) removes them -- SQ_LDS_BANK_CONFLICT 3.44e10 -> ~0
+//     at the initial state, 6.25e10 -> 2.81e10 (the table gathers of the mid-range exponential) at a late-horizon state
+//     (profiles/r04d_c5_odd_stride_pmc.txt) -- and the horizon step takes 481.8 / 580.9 ms against 476.6 / 573.2 (+1 %);
+//   * separate ds_read_b64 (half the LDS cycles again, profiles/r04_lds_read_forms.txt) cost an address instruction each on
+//     the issue port the fp64 vector and matrix instructions share: 500.3 / 604.9 ms (+5 ... 7 %, profiles/r04b_ab_c5_late_*).
+// The LDS conflicts were never on the critical path: the kernel is bound by fp64 issue (matrix + vector instructions keep the
+// shared pipe busy for 0.36 s of a 0.48 s step at the initial state, 0.45 of 0.57 s late in the horizon).  Stride kept at 18.
+__host__ __device__ constexpr int stream_row_stride(int DP) { return DP + 2; }
 
 // c tiles of TWO 16-row tiles (rows 16 t0 .., 16 t0 + 16 ..) of the stage against the wave's 16 columns.
 template <int DP>
