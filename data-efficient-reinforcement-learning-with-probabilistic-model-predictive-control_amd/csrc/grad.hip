@@ -184,9 +184,11 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
             // weightings beyond a multiple of 16 (one or two) are accumulated on the VALU instead of opening another A block
             const int NE = (nWt > 16 && nWt % 16 != 0 && nWt % 16 <= 2) ? nWt % 16 : 0;
             const int NA = NE ? nWt / 16 : (nWt + 15) / 16;
-            sg.PS = sep_grad_point_words(D, 16 * NA + NE, kmax);
+            const bool v2 = sep_grad_version(DP) == 2;
+            sg.PS = v2 ? sep_grad_point_words(D, 16 * NA + NE, kmax) : sep_grad_point_words_v1(D, NX, kmax);
+            const int chunk = v2 ? sep_grad_chunk(DP) : 64;
             const int mat_words = nWt * 16 * kSepGradBlocks;          // moment matrix of a (pair, side): weightings x monomial slots
-            sg.wave_words = kSepGradChunk * sg.PS > mat_words ? kSepGradChunk * sg.PS : mat_words;
+            sg.wave_words = chunk * sg.PS > mat_words ? chunk * sg.PS : mat_words;
             const int Poff = P - D;
             const size_t lds = ((size_t)rnd2(E) + rnd2(D * E) + rnd2((Poff > 0 ? Poff : 1) * DP * DP) + 64 + 8 + 16 * kSepGradBlocks
                                 + 8 * kSepGradBlocks + 8 + (size_t)sep_grad_waves(DP) * sg.wave_words) * sizeof(double);

@@ -64,18 +64,34 @@ struct SepGradArgs {
 // the first version read 3 and D of them (wt, two factors; one power per variable) -- 17 individually addressed reads per
 // lane and 4-point step at config 4, two thirds of whose LDS cycles were bank conflicts (profiles/r03_c4_gradient_pmc.txt:
 // 3.29e9 conflict cycles against 4.90e9 active), next to ~25 multiplies that formed the operands.
-// Stride = 16 (mod 32) doubles: the two points a 32-lane half reads (kq = 0 / 1, 2 / 3) sit 32 banks apart, and within a point
-// the 16 lanes read 16 consecutive doubles (weightings) or entries of a table of <= 15 doubles (monomial factors): conflict-free.
+// Stride: an ODD number of doubles.  The table pass WRITES with lanes = points (every lane the same slot of its own point): at
+// an even stride the 16 lanes of a store group share banks -- at 48 doubles (= 0 mod 32 dwords, chosen first because it puts
+// the two points a 32-lane half READS 32 banks apart) all of them hit ONE bank, 64 LDS cycles per store instead of 4, and the
+// pass got slower than its predecessor (87 / 83 ms at config 4 against 66: profiles/r04e_sepv2a_*, r04f_sepv2b_*).  At an odd
+// stride the stores are conflict-free and the reads nearly so (the 16 lanes of a point read 16 consecutive doubles or entries
+// of a table of <= 15 doubles; two points 2 x odd dwords apart overlap in at most one bank pair).
+// first version (kept for D <= 3, see sep_grad_version): wt | v = (1, u_0 .., nu_x ..) | powers x_d^e, e = 0 .. K | one zero; odd stride
+__host__ __device__ inline int sep_grad_point_words_v1(int D, int NX, int K) {
+    const int n = 1 + (1 + D + NX) + D * (K + 1) + 1;
+    return n | 1;
+}
+// Which table form a state dimension takes.  Version 2 (weightings + pair-product tables, 32-point chunks) wins where the
+// k-steps dominate: D = 4 (config 4: 66.4 -> 52.6 ms).  At D <= 3 the tables of 64 points no longer fit the wavefront's LDS
+// region with it, and with 32-point chunks the per-chunk table pass -- 7 instead of 4 at N = 200 -- outweighs the cheaper
+// k-steps of the one or two monomial blocks these shapes have (config 2: 0.45 -> 0.56 ms, config 3 +2 %:
+// profiles/r04f_sepv2d_*): they keep version 1 (per-variable power tables, operands assembled in the k-step).
+__host__ __device__ constexpr int sep_grad_version(int DP) { return DP >= 4 ? 2 : 1; }
+
 __host__ __device__ inline int sep_grad_tri(int K1, int nv) { return nv == 2 ? K1 * (K1 + 1) / 2 : K1; }
 __host__ __device__ inline int sep_grad_nv0(int D) { return D >= 3 ? 2 : 1; }        // variables of the first group
 __host__ __device__ inline int sep_grad_point_words(int D, int FW, int K) {
     const int nv0 = sep_grad_nv0(D), nv1 = D - nv0;
     const int n = FW + sep_grad_tri(K + 1, nv0) + sep_grad_tri(K + 1, nv1);
-    int ps = 16;
-    while (ps < n) ps += 32;
-    return ps;
+    return n | 1;
 }
-constexpr int kSepGradChunk = 32;      // points per chunk (two lanes per point in the table pass)
+// points per chunk: 64 (lane = point: weightings and both factor tables) while 64 tables fit the wavefront's LDS region (D <= 3:
+// <= 31 doubles per point); 32 at D = 4 (49 doubles per point), two lanes per point sharing the work by variable group
+__host__ __device__ constexpr int sep_grad_chunk(int DP) { return DP <= 3 ? 64 : 32; }
 
 // ------------------------------------------------------------------------------------------
 // NA: blocks of 16 weightings on the matrix cores; NE: weightings 16 NA .. 16 NA + NE - 1 accumulated by plain FMAs instead (a 17th
@@ -163,6 +179,39 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
     __syncthreads();
 
     const int r16 = lane & 15, kq = lane >> 4;
+    const int NV = 1 + D + NX;                           // weighting vector (1, u, nu_x) of the first table form
+    // per-lane selectors.  A operand: weighting r = 16 ia + (lane & 15) -> two indices into the weighting vector;
+    // B operand: monomial n = 16 ib + (lane & 15) -> packed exponents (read per block below)
+    int selA[NA][2];
+#pragma unroll
+    for (int ia = 0; ia < NA; ++ia) {
+        const int r = ia * 16 + r16;
+        int s1 = 0, s2 = 0;
+        if (r >= 1 && r <= D) s1 = r;
+        else if (r > D && r < 1 + D + D * (D + 1) / 2) {
+            int k = r - 1 - D, d = 0;
+            while (k >= D - d) { k -= D - d; ++d; }
+            s1 = 1 + d; s2 = 1 + d + k;
+        } else if (r >= 1 + D + D * (D + 1) / 2 && r < nW) s1 = 1 + D + (r - 1 - D - D * (D + 1) / 2);
+        selA[ia][0] = (r < nW) ? s1 : -1;
+        selA[ia][1] = s2;
+    }
+    // the extra weightings (wave-uniform selectors)
+    int selE[NE > 0 ? NE : 1][2];
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+        const int r = NA * 16 + e;
+        int s1 = 0, s2 = 0;
+        if (r >= 1 && r <= D) s1 = r;
+        else if (r > D && r < 1 + D + D * (D + 1) / 2) {
+            int k = r - 1 - D, d = 0;
+            while (k >= D - d) { k -= D - d; ++d; }
+            s1 = 1 + d; s2 = 1 + d + k;
+        } else if (r >= 1 + D + D * (D + 1) / 2 && r < nW) s1 = 1 + D + (r - 1 - D - D * (D + 1) / 2);
+        selE[e][0] = (r < nW) ? s1 : -1;
+        selE[e][1] = s2;
+    }
+
 
     // ---- tasks (off-diagonal pair, side): two rounds of wavefronts per pair pair, then the combination ----------------
     for (int pq0 = 0; pq0 < Poff; pq0 += NW / 2) {
@@ -180,6 +229,128 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
             const double* Z = s_Z + pq * DP * DP;
             const double* il = s_ils2 + co * E;
             const double lv = p.logvar[co];
+            mfma_d4 acc[NA][NB];
+            double accE[NE > 0 ? NE : 1][NB];
+            if constexpr (sep_grad_version(DP) == 1) {
+            const int K1 = K + 1;
+            // word offsets of the lane's monomial factors inside a point's table (loop-invariant: one address add per LDS read in
+            // the k-steps; forming them from the packed exponents there cost 3 - 4 integer instructions per read, 122 VALU
+            // instructions per 4-point step by the counters against ~16 matrix instructions)
+            const int zslot = 1 + NV + D * K1;                 // the zero of a point's table
+            int offB[NB][DP];
+#pragma unroll
+            for (int ib = 0; ib < NB; ++ib) {
+                const int ex = s_me[ib * 16 + r16];
+#pragma unroll
+                for (int d = 0; d < DP; ++d) offB[ib][d] = 1 + NV + d * K1 + ((ex >> (8 * d)) & 255);
+                if (ib * 16 + r16 >= C) offB[ib][0] = zslot;      // monomial slots past the degree's count contribute nothing
+            }
+            // weightings: wt * v[s1] * v[s2]; rows past the last weighting read the zero
+            int offA[NA][2], offE[NE > 0 ? NE : 1][2];
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia) { offA[ia][0] = selA[ia][0] >= 0 ? 1 + selA[ia][0] : zslot; offA[ia][1] = 1 + selA[ia][1]; }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) { offE[e][0] = selE[e][0] >= 0 ? 1 + selE[e][0] : zslot; offE[e][1] = 1 + selE[e][1]; }
+#pragma unroll
+            for (int ia = 0; ia < NA; ++ia)
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib) acc[ia][ib] = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int e = 0; e < NE; ++e)
+#pragma unroll
+                for (int ib = 0; ib < NB; ++ib) accE[e][ib] = 0.0;
+            for (int c0 = 0; c0 < N; c0 += 64) {
+                // -- per-point tables (lane = point) --
+                {
+                    const int pt0 = c0 + lane;
+                    const bool live = pt0 < N;
+                    const int pt = live ? pt0 : N - 1;
+                    double* tp = tabw + (size_t)lane * PS;
+                    double nu[DP], x[DP], zx[DP];
+                    double ks = 0.0;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) {
+                        nu[d] = (d < D) ? p.Xt[(size_t)d * N + pt] - s_m[d] : 0.0;
+                        x[d] = (d < D) ? nu[d] * il[d] : 0.0;          // u (rows) or w (columns)
+                        ks = fma(nu[d], x[d], ks);
+                    }
+                    tp[1] = 1.0;
+                    tp[zslot] = 0.0;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) if (d < D) tp[2 + d] = x[d];
+                    for (int xx = 0; xx < NX; ++xx) {
+                        const double v = p.Xt[(size_t)(D + xx) * N + pt] - s_m[D + xx];
+                        ks = fma(v * v, il[D + xx], ks);
+                        tp[2 + D + xx] = v;
+                    }
+                    double qq = 0.0;
+                    double g[DP];
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) g[d] = 0.0;
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) {
+                        zx[i] = 0.0;
+#pragma unroll
+                        for (int j = 0; j < DP; ++j) {
+                            zx[i] = fma(Z[i * DP + j], x[j], zx[i]);
+                            g[j] = fma(Z[i * DP + j], x[i], g[j]);            // Z^T x
+                        }
+                        qq = fma(x[i], zx[i], qq);
+                    }
+                    const double kk = lv - 0.5 * ks + 0.5 * qq;
+                    tp[0] = live ? fast_exp(kk, s_tab) * p.beta[(size_t)co * N + pt] : 0.0;
+                    // monomial variables: g = Z^T u on the row side, w itself on the column side
+                    double* pw = tp + 1 + NV;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) {
+                        if (d < D) {
+                            const double xv = side ? x[d] : g[d];
+                            double pv = 1.0;
+                            for (int e = 0; e < K1; ++e) { pw[d * K1 + e] = pv; pv *= xv; }
+                        }
+                    }
+                }
+                wave_lds_sync();
+                // -- 16 k-steps of 4 points: F^T Phi on the matrix cores.  Branch-free for a compile-time block count: every LDS
+                //    read of a step can be in flight before the first product (the first version branched per block and per
+                //    factor, each read followed by its wait: 15 % matrix-pipe and 32 % vector utilisation by the counters) --
+                auto ksteps = [&](auto nbc) {
+                    constexpr int NBK = decltype(nbc)::value;
+#pragma unroll 1
+                    for (int ks4 = 0; ks4 < 16; ++ks4) {
+                        const double* tp = tabw + (size_t)(ks4 * 4 + kq) * PS;
+                        const double wt = tp[0];
+                        double aF[NA], aE[NE > 0 ? NE : 1], phi[NBK];
+#pragma unroll
+                        for (int ia = 0; ia < NA; ++ia) aF[ia] = wt * tp[offA[ia][0]] * tp[offA[ia][1]];
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) aE[e] = wt * tp[offE[e][0]] * tp[offE[e][1]];
+#pragma unroll
+                        for (int ib = 0; ib < NBK; ++ib) {
+                            phi[ib] = tp[offB[ib][0]];
+#pragma unroll
+                            for (int d = 1; d < DP; ++d) phi[ib] *= tp[offB[ib][d]];
+                        }
+#pragma unroll
+                        for (int ib = 0; ib < NBK; ++ib) {
+#pragma unroll
+                            for (int ia = 0; ia < NA; ++ia) acc[ia][ib] = __builtin_amdgcn_mfma_f64_16x16x4f64(aF[ia], phi[ib], acc[ia][ib], 0, 0, 0);
+#pragma unroll
+                            for (int e = 0; e < NE; ++e) accE[e][ib] = fma(aE[e], phi[ib], accE[e][ib]);
+                        }
+                    }
+                };
+                static_assert(NB == 5, "block-count dispatch below");
+                switch (nb) {
+                    case 1: ksteps(std::integral_constant<int, 1>{}); break;
+                    case 2: ksteps(std::integral_constant<int, 2>{}); break;
+                    case 3: ksteps(std::integral_constant<int, 3>{}); break;
+                    case 4: ksteps(std::integral_constant<int, 4>{}); break;
+                    default: ksteps(std::integral_constant<int, 5>{}); break;
+                }
+                wave_lds_sync();
+            }
+            } else {
             const int K1 = K + 1;
             constexpr int FW = 16 * NA + NE;                   // weightings kept per point
             constexpr int NV0 = DP >= 3 ? 2 : 1, NV1 = DP - NV0;          // monomial variables of the two factor tables (D == DP here)
@@ -201,39 +372,73 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
                 offB[ib][0] = in ? FW + o0 : 0;
                 offB[ib][1] = in ? FW + n0 + o1 : 0;
             }
-            mfma_d4 acc[NA][NB];
 #pragma unroll
             for (int ia = 0; ia < NA; ++ia)
 #pragma unroll
                 for (int ib = 0; ib < NB; ++ib) acc[ia][ib] = mfma_d4{0.0, 0.0, 0.0, 0.0};
-            double accE[NE > 0 ? NE : 1][NB];
 #pragma unroll
             for (int e = 0; e < NE; ++e)
 #pragma unroll
                 for (int ib = 0; ib < NB; ++ib) accE[e][ib] = 0.0;
             // table pass roles: two lanes per point -- both form the weightings (the lower one stores them), each one of the two
             // factor tables (uniform code, the variables chosen by data)
-            const int tpt = lane & (kSepGradChunk - 1), half = lane >> 5;
+            constexpr int kSepGradChunk = sep_grad_chunk(DP);
+            const int tpt = lane & (kSepGradChunk - 1), half = kSepGradChunk == 64 ? 0 : lane >> 5;
+            // The inputs of a chunk's points are loaded ONE CHUNK AHEAD, unconditionally and from clamped indices: a load behind a
+            // per-lane condition (`d < D ? X[..] : 0`) compiles to an exec-masked branch with its own wait, i.e. the L2 latencies of
+            // the D + NX + 1 loads in sequence at the head of every chunk -- with 32-point chunks that was most of the pass (first
+            // build of this version: 87 ms at config 4 against 66 for its predecessor, profiles/r04e_sepv2a_*).
+            constexpr int NXL = 6;                             // extra inputs (actions + time) the gradient kernels take
+            // the task's small operands (Z, 1 / l^2, the input mean) as wave-uniform values in scalar registers: as LDS reads they sit
+            // behind the wavefront fences of the chunk loop and were re-read -- 16 + 2 (D + NX) broadcast reads and their latency --
+            // at the head of every chunk
+            auto uni = [](double v) {
+                return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+            };
+            double Zr[DP][DP], ilr[DP + NXL], smr[DP + NXL];
+#pragma unroll
+            for (int i = 0; i < DP; ++i)
+#pragma unroll
+                for (int j = 0; j < DP; ++j) Zr[i][j] = uni(Z[i * DP + j]);
+#pragma unroll
+            for (int e = 0; e < DP + NXL; ++e) {
+                const int ee = e < DP ? (e < D ? e : 0) : D + (e - DP < NX ? e - DP : 0);
+                const bool in = e < DP ? e < D : e - DP < NX;
+                ilr[e] = in ? uni(il[ee]) : 0.0;
+                smr[e] = in ? uni(s_m[ee]) : 0.0;
+            }
+            double xin[DP], xein[NXL], bin;
+            auto load_chunk = [&](int c0) {
+                const int pt0 = c0 + tpt;
+                const int pt = pt0 < N ? pt0 : N - 1;
+#pragma unroll
+                for (int d = 0; d < DP; ++d) xin[d] = p.Xt[(size_t)(d < D ? d : D - 1) * N + pt];
+#pragma unroll
+                for (int xx = 0; xx < NXL; ++xx) xein[xx] = p.Xt[(size_t)(D + (xx < NX ? xx : 0)) * N + pt];     // NX >= 1 (an action)
+                bin = p.beta[(size_t)co * N + pt];
+            };
+            load_chunk(0);
             for (int c0 = 0; c0 < N; c0 += kSepGradChunk) {
                 // -- per-point tables --
                 {
                     const int pt0 = c0 + tpt;
                     const bool live = pt0 < N;
-                    const int pt = live ? pt0 : N - 1;
                     double* tp = tabw + (size_t)tpt * PS;
-                    double nu[DP], x[DP], zx[DP], xe[8];
+                    double nu[DP], x[DP], zx[DP], xe[NXL];
                     double ks = 0.0;
 #pragma unroll
                     for (int d = 0; d < DP; ++d) {
-                        nu[d] = (d < D) ? p.Xt[(size_t)d * N + pt] - s_m[d] : 0.0;
-                        x[d] = (d < D) ? nu[d] * il[d] : 0.0;          // u (rows) or w (columns)
+                        nu[d] = (d < D) ? xin[d] - smr[d] : 0.0;
+                        x[d] = nu[d] * ilr[d];                         // u (rows) or w (columns)
                         ks = fma(nu[d], x[d], ks);
                     }
 #pragma unroll
-                    for (int xx = 0; xx < 8; ++xx) {
-                        xe[xx] = (xx < NX) ? p.Xt[(size_t)(D + (xx < NX ? xx : 0)) * N + pt] - s_m[D + (xx < NX ? xx : 0)] : 0.0;
-                        ks = fma(xe[xx] * xe[xx], (xx < NX) ? il[D + xx] : 0.0, ks);
+                    for (int xx = 0; xx < NXL; ++xx) {
+                        xe[xx] = (xx < NX) ? xein[xx] - smr[DP + xx] : 0.0;
+                        ks = fma(xe[xx] * xe[xx], ilr[DP + xx], ks);
                     }
+                    const double bpt = bin;
+                    if (c0 + kSepGradChunk < N) load_chunk(c0 + kSepGradChunk);          // in flight during this chunk's tables and k-steps
                     double qq = 0.0;
                     double g[DP];
 #pragma unroll
@@ -243,13 +448,13 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
                         zx[i] = 0.0;
 #pragma unroll
                         for (int j = 0; j < DP; ++j) {
-                            zx[i] = fma(Z[i * DP + j], x[j], zx[i]);
-                            g[j] = fma(Z[i * DP + j], x[i], g[j]);            // Z^T x
+                            zx[i] = fma(Zr[i][j], x[j], zx[i]);
+                            g[j] = fma(Zr[i][j], x[i], g[j]);                  // Z^T x
                         }
                         qq = fma(x[i], zx[i], qq);
                     }
                     const double kk = lv - 0.5 * ks + 0.5 * qq;
-                    const double wt = live ? fast_exp(kk, s_tab) * p.beta[(size_t)co * N + pt] : 0.0;
+                    const double wt = live ? fast_exp(kk, s_tab) * bpt : 0.0;
                     // weightings wt f(v), f in {1, v_d, v_d v_e (d <= e), nu_x}: compile-time positions (D == DP)
                     if (half == 0) {
                         constexpr int T2c = DP * (DP + 1) / 2;
@@ -263,46 +468,60 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
 #pragma unroll
                             for (int e = d; e < DP; ++e) { if (r < FW) tp[r] = wv[d] * x[e]; ++r; }
 #pragma unroll
-                        for (int xx = 0; xx < 8; ++xx) { if (1 + DP + T2c + xx < FW) tp[1 + DP + T2c + xx] = wt * xe[xx]; }     // zero past NX
+                        for (int xx = 0; xx < NXL; ++xx) { if (1 + DP + T2c + xx < FW) tp[1 + DP + T2c + xx] = wt * xe[xx]; }     // zero past NX
 #pragma unroll
-                        for (int r2 = 1 + DP + T2c + 8; r2 < FW; ++r2) tp[r2] = 0.0;
+                        for (int r2 = 1 + DP + T2c + NXL; r2 < FW; ++r2) tp[r2] = 0.0;
                     }
-                    // factor table of this lane's variable group: x_a^i x_b^j, i + j <= K (monomial variables: g = Z^T u on the row
-                    // side, w itself on the column side)
+                    // factor tables x_a^i x_b^j, i + j <= K, of the two variable groups (monomial variables: g = Z^T u on the row side, w
+                    // itself on the column side): both by this lane (64-point chunks) or the group of its half (32-point chunks)
                     {
                         double mv[DP];
 #pragma unroll
                         for (int d = 0; d < DP; ++d) mv[d] = side ? x[d] : g[d];
-                        double xa, xb;
-                        if (DP == 2) { xa = half ? mv[1] : mv[0]; xb = 0.0; }
-                        else if (DP == 3) { xa = half ? mv[2] : mv[0]; xb = half ? 0.0 : mv[1]; }
-                        else { xa = half ? mv[DP >= 4 ? 2 : 0] : mv[0]; xb = half ? mv[DP >= 4 ? 3 : 0] : mv[1]; }
-                        const bool two = half ? (NV1 == 2) : (NV0 == 2);
-                        double* tq = tp + FW + (half ? n0 : 0);
-                        double pa = 1.0;
-                        int o = 0;
-                        for (int ea = 0; ea < K1; ++ea) {
-                            double pab = pa;
-                            const int nbj = two ? K1 - ea : 1;
-                            for (int eb = 0; eb < nbj; ++eb) { tq[o++] = pab; pab *= xb; }
-                            pa *= xa;
+#pragma unroll
+                        for (int hh = 0; hh < (kSepGradChunk == 64 ? 2 : 1); ++hh) {
+                            const int hs = kSepGradChunk == 64 ? hh : half;
+                            double xa, xb;
+                            if (DP == 2) { xa = hs ? mv[1] : mv[0]; xb = 0.0; }
+                            else if (DP == 3) { xa = hs ? mv[2] : mv[0]; xb = hs ? 0.0 : mv[1]; }
+                            else { xa = hs ? mv[DP >= 4 ? 2 : 0] : mv[0]; xb = hs ? mv[DP >= 4 ? 3 : 0] : mv[1]; }
+                            const bool two = hs ? (NV1 == 2) : (NV0 == 2);
+                            double* tq = tp + FW + (hs ? n0 : 0);
+                            double pa = 1.0;
+                            int o = 0;
+                            for (int ea = 0; ea < K1; ++ea) {
+                                double pab = pa;
+                                const int nbj = two ? K1 - ea : 1;
+                                for (int eb = 0; eb < nbj; ++eb) { tq[o++] = pab; pab *= xb; }
+                                pa *= xa;
+                            }
                         }
                     }
                 }
                 wave_lds_sync();
-                // -- 8 k-steps of 4 points: F^T Phi on the matrix cores; branch-free for a compile-time block count --
+                // -- k-steps of 4 points: F^T Phi on the matrix cores; branch-free for a compile-time block count --
                 auto ksteps = [&](auto nbc) {
                     constexpr int NBK = decltype(nbc)::value;
+                    // the operands of step s + 1 are read before the matrix instructions of step s issue (a wavefront issues in order:
+                    // behind three 64-cycle matrix instructions the reads of the next step would start 130 cycles of LDS latency late)
+                    double aF[NA], aE[NE > 0 ? NE : 1], b0[NBK], b1[NBK];
+                    auto fetch = [&](int ks4, double (&fa)[NA], double (&fe)[NE > 0 ? NE : 1], double (&f0)[NBK], double (&f1)[NBK]) {
+                        const double* tp = tabw + (size_t)(ks4 * 4 + kq) * PS;
+#pragma unroll
+                        for (int ia = 0; ia < NA; ++ia) fa[ia] = tp[16 * ia + r16];
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) fe[e] = tp[16 * NA + e];
+#pragma unroll
+                        for (int ib = 0; ib < NBK; ++ib) { f0[ib] = tp[offB[ib][0]]; f1[ib] = tp[offB[ib][1]]; }
+                    };
+                    fetch(0, aF, aE, b0, b1);
 #pragma unroll 1
                     for (int ks4 = 0; ks4 < kSepGradChunk / 4; ++ks4) {
-                        const double* tp = tabw + (size_t)(ks4 * 4 + kq) * PS;
-                        double aF[NA], aE[NE > 0 ? NE : 1], phi[NBK];
+                        double nF[NA], nE[NE > 0 ? NE : 1], n0[NBK], n1[NBK];
+                        fetch(ks4 + 1 < kSepGradChunk / 4 ? ks4 + 1 : ks4, nF, nE, n0, n1);
+                        double phi[NBK];
 #pragma unroll
-                        for (int ia = 0; ia < NA; ++ia) aF[ia] = tp[16 * ia + r16];
-#pragma unroll
-                        for (int e = 0; e < NE; ++e) aE[e] = tp[16 * NA + e];
-#pragma unroll
-                        for (int ib = 0; ib < NBK; ++ib) phi[ib] = tp[offB[ib][0]] * tp[offB[ib][1]];
+                        for (int ib = 0; ib < NBK; ++ib) phi[ib] = b0[ib] * b1[ib];
 #pragma unroll
                         for (int ib = 0; ib < NBK; ++ib) {
 #pragma unroll
@@ -310,6 +529,12 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
 #pragma unroll
                             for (int e = 0; e < NE; ++e) accE[e][ib] = fma(aE[e], phi[ib], accE[e][ib]);
                         }
+#pragma unroll
+                        for (int ia = 0; ia < NA; ++ia) aF[ia] = nF[ia];
+#pragma unroll
+                        for (int e = 0; e < NE; ++e) aE[e] = nE[e];
+#pragma unroll
+                        for (int ib = 0; ib < NBK; ++ib) { b0[ib] = n0[ib]; b1[ib] = n1[ib]; }
                     }
                 };
                 static_assert(NB == 5, "block-count dispatch below");
@@ -321,6 +546,7 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
                     default: ksteps(std::integral_constant<int, 5>{}); break;
                 }
                 wave_lds_sync();
+            }
             }
             // moment matrix of this (pair, side) into the wavefront's region: M[weighting][monomial], row stride 16 NB
 #pragma unroll
