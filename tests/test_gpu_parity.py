@@ -553,6 +553,34 @@ def test_config5_full_horizon_against_oracle_fixture(engine):
     assert rel_err(out["J"].cpu().numpy(), g["J"]) < 1e-7
 
 
+def test_config5_in_range_horizon_against_oracle_fixture(engine):
+    """Config 5's size with a state that STAYS where the memory is: N = 4096, D = 16, A = 4, H = 20, four
+    candidates, targets that pull every state towards 0.5 and a DENSE initial covariance (synth `dynamics="contracting"`,
+    `dense_s0`), vs tests/golden/oracle_c5_inrange.npz (CPU oracle, `tools/gen_golden_c5.py --inrange --steps 20 --candidates 4`,
+    ~90 minutes).  In the H = 50 fixture the mean leaves [0, 1] after ~10 steps and the GP falls back to its prior (Sigma diag
+    grows to 1.6); here Sigma diag runs 1.7e-2 -> 5e-4 .. 2e-3 and every step exercises the data-dependent terms.  Every step
+    is compared relative to THAT step's covariance scale."""
+    g = load("oracle_c5_inrange")
+    H, B = int(g["H"]), int(g["B"])
+    w = synth.make_workload(int(g["N"]), int(g["D"]), int(g["A"]), H, B, seed=int(g["seed"]), dynamics="contracting", dense_s0=0.02)
+    assert np.allclose([w.X.sum(), w.Y.sum(), w.actions.sum()], g["x_checksum"], rtol=0, atol=1e-9)   # same inputs
+    assert np.abs(w.S0 - np.diag(np.diag(w.S0))).max() > 1e-3                                            # dense Sigma_0
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    _set_cost(engine, w)
+    out = engine.rollout(w.actions, w.mu0, w.S0)
+    mu, Sig = out["mu"].cpu().numpy(), out["Sig"].cpu().numpy()
+    assert g["mu"].min() > 0.0 and g["mu"].max() < 1.0                                                   # in range over the whole horizon
+    per_step = [rel_err(Sig[:, t], g["Sig"][:, t]) for t in range(1, H + 1)]
+    per_step_mu = [rel_err(mu[:, t], g["mu"][:, t]) for t in range(1, H + 1)]
+    record("config5_in_range_horizon", mu=max(per_step_mu), Sig=max(per_step), J=rel_err(out["J"].cpu().numpy(), g["J"]),
+           Sig_worst_step=float(np.argmax(per_step) + 1), Sig_step1=per_step[0], Sig_step5=per_step[4], Sig_step10=per_step[9],
+           Sig_step20=per_step[19], Sig_diag_max_step20=float(np.diagonal(g["Sig"][:, H], axis1=-1, axis2=-2).max()))
+    assert max(per_step_mu) < 1e-8
+    assert max(per_step) < 1e-5
+    assert rel_err(out["cost_var"].cpu().numpy(), g["cost_var"]) < 1e-5
+    assert rel_err(out["J"].cpu().numpy(), g["J"]) < 1e-7
+
+
 def test_random_shapes_against_oracle(engine):
     """Seeded fuzz over shapes (N not a multiple of 4 / 16 / 64, single points, padded D, time input, small and
     large input variance): layout, padding and chunking edge cases of both kernels."""

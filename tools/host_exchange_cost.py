@@ -5,7 +5,8 @@ all_gather_into_tensor of W records + the cross-rank keep-the-best rule -- `iter
 the next exchange as soon as it has the previous result, like bench.py's loop).  Prints one JSON object (rank 0):
 median / p90 / p99 / max of the per-call host time in ms, per rank.
 
-  python tools/host_exchange_cost.py --world 8 --iters 1000 > profiles/r04_host_exchange_world8.json
+  python tools/host_exchange_cost.py --world 8 --iters 1000 --out profiles/r04_host_exchange_world8.json
+(gloo prints its connection banners to stdout: the JSON goes to --out)
 """
 import argparse
 import json
@@ -49,6 +50,7 @@ def main():
     ap.add_argument("--world", type=int, default=8)
     ap.add_argument("--iters", type=int, default=1000)
     ap.add_argument("--record", type=int, default=25, help="H*A of the winner record (config 2: 25)")
+    ap.add_argument("--out", default=None)
     args = ap.parse_args()
     mgr = mp.Manager()
     ret = mgr.dict()
@@ -60,6 +62,8 @@ def main():
            "load_note": "the ranks share this box's cores with nothing else; on a GPU node each rank also drives its GPU",
            "median_ms_worst_rank": max(p["median"] for p in per), "p99_ms_worst_rank": max(p["p99"] for p in per),
            "per_rank": per}
+    if args.out:
+        json.dump(out, open(args.out, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
 
