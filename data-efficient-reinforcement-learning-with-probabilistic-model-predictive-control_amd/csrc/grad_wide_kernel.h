@@ -288,8 +288,23 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
             const double* Zu = s_Z + (orient ? 256 : 0);
             const double* beta_r = p.beta + (size_t)rs * N;
             const double* beta_c = p.beta + (size_t)cs_ * N;
-            auto fill = [&](int ch, double* st) {
-                constexpr int TPR = NT / CHW, DPT = 16 / TPR;      // threads per row, dimensions per thread
+            // Stage fill in two halves: the chunk's inputs are LOADED (unconditionally, from clamped indices: a load behind a per-lane
+            // condition compiles to a branch with its own wait) before the tile loop of the current chunk and turned into row records
+            // AFTER it -- in one piece at the head of the iteration every wavefront of the workgroup sat out the L2 latency together
+            // once per 64-row chunk (the chunks are barrier-paced: nothing else runs on the SIMDs meanwhile).
+            constexpr int TPR = NT / CHW, DPT = 16 / TPR;          // threads per row, dimensions per thread
+            auto fill_load = [&](int ch, double (&fx)[DPT], double& fb) {
+                const int row = tid / TPR, part = tid - row * TPR;
+                const int i = ch * CHW + row;
+                const int ic = i < N ? i : N - 1;
+#pragma unroll
+                for (int k = 0; k < DPT; ++k) {
+                    const int d = part * DPT + k;
+                    fx[k] = p.Xt[(size_t)(d < D ? d : D - 1) * N + ic];
+                }
+                fb = beta_r[ic];
+            };
+            auto fill_store = [&](int ch, double* st, const double (&fx)[DPT], double fb) {
                 const int row = tid / TPR, part = tid - row * TPR;
                 const int i = ch * CHW + row;
                 const bool in = i < N;
@@ -298,14 +313,19 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
 #pragma unroll
                 for (int k = 0; k < DPT; ++k) {
                     const int d = part * DPT + k;
-                    rec[2 + d] = (in && d < D) ? (p.Xt[(size_t)d * N + ic] - s_m[d]) * il_r[d] : 0.0;
+                    const int dc = d < D ? d : 0;
+                    rec[2 + d] = (in && d < D) ? (fx[k] - s_m[dc]) * il_r[dc] : 0.0;
                 }
                 if (part == 0) {
                     const double er = in ? fast_exp(k_r[ic], s_exptab) : 0.0;
-                    const double br = beta_r[ic];
-                    rec[0] = diag ? er : er * br;
-                    rec[1] = br;
+                    rec[0] = diag ? er : er * fb;
+                    rec[1] = fb;
                 }
+            };
+            auto fill = [&](int ch, double* st) {
+                double fx[DPT], fb;
+                fill_load(ch, fx, fb);
+                fill_store(ch, st, fx, fb);
             };
             for (int sw = 0; sw < nsweep; ++sw) {
                 const int ct = sw * NW + wave;
@@ -335,7 +355,9 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                 fill(0, s_stage);
                 __syncthreads();
                 for (int ch = 0; ch < nchunk; ++ch) {
-                    if (ch + 1 < nchunk) fill(ch + 1, s_stage + ((ch + 1) & 1) * CHW * RSW);
+                    double nfx[DPT], nfb = 0.0;
+                    const bool more = ch + 1 < nchunk;
+                    if (more) fill_load(ch + 1, nfx, nfb);
                     const double* st = s_stage + (ch & 1) * CHW * RSW;
                     if (act) {
 #pragma unroll 1
@@ -398,6 +420,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                             }
                         }
                     }
+                    if (more) fill_store(ch + 1, s_stage + ((ch + 1) & 1) * CHW * RSW, nfx, nfb);
                     __syncthreads();
                 }
                 if (act) {
