@@ -16,7 +16,7 @@
 // That is O(N (#weightings x #monomials)) per pair and side instead of O(N^2), and G = F^T Phi is a genuine matrix product
 // with the POINTS as the inner dimension: 16 weightings x 16 monomials per v_mfma_f64_16x16x4_f64, four points per
 // instruction, no cross-lane reduction anywhere (the element-wise form of this idea needed 4 x 16 accumulators per lane
-// and spilled: DESIGN.md section 8 item 3).  A wavefront owns one (pair, side): per 32 points it writes, per point, the
+// and spilled: DESIGN.md section 4.4).  A wavefront owns one (pair, side): per 32 points it writes, per point, the
 // weightings wt_i f(v_i) themselves and two small tables of products of the monomial variables (x_0^i x_1^j | x_2^i x_3^j) to
 // LDS (two lanes per point), then 8 k-steps of MFMAs whose A operand is ONE table read and whose B operand is the product of
 // two (sep_grad_point_words).
