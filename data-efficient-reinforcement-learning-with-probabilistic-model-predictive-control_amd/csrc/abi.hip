@@ -99,6 +99,7 @@ int gpmpc_set_option(gpmpc_t* g, const char* name, long long value) {
     if (!g || !name) return GPMPC_ERR_ARG;
     Handle* h = H_(g);
     if (!strcmp(name, "threads")) h->opt_threads = (int)value;
+    else if (!strcmp(name, "lds_limit_kb")) h->opt_lds_kb = (int)value;
     else if (!strcmp(name, "force_global_scratch")) h->opt_force_global = (int)value;
     else if (!strcmp(name, "rows_per_chunk")) h->opt_rows_per_chunk = (int)value;
     else if (!strcmp(name, "force_path")) h->opt_force_path = (int)value;

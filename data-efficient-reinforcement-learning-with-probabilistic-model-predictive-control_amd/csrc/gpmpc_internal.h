@@ -136,6 +136,7 @@ struct Handle {
     int use_constraints = 0;
     // options
     int opt_threads = 0;
+    int opt_lds_kb = 0;              // > 0: LDS budget (KiB) of a fused-horizon workgroup (with threads = 512: two workgroups per CU)
     int opt_force_global = 0;
     int opt_rows_per_chunk = 0;
     int opt_force_path = 0;

@@ -209,6 +209,15 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
             else if (a.B >= 2 * h->num_cu) nt = 512;
         }
     }
+    // Mid-size memories with many workgroups per CU: two workgroups of 8 wavefronts share a CU (half the LDS each: the row
+    // records of half the output pairs at a time), so that one's serial phases run beside the other's pairwise pass.  Measured
+    // (round 4, profiles/r04h_share_cu.txt, config-2 shape N = 200): B = 512 equal, B = 1024 +2.6 %, B = 4096 +7.9 % (606 -> 654 k
+    // rollouts/s); N = 500: -4 % at B = 1024, +2.6 % at 4096; N = 50: equal.  Hence from 8 workgroups per CU on, N in (64, 256].
+    bool share_cu = false;
+    if (h->opt_threads == 0 && h->opt_lds_kb == 0 && N > 64 && N <= 256 && D <= 4 && a.B >= 8 * h->num_cu && h->opt_pair_tiles != 1) {
+        nt = 512;
+        share_cu = true;
+    }
     const int nw = nt / 64;
     int rcm = ensure_monomials(h, D);
     if (rcm) return rcm;
@@ -221,6 +230,11 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     a.force_sep = h->opt_force_sep;
     a.exact_dim = h->opt_exact_dim;
 
+    // LDS budget of a workgroup of the fused-horizon kernel: all of it, or (option "lds_limit_kb", sharing rule below) a share
+    // that lets two workgroups of 8 wavefronts live on one CU
+    size_t lds_cap = (size_t)h->lds_limit;
+    if (h->opt_lds_kb > 0 && (size_t)h->opt_lds_kb * 1024 < lds_cap) lds_cap = (size_t)h->opt_lds_kb * 1024;
+    if (share_cu) lds_cap = (size_t)h->lds_limit / 2;
     // choose pairs-per-group G and row chunking for the LDS-resident variant
     bool gs = h->opt_force_global != 0;
     int G = 0, CH = 0, RC = 0;
@@ -260,7 +274,7 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
                 chunking(g);
                 const int wpp = (RC * NCu + 63) / 64;
                 Layout L = make_layout(N, D, A, E, g, DP, wpp, CM, CH, a.H * A, xl != 0);
-                if ((size_t)L.lds_total * 8 <= (size_t)h->lds_limit) {
+                if ((size_t)L.lds_total * 8 <= lds_cap) {
                     G = g; lds_bytes = (size_t)L.lds_total * 8; a.x_in_lds = xl;
                     break;
                 }

@@ -138,7 +138,9 @@ int gpmpc_read_factors(gpmpc_t* h, double* iK_dst_dev, double* beta_dst_dev, voi
  * step, workgroups own 128 x 128 tiles of T_a and loop over candidates; auto: D <= 4, 4 D N^2 >= 6e6, B >= 2 x CUs),
  * "tile_chunk" (candidates per tile workgroup, 0 = chosen to fill the last round), "tile_overlap" (1: point pass on a side
  * stream), "grad_separable" and "grad_tiles" (0 never / 1 auto / 2 always: see gpmpc_rollout_grad).
- * Round 4: "grad_fuse" (1 / 0: gradient launches whose forward takes the batch-major path form the diagonal pairs' tile moments
+ * Round 4: "lds_limit_kb" (LDS budget of a fused-horizon workgroup; with "threads" 512 two workgroups share a CU -- chosen
+ * automatically for 64 < N <= 256 from 8 workgroups per CU on), "prepare_overlap" (1 / 0: inverse chain of the 32-wide panel path
+ * on a side stream), "grad_mean" (1 / 0: mean part of the streaming moment pass by its own kernel), "grad_fuse" (1 / 0: gradient launches whose forward takes the batch-major path form the diagonal pairs' tile moments
  * inside the forward's tile pass). */
 int gpmpc_set_option(gpmpc_t* h, const char* name, long long value);
 
