@@ -1,6 +1,7 @@
 // grad.hip -- host-side dispatch of the analytic-gradient kernels (grad_kernels.h).
 #include "grad_stream_kernel.h"
 #include "grad_sep_kernel.h"
+#include "moment_schedule.h"
 #include <cstring>
 
 namespace gpmpc_hip {
@@ -77,31 +78,35 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
 
     GradArgs g;
     memset(&g, 0, sizeof g);
-    // tiling of the pairwise pass: 64-row chunks, as many output pairs per group as the LDS holds
-    const int CH = (N >= 64) ? 64 : ((N + 3) & ~3);
-    const int RC = (N + CH - 1) / CH;
-    const int NR = RC * CH;
+    // tiling of the pairwise pass: row chunks of CH rows (64 to start with; the LDS-resident pass re-plans with the schedule model's
+    // answer once it is known which pairs it is left with), as many output pairs per group as the LDS holds
     // two columns per lane need > 128 VGPRs, i.e. 8 waves instead of 16 per workgroup: measured slower at config 2
     // (2.86 vs 2.10 ms), so one column unless asked (option "grad_cols_per_lane")
     const int cols = (h->opt_grad_cols == 2) ? 2 : 1;
     const int NCU = (N + cols - 1) / cols;
-    const int wpp = (RC * NCU + 63) / 64;
-    int G = 0;
-    size_t mom_lds = 0;
-    for (int gg = P; gg >= 1; --gg) {
-        const MomLayout L = make_mom_layout(N, D, E, gg, RS, NR, wpp, NSP);
-        if ((size_t)L.total * 8 <= (size_t)h->lds_limit) { G = gg; mom_lds = (size_t)L.total * 8; break; }
-    }
     const int sweep_nt = DP <= 4 ? 64 : 256;
-    // a small batch leaves most CUs idle: spread the pair groups of each (candidate, step) over up to P workgroups
-    int gz = 1;
-    if (G > 0 && (long long)B * H * 2 <= h->num_cu) {
-        int zmax = h->num_cu / (B * H);
-        if (zmax > P) zmax = P;
-        const int Gs = (P + zmax - 1) / zmax;            // pairs per workgroup
-        if (Gs < G) { G = Gs; const MomLayout L = make_mom_layout(N, D, E, G, RS, NR, wpp, NSP); mom_lds = (size_t)L.total * 8; }
-        gz = (P + G - 1) / G;
-    }
+    int CH = 0, RC = 0, NR = 0, wpp = 0, G = 0, gz = 1;
+    size_t mom_lds = 0;
+    auto plan = [&](int chunk_rows) {
+        CH = chunk_rows; RC = (N + CH - 1) / CH; NR = RC * CH;
+        wpp = (RC * NCU + 63) / 64;
+        G = 0; mom_lds = 0; gz = 1;
+        for (int gg = P; gg >= 1; --gg) {
+            const MomLayout L = make_mom_layout(N, D, E, gg, RS, NR, wpp, NSP);
+            if ((size_t)L.total * 8 <= (size_t)h->lds_limit) { G = gg; mom_lds = (size_t)L.total * 8; break; }
+        }
+        // a small batch leaves most CUs idle: spread the pair groups of each (candidate, step) over up to P workgroups
+        if (G > 0 && (long long)B * H * 2 <= h->num_cu) {
+            int zmax = h->num_cu / (B * H);
+            if (zmax > P) zmax = P;
+            const int Gs = (P + zmax - 1) / zmax;            // pairs per workgroup
+            if (Gs < G) { G = Gs; const MomLayout L = make_mom_layout(N, D, E, G, RS, NR, wpp, NSP); mom_lds = (size_t)L.total * 8; }
+            gz = (P + G - 1) / G;
+        }
+        return G > 0 && (unsigned long long)RC * NCU * NCU < 0x100000000ULL && (unsigned long long)G * wpp * wpp < 0x100000000ULL;
+    };
+    const int CH0 = (N >= 64) ? 64 : ((N + 3) & ~3);
+    plan(CH0);
     int pre_steps = 0;
     if (DP <= 4) {               // state-independent small algebra of all steps up front when it fits beside the rest
         const SweepLayout Lp = make_sweep_layout(D, A, E, H, NSP, sweep_nt / 64, 0, H);
@@ -152,9 +157,13 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     g.N = N; g.D = D; g.A = A; g.E = E; g.H = H; g.B = B; g.include_time = a.include_time; g.time0 = a.time0;
     g.grad = grad_out;
     g.DP = DP; g.NXP = NXP; g.NSP = NSP;
-    g.G = G; g.CH = CH; g.RC = RC; g.wpp = wpp; g.gz = gz; g.pre_steps = pre_steps;
+    g.pre_steps = pre_steps;
     g.cols = cols;
-    g.magic_N = magic((unsigned)NCU); g.magic_wpp = magic((unsigned)wpp);
+    auto publish_plan = [&]() {
+        g.G = G; g.CH = CH; g.RC = RC; g.wpp = wpp; g.gz = gz;
+        g.magic_N = magic((unsigned)NCU); g.magic_wpp = magic((unsigned)wpp);
+    };
+    publish_plan();
 
     g.xrange = h->xrange.p; g.force_path = h->opt_force_path;
     // Off-diagonal pairs in separable form on the matrix cores (grad_sep_kernel.h) where the Taylor degree allows; the
@@ -247,13 +256,42 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
             case 6:  rc = launch_moments_stream_dp<6>(h, g, gs_lds, s); break;
             default: rc = launch_moments_stream_dp<8>(h, g, gs_lds, s); break;
         }
-    } else
+    } else {
+        // the pairs this pass is left with (the kernel walks them in a <= b order) decide the row-chunk length: see moment_schedule_cost
+        std::vector<int> pair_is_diag;
+        for (int a1 = 0; a1 < D; ++a1)
+            for (int b1 = a1; b1 < D; ++b1) {
+                const bool dg = (a1 == b1);
+                if (dg ? (h->last_grad_path & 2) != 0 : (h->last_grad_path & 1) != 0) continue;
+                pair_is_diag.push_back(dg ? 1 : 0);
+            }
+        const int NW = (cols == 2) ? kMomThreads / 64 : (DP <= 3 ? 16 : 8);
+        int want = CH0;
+        if (h->opt_grad_chunk > 0) want = h->opt_grad_chunk < CH0 ? h->opt_grad_chunk : CH0;
+        else if (!pair_is_diag.empty()) {
+            int nd = 0;
+            for (int v : pair_is_diag) nd += v;
+            const int key[8] = {N, D, E, cols, NW, (int)(h->lds_limit >> 10), (long long)B * H * 2 <= h->num_cu ? B * H : 0, nd * 64 + (int)pair_is_diag.size() - nd};
+            if (memcmp(key, h->chunk_key, sizeof key) == 0 && h->chunk_rows > 0) want = h->chunk_rows;
+            else {
+                want = choose_moment_chunk(N, cols, NW, CH0, pair_is_diag, [&](int c, int& Gc, int& gzc) {
+                    const bool ok = plan(c);
+                    Gc = G; gzc = gz;
+                    return ok;
+                });
+                memcpy(h->chunk_key, key, sizeof key);
+                h->chunk_rows = want;
+            }
+        }
+        if (!plan(want)) plan(CH0);
+        publish_plan();
     switch (DP) {
         case 2:  rc = launch_moments_dp<2>(h, g, mom_lds, s); break;
         case 3:  rc = launch_moments_dp<3>(h, g, mom_lds, s); break;
         case 4:  rc = launch_moments_dp<4>(h, g, mom_lds, s); break;
         case 6:  rc = launch_moments_dp<6>(h, g, mom_lds, s); break;
         default: rc = launch_moments_dp<8>(h, g, mom_lds, s); break;
+    }
     }
     if (rc) return rc;
     switch (DP) {

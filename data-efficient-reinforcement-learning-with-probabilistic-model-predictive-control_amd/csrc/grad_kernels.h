@@ -391,6 +391,10 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
             const int a = __builtin_amdgcn_readfirstlane(s_pa[q0 + gq]);
             const int b = __builtin_amdgcn_readfirstlane(s_pb[q0 + gq]);
             const bool diag = (a == b);
+            if (diag && slot * 64 >= s_tri[p.RC]) {        // a slot beyond the triangle's tiles (wpp counts those of a full matrix)
+                for (int k = lane; k < NSP; k += 64) s_part[(size_t)wi * NSP + k] = 0.0;
+                continue;
+            }
             const int flat = slot * 64 + lane;
             bool valid;
             int r, jc;
@@ -513,33 +517,53 @@ __global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
 #pragma unroll
                 for (int x = 0; x < NXP; ++x) xb[q][x] = (x < NX && vcol[q]) ? a_xe[x * N + j + q] * c_ils2[b * E + D + x] : 0.0;
             }
-            auto fold = [&](auto f) {             // sum of f(column) * colf over the lane's columns, then over the wave
+            // f(column) * colf summed over the lane's columns, then the NSP lane values over the wavefront: sixteen at a time on the
+            // halving exchange network (wave_reduce16: 57 instructions per 16 values, lane l ends with the total of value l >> 2)
+            // instead of one 6-step butterfly per value -- the fold was a fifth of a 64-row item
+            double* out = s_part + (size_t)wi * NSP;
+            double fv[NSP];
+            auto fold = [&](int slot, auto f) {
                 double v = 0.0;
 #pragma unroll
                 for (int q = 0; q < NC; ++q) v = fma(f(q), colf[q], v);
-                return wave_sum(v);
+                fv[slot] = v;
             };
-            double* out = s_part + (size_t)wi * NSP;
-            {
-                const double v = fold([&](int q) { return cs[q]; });
-                if (lane == 0) out[0] = v;
-            }
+            fold(0, [&](int q) { return cs[q]; });
             int k = 0;
 #pragma unroll
             for (int d = 0; d < DP; ++d) {
-                const double v1 = fold([&](int q) { return h[q][d] + cs[q] * w[q][d]; });
-                if (lane == 0) out[1 + d] = v1;
+                fold(1 + d, [&](int q) { return h[q][d] + cs[q] * w[q][d]; });
 #pragma unroll
                 for (int d2 = d; d2 < DP; ++d2) {
-                    const double s2 = fold([&](int q) { return hh[q][k] + cs[q] * w[q][d] * w[q][d2] + h[q][d] * w[q][d2] + w[q][d] * h[q][d2]; });
-                    if (lane == 0) out[1 + DP + k] = s2;
+                    fold(1 + DP + k, [&](int q) { return hh[q][k] + cs[q] * w[q][d] * w[q][d2] + h[q][d] * w[q][d2] + w[q][d] * h[q][d2]; });
                     ++k;
                 }
             }
 #pragma unroll
-            for (int x = 0; x < NXP; ++x) {
-                const double v = fold([&](int q) { return h[q][DP + x] + cs[q] * xb[q][x]; });
-                if (lane == 0) out[1 + DP + NH + x] = v;
+            for (int x = 0; x < NXP; ++x) fold(1 + DP + NH + x, [&](int q) { return h[q][DP + x] + cs[q] * xb[q][x]; });
+            constexpr int NFG = NSP / 16, NFR = NSP % 16;         // full groups of 16; the rest: one more group, or single sums when it is short
+            if constexpr (NSP <= 8) {
+                double grp[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) grp[e] = (e < NSP) ? fv[e] : 0.0;
+                const double tot = wave_reduce8(grp);
+                if ((lane & 3) == 0 && lane < 32 && (lane >> 2) < NSP) out[lane >> 2] = tot;
+            } else
+#pragma unroll
+            for (int g = 0; g < NFG + ((NFR > 2) ? 1 : 0); ++g) {
+                double grp[16];
+#pragma unroll
+                for (int e = 0; e < 16; ++e) grp[e] = (16 * g + e < NSP) ? fv[16 * g + e] : 0.0;
+                const double tot = wave_reduce16(grp);
+                const int slot = 16 * g + (lane >> 2);
+                if ((lane & 3) == 0 && slot < NSP) out[slot] = tot;
+            }
+            if constexpr (NSP > 8 && NFR > 0 && NFR <= 2) {
+#pragma unroll
+                for (int e = 0; e < NFR; ++e) {
+                    const double tot = wave_sum(fv[16 * NFG + e]);
+                    if (lane == 0) out[16 * NFG + e] = tot;
+                }
             }
         }
         GPMPC_GTRACE(4);

@@ -163,6 +163,34 @@ def test_two_columns_per_lane_variant_agrees(engine):
     assert rel_err(two.cpu().numpy(), one.cpu().numpy()) < 1e-9
 
 
+@pytest.mark.parametrize("N,D,A,H,B,tm,sep", [(50, 3, 1, 4, 3, False, 0), (200, 3, 1, 3, 2, False, 0), (200, 3, 1, 3, 300, False, 1), (131, 2, 2, 3, 2, True, 0),
+                                              (257, 4, 2, 2, 2, False, 0), (90, 6, 2, 3, 2, False, 0), (67, 1, 1, 3, 2, False, 0)])
+def test_row_chunk_length_of_the_moment_pass(engine, N, D, A, H, B, tm, sep):
+    """The LDS-resident moment pass cuts the rows into chunks whose length the host's schedule model chooses (round 4:
+    csrc/moment_schedule.h; 64 rows before).  Every admissible length gives the same moments up to the order of the sums -- several
+    chunks per lane block, ragged last chunks, chunk boundaries inside a wavefront, triangle slots without a valid lane -- and
+    the chosen one is checked against the numpy adjoint (B = 300: the batch that sends the off-diagonal pairs to the matrix cores,
+    config 2's dispatch)."""
+    w = synth.make_workload(N, D, A, H, B, include_time=tm, seed=3 * N + D)
+    f = _load_model(engine, w)
+    auto = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+    assert sep or not engine.last_grad_path & 1
+    for c in (0, B - 1):
+        J, gr, *_ = adjoint.lcb_and_gradient(f, w.actions[c], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
+        assert rel_err(auto["grad"][c].cpu().numpy(), gr) < 1e-7
+    try:
+        for rows in (8, 12, 20, 36, 44, 64):
+            engine.set_option("grad_chunk_rows", rows)
+            got = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+            assert rel_err(got["grad"].cpu().numpy(), auto["grad"].cpu().numpy()) < 1e-10, rows
+            again = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+            assert torch.equal(again["grad"], got["grad"])
+    finally:
+        engine.set_option("grad_chunk_rows", 0)
+    with pytest.raises(Exception):
+        engine.set_option("grad_chunk_rows", 30)
+
+
 @pytest.mark.parametrize("N,D,A,H,B,tm,path", [(30, 3, 1, 5, 3, False, 0), (25, 2, 2, 4, 2, True, 0), (70, 4, 2, 3, 2, False, 0),
                                                (1, 2, 1, 3, 2, False, 0), (65, 1, 1, 4, 2, False, 0), (90, 6, 2, 4, 2, True, 0),
                                                (40, 8, 3, 3, 2, False, 0), (130, 3, 5, 3, 2, True, 0), (200, 3, 1, 6, 3, False, 0),

@@ -500,3 +500,89 @@ def test_lockstep_training_batches_the_gps_and_isolates_a_failing_one():
     for a in range(3):
         assert np.allclose(np.asarray(got[a][gm.GpHyperParameters.KEYS[0]]).ravel(), want[a]["lengthscale"], rtol=1e-5)
         assert abs(float(got[a][gm.GpHyperParameters.KEYS[1]]) - want[a]["outputscale"]) < 1e-5 * want[a]["outputscale"]
+
+
+def _moment_items_by_lane(N, CH, NC, diag):
+    """The lane mapping of pair_moments_kernel (grad_kernels.h: the work-item loop), lane by lane: rows of every work item."""
+    NCU = (N + NC - 1) // NC
+    RC = (N + CH - 1) // CH
+    wpp = (RC * NCU + 63) // 64
+    tri, run = [], 0
+    for r in range(RC + 1):
+        tri.append(run)
+        first = (r * CH) // NC
+        run += NCU - first if first < NCU else 0
+    rows = []
+    for slot in range(wpp):
+        longest = 0
+        for lane in range(64):
+            flat = slot * 64 + lane
+            if diag:
+                if flat >= tri[RC]:
+                    continue
+                r = max(k for k in range(RC) if tri[k] <= flat)
+                jc = (r * CH) // NC + (flat - tri[r])
+            else:
+                if flat >= RC * NCU:
+                    continue
+                r, jc = divmod(flat, NCU)
+            jl = min(NC * jc + NC - 1, N - 1)
+            i0 = r * CH
+            i1 = min(i0 + CH, N)
+            if diag:
+                i1 = min(i1, jl + 1)
+            longest = max(longest, i1 - i0)
+        rows.append((longest + 3) & ~3)
+    return rows
+
+
+def test_moment_pass_schedule_model(tmp_path):
+    """csrc/moment_schedule.h (host-only C++): its work items are those of the kernel's lane mapping, the chosen chunk length is
+    admissible and never worse than the 64-row chunks it replaces, and the small memories get short chunks (config 1 had ONE item
+    per pair with 64-row chunks: 3 of 16 wavefronts busy)."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    csrc = os.path.join(ROOT, "data-efficient-reinforcement-learning-with-probabilistic-model-predictive-control_amd", "csrc")
+    src = tmp_path / "model.cc"
+    src.write_text(r'''
+#include "moment_schedule.h"
+#include <cstdio>
+#include <cstdlib>
+using namespace gpmpc_hip;
+int main(int argc, char** argv) {
+    const int N = atoi(argv[1]), NC = atoi(argv[2]), NW = atoi(argv[3]), G = atoi(argv[4]), nd = atoi(argv[5]), no = atoi(argv[6]), CH = atoi(argv[7]);
+    std::vector<int> pairs;
+    for (int i = 0; i < nd; ++i) pairs.push_back(1);
+    for (int i = 0; i < no; ++i) pairs.push_back(0);
+    const int CH0 = N >= 64 ? 64 : ((N + 3) & ~3);
+    const int want = choose_moment_chunk(N, NC, NW, CH0, pairs, [&](int, int& Gc, int& gz) { Gc = G; gz = 1; return true; });
+    printf("%d %.6f %.6f\n", want, moment_schedule_cost(moment_items(N, NC, want), pairs, G, 1, NW), moment_schedule_cost(moment_items(N, NC, CH0), pairs, G, 1, NW));
+    const MomentItems it = moment_items(N, NC, CH);
+    for (int v : it.diag) printf("%d ", v);
+    printf("\n");
+    for (int v : it.full) printf("%d ", v);
+    printf("\n");
+    return 0;
+}
+''')
+    exe = tmp_path / "model"
+    r = subprocess.run(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-I", csrc, str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    chosen = {}
+    for (N, NC, NW, G, nd, no, CH) in [(50, 1, 16, 3, 3, 0, 8), (200, 1, 16, 3, 3, 0, 40), (200, 1, 16, 6, 3, 3, 52), (500, 1, 16, 2, 2, 0, 56),
+                                       (200, 1, 8, 4, 4, 0, 64), (37, 2, 8, 3, 2, 1, 12), (3, 1, 16, 1, 1, 0, 4), (129, 1, 16, 3, 3, 0, 20)]:
+        r = subprocess.run([str(exe)] + [str(v) for v in (N, NC, NW, G, nd, no, CH)], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 0, r.stderr
+        head, diag, full = r.stdout.strip("\n").split("\n")
+        want, cost, cost0 = head.split()
+        want = int(want)
+        CH0 = 64 if N >= 64 else (N + 3) & ~3
+        assert want % 4 == 0 and (want == CH0 or 8 <= want <= CH0)
+        assert float(cost) <= float(cost0) * (1 + 1e-12)
+        assert [int(v) for v in diag.split()] == _moment_items_by_lane(N, CH, NC, True)
+        assert [int(v) for v in full.split()] == _moment_items_by_lane(N, CH, NC, False)
+        chosen[(N, NW, nd, no)] = want
+    assert chosen[(50, 16, 3, 0)] <= 20           # config 1: several items per pair instead of one
+    assert 36 <= chosen[(200, 16, 3, 0)] <= 48    # config 2 with the off-diagonal pairs on the matrix cores: 30 items for 2 rounds of 16 wavefronts
