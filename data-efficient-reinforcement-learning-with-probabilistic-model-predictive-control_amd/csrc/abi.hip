@@ -107,6 +107,7 @@ int gpmpc_set_option(gpmpc_t* g, const char* name, long long value) {
     else if (!strcmp(name, "cols_per_lane")) h->opt_cols_per_lane = (int)value;
     else if (!strcmp(name, "exact_dim")) h->opt_exact_dim = (int)value;
     else if (!strcmp(name, "grad_cols_per_lane")) h->opt_grad_cols = (int)value;
+    else if (!strcmp(name, "grad_share_cu")) h->opt_grad_share = (int)value;
     else if (!strcmp(name, "grad_chunk_rows")) {
         const int v = (int)value;
         if (v < 0 || v > 64 || (v & 3)) { h->err = "grad_chunk_rows: 0 (auto) or a multiple of 4 up to 64"; return GPMPC_ERR_ARG; }

@@ -143,6 +143,7 @@ struct Handle {
     int opt_force_sep = 0;
     int opt_grad_stream = 0;         // 1: always the streaming moment pass of the gradient (tests); otherwise only when N needs it
     int opt_grad_cols = 0;           // 2: two columns per lane in the gradient's moment pass (A/B)
+    int opt_grad_share = 0;          // moment pass of the gradient, D <= 3: two 512-thread workgroups per CU -- 0 auto (grad.hip), 1 where the LDS fits twice, 2 never
     int opt_grad_chunk = 0;          // rows per work item of the LDS-resident moment pass: 0 = chosen by the schedule model (grad.hip), else fixed (multiple of 4, <= 64)
     int chunk_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the model's last answer: (N, D, E, columns per lane, waves, LDS KiB, small-batch items, pairs left) -> chunk_rows
     int chunk_rows = 0;

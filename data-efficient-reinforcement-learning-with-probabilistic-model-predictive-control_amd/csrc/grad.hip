@@ -12,22 +12,23 @@ constexpr int kMomThreads = 512;
 
 template <int DP, int NXP>
 int launch_moments(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s) {
-    if (g.cols == 2) {
-        // two columns per lane: twice the accumulators, 8 waves per (candidate, step)
-        auto kern = pair_moments_kernel<DP, NXP, kMomThreads, 2>;
+    auto go = [&](auto kern, int nt) -> int {
         int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
         if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3(g.H, g.B, g.gz), dim3(kMomThreads), lds_bytes, s, g);
+        hipLaunchKernelGGL(kern, dim3(g.H, g.B, g.gz), dim3(nt), lds_bytes, s, g);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+        return GPMPC_OK;
+    };
+    // two columns per lane: twice the accumulators, 8 waves per (candidate, step)
+    if (g.cols == 2) return go(pair_moments_kernel<DP, NXP, kMomThreads, 2>, kMomThreads);
+    if constexpr (DP <= 3) {
+        // two 512-thread workgroups per CU (see pair_moments_kernel), or
+        // 16 waves per (candidate, step): the accumulators fit the 128-VGPR budget of a 1024-thread workgroup
+        if (g.share_cu) return go(pair_moments_kernel<DP, NXP, 512, 1>, 512);
+        return go(pair_moments_kernel<DP, NXP, 1024, 1>, 1024);
     } else {
-        // 16 waves per (candidate, step) where the accumulators fit the 128-VGPR budget of a 1024-thread workgroup
-        constexpr int NT = (DP <= 3) ? 1024 : kMomThreads;
-        auto kern = pair_moments_kernel<DP, NXP, NT, 1>;
-        int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
-        if (rc) return rc;
-        hipLaunchKernelGGL(kern, dim3(g.H, g.B, g.gz), dim3(NT), lds_bytes, s, g);
+        return go(pair_moments_kernel<DP, NXP, kMomThreads, 1>, kMomThreads);
     }
-    GPMPC_HIP_CHECK(h, hipGetLastError());
-    return GPMPC_OK;
 }
 
 template <int DP, int NT>
@@ -62,6 +63,13 @@ int launch_moments_dp(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_
     return g.NXP == 2 ? launch_moments<DP, 2>(h, g, lds_bytes, s) : launch_moments<DP, 6>(h, g, lds_bytes, s);
 }
 
+// Two moment-pass workgroups per CU: pays where a (candidate, step) item's serial phases (per-point set-up, reductions, barriers)
+// are a sizeable share of it and there are several items per CU -- set from the measured A/B (tools/gpu_grad_sweep.py).
+bool moments_share_cu_auto(int N, int D, long long B, long long H, int num_cu) {
+    (void)N; (void)D; (void)B; (void)H; (void)num_cu;
+    return false;
+}
+
 }  // namespace
 
 int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t s) {
@@ -87,13 +95,15 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     const int sweep_nt = DP <= 4 ? 64 : 256;
     int CH = 0, RC = 0, NR = 0, wpp = 0, G = 0, gz = 1;
     size_t mom_lds = 0;
+    int pairs_left = P;              // pairs the LDS-resident pass works on (known after the separable / tile passes were dispatched)
+    size_t lds_budget = (size_t)h->lds_limit;
     auto plan = [&](int chunk_rows) {
         CH = chunk_rows; RC = (N + CH - 1) / CH; NR = RC * CH;
         wpp = (RC * NCU + 63) / 64;
         G = 0; mom_lds = 0; gz = 1;
-        for (int gg = P; gg >= 1; --gg) {
+        for (int gg = pairs_left; gg >= 1; --gg) {
             const MomLayout L = make_mom_layout(N, D, E, gg, RS, NR, wpp, NSP);
-            if ((size_t)L.total * 8 <= (size_t)h->lds_limit) { G = gg; mom_lds = (size_t)L.total * 8; break; }
+            if ((size_t)L.total * 8 <= lds_budget) { G = gg; mom_lds = (size_t)L.total * 8; break; }
         }
         // a small batch leaves most CUs idle: spread the pair groups of each (candidate, step) over up to P workgroups
         if (G > 0 && (long long)B * H * 2 <= h->num_cu) {
@@ -265,13 +275,21 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
                 if (dg ? (h->last_grad_path & 2) != 0 : (h->last_grad_path & 1) != 0) continue;
                 pair_is_diag.push_back(dg ? 1 : 0);
             }
-        const int NW = (cols == 2) ? kMomThreads / 64 : (DP <= 3 ? 16 : 8);
+        pairs_left = pair_is_diag.empty() ? 1 : (int)pair_is_diag.size();
+        // two workgroups per CU (option "grad_share_cu": 0 auto, 1 always where it fits, 2 never): half the LDS each
+        bool share = DP <= 3 && cols == 1 && h->opt_grad_share != 2 && (h->opt_grad_share == 1 || moments_share_cu_auto(N, D, B, H, h->num_cu));
+        if (share) {
+            lds_budget = (size_t)h->lds_limit / 2;
+            if (!plan(CH0)) { share = false; lds_budget = (size_t)h->lds_limit; }
+        }
+        g.share_cu = share ? 1 : 0;
+        const int NW = (cols == 2 || share) ? 8 : (DP <= 3 ? 16 : 8);
         int want = CH0;
         if (h->opt_grad_chunk > 0) want = h->opt_grad_chunk < CH0 ? h->opt_grad_chunk : CH0;
         else if (!pair_is_diag.empty()) {
             int nd = 0;
             for (int v : pair_is_diag) nd += v;
-            const int key[8] = {N, D, E, cols, NW, (int)(h->lds_limit >> 10), (long long)B * H * 2 <= h->num_cu ? B * H : 0, nd * 64 + (int)pair_is_diag.size() - nd};
+            const int key[8] = {N, D, E, cols, NW, (int)(lds_budget >> 10), (long long)B * H * 2 <= h->num_cu ? B * H : 0, nd * 64 + (int)pair_is_diag.size() - nd};
             if (memcmp(key, h->chunk_key, sizeof key) == 0 && h->chunk_rows > 0) want = h->chunk_rows;
             else {
                 want = choose_moment_chunk(N, cols, NW, CH0, pair_is_diag, [&](int c, int& Gc, int& gzc) {

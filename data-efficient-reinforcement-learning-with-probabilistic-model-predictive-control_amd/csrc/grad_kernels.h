@@ -48,6 +48,7 @@ struct GradArgs {
     int G, CH, RC, wpp;
     int gz;                 // workgroups per (candidate, step) in the moment pass (pair groups spread over blockIdx.z)
     const int* sepdone;     // (B, H, P) or NULL: 1 = the pair's moments were written by sep_grad_moments_kernel (skip it here)
+    int share_cu;           // 1: launched as two 512-thread workgroups per CU (pair_moments_kernel, D <= 3)
     int mean_done;          // 1: msum was written by mean_moments_kernel (grad_stream_kernel.h): the streaming pass skips its mean part
     unsigned magic_N, magic_wpp;
 };
@@ -114,8 +115,10 @@ __host__ __device__ inline MomLayout make_mom_layout(int N, int D, int E, int G,
 }
 
 // ------------------------------------------------------------------------------------------
+// NT = 512 with one column per lane at D <= 3: the same 128-VGPR code as the 1024-thread workgroup, TWO workgroups per CU (when
+// their LDS fits twice) -- one's per-step set-up and reductions overlap the other's item loop.
 template <int DP, int NXP, int NT, int NC>
-__global__ __launch_bounds__(NT) void pair_moments_kernel(const GradArgs p) {
+__global__ __launch_bounds__(NT, (NT == 512 && NC == 1 && DP <= 3) ? 4 : 1) void pair_moments_kernel(const GradArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NT / kWave;
     constexpr int RS = grad_row_stride(DP, NXP);     // row record: ka'_i, beta_ai, g_i (DP), u_i (DP), nu_ie / l_ae^2 (NXP), pad

@@ -185,8 +185,16 @@ def test_row_chunk_length_of_the_moment_pass(engine, N, D, A, H, B, tm, sep):
             assert rel_err(got["grad"].cpu().numpy(), auto["grad"].cpu().numpy()) < 1e-10, rows
             again = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
             assert torch.equal(again["grad"], got["grad"])
+            if D <= 3:          # two 512-thread workgroups per CU: the same items, the same sums
+                engine.set_option("grad_share_cu", 1)
+                shared = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+                engine.set_option("grad_share_cu", 2)
+                alone = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+                engine.set_option("grad_share_cu", 0)
+                assert torch.equal(shared["grad"], alone["grad"]), rows
     finally:
         engine.set_option("grad_chunk_rows", 0)
+        engine.set_option("grad_share_cu", 0)
     with pytest.raises(Exception):
         engine.set_option("grad_chunk_rows", 30)
 
