@@ -168,7 +168,7 @@ struct Handle {
                                      // of 2.14 + 0.49 ms) but the fp64 pipe is already at the ~76 % of its nominal rate an FMA loop reaches
     int last_rollout_path = 0;       // what the last rollout launch used: 0 fused-horizon kernel, 1 streaming kernel, 2 batch-major tiles
     int last_fused_tiles = 0;        // 1: the last batch-major forward also formed the gradient's tile moments (RolloutArgs::grad_mom)
-    int opt_grad_mean = 1;           // streaming moment pass (D <= 4): the mean part by mean_moments_kernel (lanes over points); 0: inside the pass (A/B)
+    int opt_grad_mean = 1;           // moment pass (D <= 4): the mean part by mean_moments_kernel (lanes over points); 0: inside the pass (A/B, tests)
     int opt_grad_fuse = 1;           // gradient: form the diagonal pairs' tile moments inside the batch-major forward (0: separate pass, A/B)
     int last_grad_path = 0;          // moment passes of the last gpmpc_rollout_grad: bit 0 separable off-diagonal pairs, bit 1 tile moments of
                                      // the diagonal pairs, bit 2 streaming element-wise pass, bit 3 the wide (8 < D <= 16) pass

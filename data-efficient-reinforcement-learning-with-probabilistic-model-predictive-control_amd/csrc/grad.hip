@@ -63,13 +63,6 @@ int launch_moments_dp(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_
     return g.NXP == 2 ? launch_moments<DP, 2>(h, g, lds_bytes, s) : launch_moments<DP, 6>(h, g, lds_bytes, s);
 }
 
-// Two moment-pass workgroups per CU: pays where a (candidate, step) item's serial phases (per-point set-up, reductions, barriers)
-// are a sizeable share of it and there are several items per CU -- set from the measured A/B (tools/gpu_grad_sweep.py).
-bool moments_share_cu_auto(int N, int D, long long B, long long H, int num_cu) {
-    (void)N; (void)D; (void)B; (void)H; (void)num_cu;
-    return false;
-}
-
 }  // namespace
 
 int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t s) {
@@ -97,14 +90,21 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     size_t mom_lds = 0;
     int pairs_left = P;              // pairs the LDS-resident pass works on (known after the separable / tile passes were dispatched)
     size_t lds_budget = (size_t)h->lds_limit;
+    // pairs per group (as many as the LDS budget holds, 0: none) and the LDS bytes for row chunks of `chunk_rows`
+    auto fit = [&](int chunk_rows, int npairs, size_t budget, size_t& bytes) {
+        const int rc_ = (N + chunk_rows - 1) / chunk_rows, nr_ = rc_ * chunk_rows, wpp_ = (rc_ * NCU + 63) / 64;
+        for (int gg = npairs; gg >= 1; --gg) {
+            const MomLayout L = make_mom_layout(N, D, E, gg, RS, nr_, wpp_, NSP);
+            if ((size_t)L.total * 8 <= budget) { bytes = (size_t)L.total * 8; return gg; }
+        }
+        bytes = 0;
+        return 0;
+    };
     auto plan = [&](int chunk_rows) {
         CH = chunk_rows; RC = (N + CH - 1) / CH; NR = RC * CH;
         wpp = (RC * NCU + 63) / 64;
-        G = 0; mom_lds = 0; gz = 1;
-        for (int gg = pairs_left; gg >= 1; --gg) {
-            const MomLayout L = make_mom_layout(N, D, E, gg, RS, NR, wpp, NSP);
-            if ((size_t)L.total * 8 <= lds_budget) { G = gg; mom_lds = (size_t)L.total * 8; break; }
-        }
+        gz = 1;
+        G = fit(CH, pairs_left, lds_budget, mom_lds);
         // a small batch leaves most CUs idle: spread the pair groups of each (candidate, step) over up to P workgroups
         if (G > 0 && (long long)B * H * 2 <= h->num_cu) {
             int zmax = h->num_cu / (B * H);
@@ -243,8 +243,9 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
         if (rc) return rc;
         h->last_grad_path |= 2;
     }
-    if (stream && DP <= 4 && h->opt_grad_mean != 0) {
-        // the mean part on its own, lanes over points (mean_moments_kernel): 22 -> ~1 ms of a config-4 launch
+    if (DP <= 4 && h->opt_grad_mean != 0) {
+        // the mean part on its own, lanes over points (mean_moments_kernel): 22 -> ~1 ms of a config-4 launch (streaming pass); in the
+        // LDS-resident pass it was a quarter of the kernel's time per (candidate, step) at config 2 (profiles/r04j_moment_phases.txt)
         auto launch = [&](auto kern) -> int {
             hipLaunchKernelGGL(kern, dim3(H, B), dim3(64 * DP), 0, s, g);
             GPMPC_HIP_CHECK(h, hipGetLastError());
@@ -267,39 +268,55 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
             default: rc = launch_moments_stream_dp<8>(h, g, gs_lds, s); break;
         }
     } else {
-        // the pairs this pass is left with (the kernel walks them in a <= b order) decide the row-chunk length: see moment_schedule_cost
-        std::vector<int> pair_is_diag;
+        int left = 0;
         for (int a1 = 0; a1 < D; ++a1)
-            for (int b1 = a1; b1 < D; ++b1) {
-                const bool dg = (a1 == b1);
-                if (dg ? (h->last_grad_path & 2) != 0 : (h->last_grad_path & 1) != 0) continue;
-                pair_is_diag.push_back(dg ? 1 : 0);
-            }
-        pairs_left = pair_is_diag.empty() ? 1 : (int)pair_is_diag.size();
-        // two workgroups per CU (option "grad_share_cu": 0 auto, 1 always where it fits, 2 never): half the LDS each
-        bool share = DP <= 3 && cols == 1 && h->opt_grad_share != 2 && (h->opt_grad_share == 1 || moments_share_cu_auto(N, D, B, H, h->num_cu));
+            for (int b1 = a1; b1 < D; ++b1)
+                left += ((a1 == b1) ? (h->last_grad_path & 2) != 0 : (h->last_grad_path & 1) != 0) ? 0 : 1;
+        pairs_left = left > 0 ? left : 1;
+        // Two workgroups per CU, half the LDS each (option "grad_share_cu": 0 auto, 1 wherever it fits, 2 never).  Measured
+        // (profiles/r04j_grad_sweep.txt, objective + gradient per launch): config 2 B = 256 2.04 -> 1.84 ms, B = 1024 7.57 -> 7.01,
+        // config 1 B = 2048 3.58 -> 2.92, config 3 B = 1024 18.2 -> 17.7; nothing at B = 1 -- hence from two workgroups per CU on.
+        bool share = DP <= 3 && cols == 1 && h->opt_grad_share != 2 && (h->opt_grad_share == 1 || (long long)B * H >= 2LL * h->num_cu);
         if (share) {
             lds_budget = (size_t)h->lds_limit / 2;
             if (!plan(CH0)) { share = false; lds_budget = (size_t)h->lds_limit; }
         }
         g.share_cu = share ? 1 : 0;
-        const int NW = (cols == 2 || share) ? 8 : (DP <= 3 ? 16 : 8);
+        // Row-chunk length from the schedule model (moment_schedule.h), as a function of the MODEL'S SHAPE ONLY -- evaluated for the
+        // throughput configuration (the pairs the element-wise pass keeps when the separable pass takes the off-diagonal ones,
+        // two workgroups per CU where they fit, no spreading over blockIdx.z) whatever the batch at hand: every pair's sums are
+        // then formed in the same order for any batch size, grouping and workgroup shape (the lockstep L-BFGS restarts rely on
+        // one candidate's gradient being bit-identical alone and inside a batch).
         int want = CH0;
         if (h->opt_grad_chunk > 0) want = h->opt_grad_chunk < CH0 ? h->opt_grad_chunk : CH0;
-        else if (!pair_is_diag.empty()) {
-            int nd = 0;
-            for (int v : pair_is_diag) nd += v;
-            const int key[8] = {N, D, E, cols, NW, (int)(lds_budget >> 10), (long long)B * H * 2 <= h->num_cu ? B * H : 0, nd * 64 + (int)pair_is_diag.size() - nd};
+        else {
+            const bool sep_shape = h->opt_grad_sep != 0 && N >= 128 && D >= 2 && D <= 4 && h->opt_force_path == 0;
+            std::vector<int> pair_is_diag;
+            for (int a1 = 0; a1 < D; ++a1)
+                for (int b1 = a1; b1 < D; ++b1)
+                    if (a1 == b1 || !sep_shape) pair_is_diag.push_back(a1 == b1 ? 1 : 0);
+            const int npairs = (int)pair_is_diag.size();
+            size_t bytes = 0;
+            const bool two = DP <= 3 && cols == 1 && h->opt_grad_share != 2 && fit(CH0, npairs, (size_t)h->lds_limit / 2, bytes) > 0;
+            const size_t budget = two ? (size_t)h->lds_limit / 2 : (size_t)h->lds_limit;
+            const int NW = (cols == 2 || two) ? 8 : (DP <= 3 ? 16 : 8);
+            const int key[8] = {N, D, E, cols, NW, (int)(budget >> 10), npairs, sep_shape ? 1 : 0};
             if (memcmp(key, h->chunk_key, sizeof key) == 0 && h->chunk_rows > 0) want = h->chunk_rows;
             else {
                 want = choose_moment_chunk(N, cols, NW, CH0, pair_is_diag, [&](int c, int& Gc, int& gzc) {
-                    const bool ok = plan(c);
-                    Gc = G; gzc = gz;
-                    return ok;
+                    size_t bb = 0;
+                    Gc = fit(c, npairs, budget, bb);
+                    gzc = 1;
+                    return Gc > 0;
                 });
                 memcpy(h->chunk_key, key, sizeof key);
                 h->chunk_rows = want;
             }
+        }
+        if (!plan(want) && share) {                 // the chosen chunk does not fit twice: one workgroup per CU rather than another chunk length
+            share = false;
+            g.share_cu = 0;
+            lds_budget = (size_t)h->lds_limit;
         }
         if (!plan(want)) plan(CH0);
         publish_plan();

@@ -198,9 +198,63 @@ __global__ __launch_bounds__(NT, (NT == 512 && NC == 1 && DP <= 3) ? 4 : 1) void
 #define GPMPC_GTRACE(id) do {} while (0)
 #endif
 
+    // Z = R^-1 Sigma of a pair (gp_model.py:156-163) into its augmented block, and the Taylor degree of exp(g . w) from the bound
+    // |g_i . w_j| <= cmax over the data range of the memory points (as in the forward kernel); one thread per pair
+    auto solve_pair = [&](int gq, int q0) {
+        const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
+        double* aug = s_aug + (D + gq) * (D * LD);
+        if constexpr (DP <= 4) {
+            double m[DP][2 * DP];
+#pragma unroll
+            for (int i = 0; i < DP; ++i)
+#pragma unroll
+                for (int j = 0; j < DP; ++j) {
+                    const bool in = (i < D && j < D);
+                    const double sg = in ? s_Sig[i * D + j] : 0.0;
+                    m[i][j] = sg * (in ? c_ils2[a * E + j] + c_ils2[b * E + j] : 0.0) + (i == j ? 1.0 : 0.0);     // R (:156-159)
+                    m[i][DP + j] = sg;
+                }
+            (void)small_solve<DP>(m);                                                       // Z = R^-1 Sigma
+#pragma unroll
+            for (int i = 0; i < DP; ++i)
+#pragma unroll
+                for (int j = 0; j < DP; ++j)
+                    if (i < D && j < D) aug[i * LD + D + j] = m[i][DP + j];
+        } else {
+            for (int i = 0; i < D; ++i)
+                for (int j = 0; j < D; ++j) {
+                    const double dab = c_ils2[a * E + j] + c_ils2[b * E + j];
+                    aug[i * LD + j] = s_Sig[i * D + j] * dab + (i == j ? 1.0 : 0.0);
+                    aug[i * LD + D + j] = s_Sig[i * D + j];
+                }
+            (void)gauss_solve(aug, D, D, LD);
+        }
+        double cmax = 0.0;
+        for (int i = 0; i < D; ++i) {
+            const double ui = fmax(fabs(c_xr[i] - s_m[i]), fabs(c_xr[E + i] - s_m[i])) * c_ils2[a * E + i];
+            for (int j = 0; j < D; ++j) {
+                const double wj = fmax(fabs(c_xr[j] - s_m[j]), fabs(c_xr[E + j] - s_m[j])) * c_ils2[b * E + j];
+                cmax = fma(fabs(aug[i * LD + D + j]) * ui, wj, cmax);
+            }
+        }
+        int K = 0;
+        if (p.force_path != 1 && cmax <= kTaylorMaxArg[kMaxTaylor]) {
+            K = 1;
+            for (int k = 1; k < kMaxTaylor; ++k) K += (cmax > kTaylorMaxArg[k]) ? 1 : 0;
+        }
+        s_K[gq] = K;
+    };
+
+    // Set-up.  The mean part (lb_ai and the third-order moments of nu under it) is formed here only when mean_moments_kernel has
+    // not done it (p.mean_done): 162 wave reductions over LDS-resident points at config 2 -- a quarter of this kernel's time per
+    // (candidate, step), bound by the LDS reads of its products (profiles/r04j_moment_phases.txt).  The small solves of the FIRST
+    // pair group run on wavefront 1 beside the loads and the A_a solves of wavefront 0 instead of as a serial phase of their own.
+    const bool mean_here = !p.mean_done;
+    const int Pn = *s_pn;
+    const int q_first = (int)blockIdx.z * G;
     for (int i = tid; i < D * N; i += NT) a_nu[i] = p.Xt[i] - s_m[i / N];
     for (int i = tid; i < NX * N; i += NT) a_xe[i] = p.Xt[(size_t)D * N + i] - s_m[D + i / N];
-    if (tid < D) {
+    if (mean_here && tid < D) {
         const int a = tid;
         double* aug = s_aug + a * (D * LD);
         if constexpr (DP <= 4) {
@@ -228,98 +282,59 @@ __global__ __launch_bounds__(NT, (NT == 512 && NC == 1 && DP <= 3) ? 4 : 1) void
             (void)gauss_solve(aug, D, D, LD);
         }
     }
+    if (tid >= 64 && tid < 64 + G && q_first + (tid - 64) < Pn) solve_pair(tid - 64, q_first);
+    if (tid == NT - 1) *s_counter = 0;
     __syncthreads();
 
-    // mean part: lb_ai (gp_model.py:148) and its first moments
-    for (int it = tid; it < D * N; it += NT) {
-        const int a = it / N, pt = it - a * N;
-        const double* Ai = s_aug + a * (D * LD) + D;
-        double q = 0.0;
-        for (int i = 0; i < D; ++i) {
-            double r = 0.0;
-            for (int j = 0; j < D; ++j) r = fma(Ai[i * LD + j], a_nu[j * N + pt], r);
-            q = fma(a_nu[i * N + pt], r, q);
+    if (mean_here) {
+        // mean part: lb_ai (gp_model.py:148) and its first moments
+        for (int it = tid; it < D * N; it += NT) {
+            const int a = it / N, pt = it - a * N;
+            const double* Ai = s_aug + a * (D * LD) + D;
+            double q = 0.0;
+            for (int i = 0; i < D; ++i) {
+                double r = 0.0;
+                for (int j = 0; j < D; ++j) r = fma(Ai[i * LD + j], a_nu[j * N + pt], r);
+                q = fma(a_nu[i * N + pt], r, q);
+            }
+            for (int x = 0; x < NX; ++x) {
+                const double v = a_xe[x * N + pt];
+                q = fma(v * v, c_ils2[a * E + D + x], q);
+            }
+            a_lb[it] = exp(-0.5 * q) * p.beta[it];
         }
-        for (int x = 0; x < NX; ++x) {
-            const double v = a_xe[x * N + pt];
-            q = fma(v * v, c_ils2[a * E + D + x], q);
+        __syncthreads();
+        GPMPC_GTRACE(0);
+        // moments of nu under the weights lb_ai up to third order (what the reverse sweep needs of the mean part)
+        const int NM = mean_moment_count(D, NX);
+        for (int task = wave; task < ((blockIdx.z == 0) ? D * NM : 0); task += NW) {
+            const int a = task / NM, comp = task - a * NM;
+            int i1, i2, i3;
+            decode_mean_moment(comp, D, NX, i1, i2, i3);
+            const double* f1 = i1 < 0 ? nullptr : (i1 < D ? a_nu + i1 * N : a_xe + (i1 - D) * N);
+            const double* f2 = i2 < 0 ? nullptr : (i2 < D ? a_nu + i2 * N : a_xe + (i2 - D) * N);
+            const double* f3 = i3 < 0 ? nullptr : (i3 < D ? a_nu + i3 * N : a_xe + (i3 - D) * N);
+            double v = 0.0;
+            if (!f1) { for (int pt = lane; pt < N; pt += 64) v += a_lb[a * N + pt]; }
+            else if (!f2) { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt], f1[pt], v); }
+            else if (!f3) { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt] * f1[pt], f2[pt], v); }
+            else { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt] * f1[pt] * f2[pt], f3[pt], v); }
+            v = wave_sum(v);
+            if (lane == 0) p.msum[(((size_t)c * H + t) * D + a) * NM + comp] = v;
         }
-        a_lb[it] = exp(-0.5 * q) * p.beta[it];
-    }
-    __syncthreads();
-    GPMPC_GTRACE(0);
-    // moments of nu under the weights lb_ai up to third order (what the reverse sweep needs of the mean part)
-    const int NM = mean_moment_count(D, NX);
-    for (int task = wave; task < ((blockIdx.z == 0) ? D * NM : 0); task += NW) {
-        const int a = task / NM, comp = task - a * NM;
-        int i1, i2, i3;
-        decode_mean_moment(comp, D, NX, i1, i2, i3);
-        const double* f1 = i1 < 0 ? nullptr : (i1 < D ? a_nu + i1 * N : a_xe + (i1 - D) * N);
-        const double* f2 = i2 < 0 ? nullptr : (i2 < D ? a_nu + i2 * N : a_xe + (i2 - D) * N);
-        const double* f3 = i3 < 0 ? nullptr : (i3 < D ? a_nu + i3 * N : a_xe + (i3 - D) * N);
-        double v = 0.0;
-        if (!f1) { for (int pt = lane; pt < N; pt += 64) v += a_lb[a * N + pt]; }
-        else if (!f2) { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt], f1[pt], v); }
-        else if (!f3) { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt] * f1[pt], f2[pt], v); }
-        else { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt] * f1[pt] * f2[pt], f3[pt], v); }
-        v = wave_sum(v);
-        if (lane == 0) p.msum[(((size_t)c * H + t) * D + a) * NM + comp] = v;
     }
 
     // small batches: the pair groups of one (candidate, step) are spread over gridDim.z workgroups (each repeats the
     // per-point set-up; the mean moments are written by z = 0)
-    const int Pn = *s_pn;
-    for (int q0 = (int)blockIdx.z * G; q0 < Pn; q0 += G * (int)gridDim.z) {
+    for (int q0 = q_first; q0 < Pn; q0 += G * (int)gridDim.z) {
         const int Gc = (Pn - q0 < G) ? (Pn - q0) : G;
-        if (tid < Gc) {
-            const int gq = tid;
-            const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
-            double* aug = s_aug + (D + gq) * (D * LD);
-            if constexpr (DP <= 4) {
-                double m[DP][2 * DP];
-#pragma unroll
-                for (int i = 0; i < DP; ++i)
-#pragma unroll
-                    for (int j = 0; j < DP; ++j) {
-                        const bool in = (i < D && j < D);
-                        const double sg = in ? s_Sig[i * D + j] : 0.0;
-                        m[i][j] = sg * (in ? c_ils2[a * E + j] + c_ils2[b * E + j] : 0.0) + (i == j ? 1.0 : 0.0);     // R (:156-159)
-                        m[i][DP + j] = sg;
-                    }
-                (void)small_solve<DP>(m);                                                       // Z = R^-1 Sigma
-#pragma unroll
-                for (int i = 0; i < DP; ++i)
-#pragma unroll
-                    for (int j = 0; j < DP; ++j)
-                        if (i < D && j < D) aug[i * LD + D + j] = m[i][DP + j];
-            } else {
-                for (int i = 0; i < D; ++i)
-                    for (int j = 0; j < D; ++j) {
-                        const double dab = c_ils2[a * E + j] + c_ils2[b * E + j];
-                        aug[i * LD + j] = s_Sig[i * D + j] * dab + (i == j ? 1.0 : 0.0);
-                        aug[i * LD + D + j] = s_Sig[i * D + j];
-                    }
-                (void)gauss_solve(aug, D, D, LD);
-            }
-            // |g_i . w_j| <= cmax from the data range of the memory points -> Taylor degree (as in the forward kernel)
-            double cmax = 0.0;
-            for (int i = 0; i < D; ++i) {
-                const double ui = fmax(fabs(c_xr[i] - s_m[i]), fabs(c_xr[E + i] - s_m[i])) * c_ils2[a * E + i];
-                for (int j = 0; j < D; ++j) {
-                    const double wj = fmax(fabs(c_xr[j] - s_m[j]), fabs(c_xr[E + j] - s_m[j])) * c_ils2[b * E + j];
-                    cmax = fma(fabs(aug[i * LD + D + j]) * ui, wj, cmax);
-                }
-            }
-            int K = 0;
-            if (p.force_path != 1 && cmax <= kTaylorMaxArg[kMaxTaylor]) {
-                K = 1;
-                for (int k = 1; k < kMaxTaylor; ++k) K += (cmax > kTaylorMaxArg[k]) ? 1 : 0;
-            }
-            s_K[gq] = K;
+        if (q0 != q_first) {                       // later groups: their small solves as a phase of their own
+            if (tid < Gc) solve_pair(tid, q0);
+            if (tid == NT - 1) *s_counter = 0;
+            __syncthreads();
         }
-        if (tid == NT - 1) *s_counter = 0;
-        __syncthreads();
         GPMPC_GTRACE(2);
+
 
         for (int it = tid; it < Gc * N; it += NT) {
             const int gq = it / N, pt = it - gq * N;

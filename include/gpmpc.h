@@ -140,7 +140,7 @@ int gpmpc_read_factors(gpmpc_t* h, double* iK_dst_dev, double* beta_dst_dev, voi
  * stream), "grad_separable" and "grad_tiles" (0 never / 1 auto / 2 always: see gpmpc_rollout_grad).
  * Round 4: "lds_limit_kb" (LDS budget of a fused-horizon workgroup; with "threads" 512 two workgroups share a CU -- chosen
  * automatically for 64 < N <= 256 from 8 workgroups per CU on), "prepare_overlap" (1 / 0: inverse chain of the 32-wide panel path
- * on a side stream), "grad_mean" (1 / 0: mean part of the streaming moment pass by its own kernel), "grad_fuse" (1 / 0: gradient launches whose forward takes the batch-major path form the diagonal pairs' tile moments
+ * on a side stream), "grad_mean" (1 / 0: mean part of the moment pass by its own kernel, D <= 4), "grad_fuse" (1 / 0: gradient launches whose forward takes the batch-major path form the diagonal pairs' tile moments
  * inside the forward's tile pass), "grad_chunk_rows" (rows per work item of the LDS-resident moment pass: 0 = chosen by the host's
  * schedule model, csrc/moment_schedule.h; else a multiple of 4 up to 64 -- GPMPC_ERR_ARG otherwise), "grad_share_cu" (that pass
  * at D <= 3 as two 512-thread workgroups per CU: 0 auto / 1 where the LDS fits twice / 2 never). */

@@ -178,7 +178,13 @@ def test_row_chunk_length_of_the_moment_pass(engine, N, D, A, H, B, tm, sep):
     for c in (0, B - 1):
         J, gr, *_ = adjoint.lcb_and_gradient(f, w.actions[c], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
         assert rel_err(auto["grad"][c].cpu().numpy(), gr) < 1e-7
+    assert bool(engine.last_grad_path & 32) == (D <= 4)               # the mean part by mean_moments_kernel (lanes over points)
     try:
+        engine.set_option("grad_mean", 0)                             # ... and inside the pass (what D > 4 takes)
+        inpass = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+        assert not engine.last_grad_path & 32
+        assert rel_err(inpass["grad"].cpu().numpy(), auto["grad"].cpu().numpy()) < 1e-10
+        engine.set_option("grad_mean", 1)
         for rows in (8, 12, 20, 36, 44, 64):
             engine.set_option("grad_chunk_rows", rows)
             got = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
@@ -195,6 +201,7 @@ def test_row_chunk_length_of_the_moment_pass(engine, N, D, A, H, B, tm, sep):
     finally:
         engine.set_option("grad_chunk_rows", 0)
         engine.set_option("grad_share_cu", 0)
+        engine.set_option("grad_mean", 1)
     with pytest.raises(Exception):
         engine.set_option("grad_chunk_rows", 30)
 
