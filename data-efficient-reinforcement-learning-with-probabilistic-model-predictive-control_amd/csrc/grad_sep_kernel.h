@@ -215,7 +215,12 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
 
     // ---- tasks (off-diagonal pair, side): two rounds of wavefronts per pair pair, then the combination ----------------
     for (int pq0 = 0; pq0 < Poff; pq0 += NW / 2) {
-        const int pq = pq0 + (wave >> 1), side = wave & 1;
+        // D = 3: three pairs for two pairs of wavefronts -- in the second round BOTH pairs of wavefronts take the last pair, each one
+        // half of its point chunks (the moment matrices are sums over points: the halves are added before the combination),
+        // instead of one pair of wavefronts idling through it
+        const bool split = sep_grad_version(DP) == 1 && NW == 4 && Poff - pq0 == 1;
+        const int half = split ? (wave >> 1) : 0;
+        const int pq = split ? pq0 : pq0 + (wave >> 1), side = wave & 1;
         const bool active = pq < Poff && s_K[pq < Poff ? pq : 0] > 0;
         const int K = active ? s_K[pq] : 0;
         const int C = p.mono_cum[K];
@@ -259,7 +264,10 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
             for (int e = 0; e < NE; ++e)
 #pragma unroll
                 for (int ib = 0; ib < NB; ++ib) accE[e][ib] = 0.0;
-            for (int c0 = 0; c0 < N; c0 += 64) {
+            const int nch = (N + 63) >> 6, nch0 = (nch + 1) >> 1;
+            const int c_lo = split ? half * nch0 * 64 : 0;
+            const int c_hi = (split && half == 0) ? (nch0 * 64 < N ? nch0 * 64 : N) : N;
+            for (int c0 = c_lo; c0 < c_hi; c0 += 64) {
                 // -- per-point tables (lane = point) --
                 {
                     const int pt0 = c0 + lane;
@@ -572,8 +580,17 @@ __global__ __launch_bounds__(64 * sep_grad_waves(DP), DP <= 3 ? 3 : 2) void sep_
                     }
         }
         __syncthreads();
+        if (split && active) {                       // (uniform over the workgroup: all four wavefronts worked on pair pq0)
+            const int nmat = nW * 16 * NB;
+            for (int idx = tid; idx < 2 * nmat; idx += NT) {
+                const int sd = idx >= nmat ? 1 : 0, k = idx - sd * nmat;
+                double* dst = s_wave + (size_t)sd * p.wave_words;
+                dst[k] += dst[(size_t)2 * p.wave_words + k];
+            }
+            __syncthreads();
+        }
         // ---- combination: the two wavefronts of a pair share the outputs (side 0 wave: even outputs, side 1: odd) --------
-        if (active) {
+        if (active && half == 0) {
             const int qf = s_q[pq];
             int a = 0, rem = qf;
             while (rem >= D - a) { rem -= D - a; ++a; }
