@@ -12,6 +12,8 @@ bash tools/gpu_counters.sh r04z_c2 c2:N200:B256 rollout_kernel --workload c2 2>&
 bash tools/gpu_counters.sh r04z_c1 c1:N50:B256 rollout_kernel --workload c1 2>&1 | tail -1
 bash tools/gpu_counters.sh r04z_c3 c3:N500:B1024 rollout_kernel --workload c3 2>&1 | tail -1
 bash tools/gpu_counters.sh r04z_c4 c4:N1000:B2048 "pair_tile_kernel*30,point_pass_kernel*30,step_params_kernel*30,step_combine_kernel*30" --workload c4 2>&1 | tail -1
+# config 5: one 28 s launch per step -- the four passes the bench line's counter figures need (traffic, VALU, fp64 / matrix ops), three launches each
+PMC_GROUPS="0 1 2 4" SKIP_TRACE=1 PMC_RUN="--steps 1 --warmup 0 --no-gradient" PASS_LIMIT=400 bash tools/gpu_counters.sh r04z_c5 c5:N4096:B256 rollout_stream_kernel --workload c5 --candidates-total 256 2>&1 | tail -1
 timeout 600 python bench.py > $OUT/r04z_c2_bench.json 2> $OUT/r04z_c2_bench.err
 timeout 600 python bench.py --workload c1 > $OUT/r04z_c1_bench.json 2> $OUT/r04z_c1_bench.err
 timeout 600 python bench.py --workload c3 > $OUT/r04z_c3_bench.json 2> $OUT/r04z_c3_bench.err
