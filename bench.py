@@ -76,6 +76,66 @@ def algorithmic_bytes_per_rollout(N, D, E, H):
     return H * 8 * (D * N * N + N * E + 2 * D * N)
 
 
+def counter_figures(workload, N, Bg, kernel_ms, build_id):
+    """Counter-derived figures of a launch shape, collected with rocprofv3 --pmc in separate passes
+    (tools/gpu_counters.sh -> profiles/pmc_traffic.json, profiles/pmc_counters.json): traffic, the counters themselves, a note when
+    they belong to another build, the pipe-occupancy figure and the executed-flop view.  A pure function of the kernel time and the
+    counter files (also behind --refresh-line)."""
+    traffic, counters, counters_note = None, None, None
+    key = f"{workload}:N{N}:B{Bg}"
+    for fname in ("pmc_traffic.json", "pmc_counters.json"):
+        try:
+            val = json.load(open(os.path.join(ROOT, "profiles", fname))).get(key)
+        except Exception:
+            val = None
+        # counter files name the build they were collected on (gpmpc_build_id); figures of another build are not reported
+        bid = val.get("_build_id" if fname == "pmc_counters.json" else "build_id") if isinstance(val, dict) else None
+        if val is not None and bid != build_id:
+            counters_note = (f"profiles/{fname}[{key}] was collected on build {bid}, the loaded library is {build_id}: "
+                             "counter-derived figures withheld (re-run tools/gpu_counters.sh)")
+            val = None
+        if fname == "pmc_traffic.json":
+            traffic = val["bytes"] if isinstance(val, dict) else val
+        else:
+            counters = val
+    valu_busy, executed = None, None
+    # SQ_INSTS_VALU_MFMA_MOPS_F64 counts 4 per v_mfma_f64_16x16x4_f64 (256 multiply-adds per count) and SQ_INSTS_VALU includes the
+    # matrix instructions: calibrated on the pure-MFMA probe, profiles/r04z_mfma_mops_unit.txt (SQ_INSTS_MFMA 25 728 000,
+    # MOPS 102 912 000, SQ_INSTS_VALU 25 786 881, SQ_VALU_MFMA_BUSY_CYCLES = 64 per instruction)
+    n_mfma = 0.25 * counters.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0) if counters else 0.0
+    if counters and counters.get("SQ_INSTS_VALU"):
+        # a wave64 fp64 VALU instruction occupies its SIMD's 16 lanes for 4 cycles, an fp64 16x16x4 matrix instruction the same
+        # pipe for 64; 1024 SIMDs
+        valu_busy = ((counters["SQ_INSTS_VALU"] - n_mfma) * 4.0 + n_mfma * 64.0) / (1024.0 * kernel_ms * 1e-3 * NOMINAL_CLOCK_GHZ * 1e9)
+    if counters and counters.get("SQ_INSTS_VALU_FMA_F64") is not None:
+        # fp64 operations the SIMDs actually issued (wave-instructions x 64 lanes; FMA = 2 flop; the f64 matrix counter is
+        # in units of 256 multiply-adds, see above -- until round 4 this line priced it at 512, unnoticed because no bench
+        # line of a matrix-core kernel had counters): the EXECUTED-flop roofline beside the algorithmic one
+        flops = 64.0 * (counters.get("SQ_INSTS_VALU_ADD_F64", 0.0) + counters.get("SQ_INSTS_VALU_MUL_F64", 0.0)
+                        + 2.0 * counters["SQ_INSTS_VALU_FMA_F64"]) + 512.0 * counters.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
+        executed = {"fp64_flops_per_launch": flops, "tflops": flops / (kernel_ms * 1e-3) / 1e12,
+                    "frac_of_peak": flops / (kernel_ms * 1e-3) / 1e12 / PEAK_F64_VECTOR_TFLOPS,
+                    "note": "64 x (ADD_F64 + MUL_F64 + 2 FMA_F64) + 512 x MFMA_MOPS_F64 from the SQ counters of this build; "
+                            "lanes switched off by the exec mask are counted (upper bound of useful work)"}
+    return traffic, counters, counters_note, valu_busy, executed
+
+
+def refresh_line(path):
+    """--refresh-line: the counter-derived fields of a stored bench line recomputed from profiles/pmc_*.json with the functions above
+    (the counters of a shape are collected AFTER its line when a launch is long: config 5).  Nothing measured is touched."""
+    d = json.load(open(path))
+    c, r = d["config"], d["roofline"]
+    workload = c["workload"].split(":")[0]
+    traffic, counters, note, valu_busy, executed = counter_figures(workload, c["N"], c["B_per_gpu"], r["kernel_ms"], r["build_id"])
+    r.update({"traffic": traffic, "counters": counters, "counters_note": note, "valu_busy_frac": valu_busy, "executed": executed,
+              "traffic_gbps": None if not traffic else traffic / (r["kernel_ms"] * 1e-3) / 1e9,
+              "traffic_frac_of_hbm_peak": None if not traffic else traffic / (r["kernel_ms"] * 1e-3) / 1e9 / 8000.0,
+              "counters_refreshed": "counter-derived fields recomputed by `bench.py --refresh-line` from profiles/pmc_counters.json / "
+                                    "pmc_traffic.json (same build id); every measured field is as the run printed it"})
+    json.dump(d, open(path, "w"))
+    print(json.dumps(d))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,6 +149,8 @@ def main():
     ap.add_argument("--points", type=int, default=0, help="override N")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gradient", action="store_true", help="skip the objective + gradient leg (config 5: ~2 minutes per launch)")
+    ap.add_argument("--refresh-line", default=None, metavar="JSON",
+                    help="no run: recompute the counter-derived fields of a stored bench line from profiles/pmc_*.json (no GPU needed)")
     ap.add_argument("--force-dist", action="store_true", help="initialise RCCL even with one rank (exercises the N > 1 code path)")
     ap.add_argument("--exchange", default="rccl_side", choices=["rccl_side", "host", "rccl"],
                     help="N > 1: how the per-rank winner records meet -- 'rccl_side' (default): one RCCL all_gather per step over xGMI "
@@ -98,6 +160,9 @@ def main():
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option for an A/B run (gpmpc_set_option; recorded in config.engine_options)")
     args = ap.parse_args()
+    if args.refresh_line:
+        refresh_line(args.refresh_line)
+        return
 
     # Exactly ONE line goes to stdout: native libraries (RCCL prints a version banner to fd 1 when its communicator comes up)
     # are pointed at stderr for the duration of the run; the JSON line is printed after stdout has been restored.
@@ -313,39 +378,8 @@ def main():
     if rank == 0:
         flops_launch = algorithmic_flops_per_rollout(N, D, A, E, H) * Bg
         achieved_tflops = flops_launch / (kernel_ms * 1e-3) / 1e12
-        # counter-derived figures of the same launch shape, collected with rocprofv3 --pmc in separate passes
-        # (tools/gpu_counters.sh -> profiles/pmc_traffic.json, profiles/pmc_counters.json)
-        traffic, counters, counters_note = None, None, None
-        key = f"{args.workload}:N{N}:B{Bg}"
-        for fname in ("pmc_traffic.json", "pmc_counters.json"):
-            try:
-                val = json.load(open(os.path.join(ROOT, "profiles", fname))).get(key)
-            except Exception:
-                val = None
-            # counter files name the build they were collected on (gpmpc_build_id); figures of another build are not reported
-            bid = val.get("_build_id" if fname == "pmc_counters.json" else "build_id") if isinstance(val, dict) else None
-            if val is not None and bid != build_id:
-                counters_note = (f"profiles/{fname}[{key}] was collected on build {bid}, the loaded library is {build_id}: "
-                                 "counter-derived figures withheld (re-run tools/gpu_counters.sh)")
-                val = None
-            if fname == "pmc_traffic.json":
-                traffic = val["bytes"] if isinstance(val, dict) else val
-            else:
-                counters = val
+        traffic, counters, counters_note, valu_busy, executed = counter_figures(args.workload, N, Bg, kernel_ms, build_id)
         fma_peak, fma_src = measured_fma_loop_peak()
-        valu_busy, executed = None, None
-        if counters and counters.get("SQ_INSTS_VALU"):
-            # a wave64 fp64 VALU instruction occupies its SIMD's 16 lanes for 4 cycles; 1024 SIMDs
-            valu_busy = counters["SQ_INSTS_VALU"] * 4.0 / (1024.0 * kernel_ms * 1e-3 * NOMINAL_CLOCK_GHZ * 1e9)
-        if counters and counters.get("SQ_INSTS_VALU_FMA_F64") is not None:
-            # fp64 operations the SIMDs actually issued (wave-instructions x 64 lanes; FMA = 2 flop; the f64 matrix counter is
-            # in units of 512 multiply-adds): the EXECUTED-flop roofline beside the algorithmic one
-            flops = 64.0 * (counters.get("SQ_INSTS_VALU_ADD_F64", 0.0) + counters.get("SQ_INSTS_VALU_MUL_F64", 0.0)
-                            + 2.0 * counters["SQ_INSTS_VALU_FMA_F64"]) + 1024.0 * counters.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0.0)
-            executed = {"fp64_flops_per_launch": flops, "tflops": flops / (kernel_ms * 1e-3) / 1e12,
-                        "frac_of_peak": flops / (kernel_ms * 1e-3) / 1e12 / PEAK_F64_VECTOR_TFLOPS,
-                        "note": "64 x (ADD_F64 + MUL_F64 + 2 FMA_F64) + 1024 x MFMA_MOPS_F64 from the SQ counters of this build; "
-                                "lanes switched off by the exec mask are counted (upper bound of useful work)"}
         result = {
             "metric": "MPC trajectory rollouts/sec",
             "value": B_total * args.steps / elapsed,
@@ -399,7 +433,7 @@ def main():
                                  "HIP-event kernel time / nominal peak: an algorithmic figure -- the kernel executes fewer "
                                  "instructions than that formulation (Taylor instead of exp, triangle-only diagonal pairs, "
                                  "separable off-diagonal pairs), so it can exceed what a direct evaluation could reach; "
-                                 "valu_busy_frac = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles at 2.4 GHz) is the "
+                                 "valu_busy_frac = (vector instructions x 4 + fp64 matrix instructions x 64 cycles) / (1024 SIMDs x kernel cycles at 2.4 GHz) is the "
                                  "hardware-utilisation view of the same launch (null until the counters of this build and "
                                  "shape are under profiles/); bound is fp64 VALU, not HBM, while the tables T_a are L2-resident "
                                  "(c1-c3: traffic_frac_of_hbm_peak ~ 0); at c4 (D N^2 / 2 x 8 B = 16 MB of T_a per candidate and "
