@@ -444,6 +444,40 @@ def test_committed_bench_line_has_the_contract_fields():
     assert d5["scaling"] == "strong" and d5["cpu_baseline"].get("extrapolated") is True and d5["config"]["N"] == 4096
 
 
+def test_counter_derived_fields_of_the_round4_lines(tmp_path):
+    """The counter-derived fields of a bench line are a pure function of the kernel time and profiles/pmc_*.json
+    (bench.counter_figures): `bench.py --refresh-line` on a copy of the stored config-5 line reproduces them, the pipe occupancy
+    prices a matrix instruction at 64 cycles and the executed flops at 256 multiply-adds per SQ_INSTS_VALU_MFMA_MOPS_F64 count
+    (profiles/r04z_mfma_mops_unit.txt: 4 counts per v_mfma_f64_16x16x4_f64) -- nothing may execute more than the peak."""
+    import json
+    import shutil
+    import subprocess
+    import sys
+    for name in ("r04z_c5_bench_B256.json", "r04z_c2_bench.json", "r04z_c4_bench.json"):
+        src = os.path.join(ROOT, "profiles", name)
+        stored = json.loads(open(src).read().strip().splitlines()[-1])
+        cp = tmp_path / name
+        shutil.copy(src, cp)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--refresh-line", str(cp)], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        got = json.load(open(cp))
+        a, b = stored["roofline"], got["roofline"]
+        assert b["counters_note"] is None and b["build_id"] == a["build_id"] == b["counters"]["_build_id"]
+        assert 0.3 < b["valu_busy_frac"] < 1.0 and 0.1 < b["executed"]["frac_of_peak"] < 1.0
+        for k in ("kernel_ms", "frac", "achieved"):
+            assert a[k] == b[k]
+        assert stored["value"] == got["value"] and stored["gradient"] == got["gradient"]
+        if name.startswith("r04z_c5"):            # the stored line already went through the refresh: idempotent
+            assert abs(a["valu_busy_frac"] - b["valu_busy_frac"]) < 1e-12 and a["executed"] == b["executed"]
+            c = b["counters"]
+            n_mfma = 0.25 * c["SQ_INSTS_VALU_MFMA_MOPS_F64"]
+            want = ((c["SQ_INSTS_VALU"] - n_mfma) * 4 + n_mfma * 64) / (1024 * b["kernel_ms"] * 1e-3 * 2.4e9)
+            assert abs(b["valu_busy_frac"] - want) < 1e-12 and 0.7 < want < 0.8
+        else:                                     # no matrix instructions in the fused-horizon / batch-major forward: unchanged by the unit
+            assert abs(a["valu_busy_frac"] - b["valu_busy_frac"]) < 1e-12
+            assert abs(a["executed"]["frac_of_peak"] - b["executed"]["frac_of_peak"]) < 1e-12
+
+
 def test_lockstep_training_batches_the_gps_and_isolates_a_failing_one():
     """GpStateTransitionModel.train with a device loss: the D per-GP LBFGS searches run as threads and every round of
     pending evaluations is ONE engine.mll call over the waiting GPs (reference: GP after GP, gp_model.py:233-290).  A fake
