@@ -312,7 +312,11 @@ def memory_trace_case(name, seed, D, A, include_time, n_add, prepare_every, thre
              prepare_every=np.array(prepare_every), states=states, actions=acts, states_next=nxt, rewards=rewards,
              predicted=pred, predicted_std=std, has_pred=has_pred, has_std=has_std,
              empty_x=x0.numpy(), empty_y=y0.numpy(),
-             admitted=np.array(mem.active_data_mask[:n_add], dtype=bool), errors=mem.errors[:n_add].numpy(), stds=mem.stds[:n_add].numpy(),
+             admitted=np.array(mem.active_data_mask[:n_add], dtype=bool),
+             # check_errors_for_storage = False: the reference never writes these rows (torch.empty: whatever the allocator held) -- NaN here,
+             # so that the fixture regenerates bit for bit; the test compares them only for the checked traces
+             errors=mem.errors[:n_add].numpy() if check else np.full((n_add, D), np.nan),
+             stds=mem.stds[:n_add].numpy() if check else np.full((n_add, D), np.nan),
              inputs=mem.inputs[:n_add].numpy(), iter_ctrls=mem.iter_ctrls[:n_add].numpy(),
              snap_len=np.array(snap_len), final_x=get_x[-1], final_y=get_y[-1],
              snap_first_x=get_x[0], snap_first_y=get_y[0],
