@@ -10,6 +10,10 @@ outputs are stored.
                                                              (round 3; ~ an hour on 8 cores: run it in the background)
   python tools/gen_golden_c5.py --inrange --steps 20 --candidates 4   contracting targets + dense Sigma_0: the state stays inside
                                                              the memory's range over the horizon -> oracle_c5_inrange.npz (round 4)
+
+Reproducibility (checked in a scratch copy, round 4): the one-step fixture regenerates bit for bit; the 20-step in-range fixture to
+6e-13 (means) / 5e-12 (covariances) -- the oracle's matrix products run on a threaded BLAS whose summation order depends on the
+threads it gets, and twenty moment-matched steps carry that forward.  The GPU tests compare at 1e-9 and looser.
 """
 import argparse
 import os
