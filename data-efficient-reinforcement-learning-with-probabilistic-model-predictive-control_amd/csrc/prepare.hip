@@ -478,6 +478,91 @@ __global__ __launch_bounds__(256) void syrk_trailing_kernel(double* __restrict__
     }
 }
 
+// Trailing update of panel k FUSED with the factorisation of panel k + 1's diagonal block (32-wide path, round 5 staging): the
+// workgroup that owns trailing tile (0, 0) -- rows / columns [k0 + nb, k0 + nb + 32): exactly the next diagonal block -- keeps its
+// updated block in LDS instead of writing it back and runs potrf_diag_fast_kernel's register pivot loop on it (all 1024 threads; in
+// the other workgroups wavefronts 4 .. 15 leave at once).  One launch and one dependent launch gap less per panel, and the
+// factorisation of the next block no longer waits for the slowest trailing tile.
+__global__ __launch_bounds__(NB * NB) void syrk_trailing_potrf_kernel(double* __restrict__ Kall, double* __restrict__ Yall,
+                                                                     int N, int k0, int nb, int* __restrict__ info) {
+    __shared__ double blk[NB][NB + 1];
+    __shared__ double colb[2][2 * NB];
+    __shared__ double sinv[NB];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    const int a = blockIdx.z;
+    double* K = Kall + (size_t)a * N * N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool special = (ti == 0 && tj == 0);
+    if (!special && wave >= 4) return;
+    const int r0 = k0 + nb;
+    if (wave < 4) {
+        const int i0 = r0 + ti * 32 + (wave >> 1) * 16;
+        const int j0 = r0 + tj * 32 + (wave & 1) * 16;
+        if (j0 <= i0 + 15) {
+            const int li = lane & 15, lk = lane >> 4;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const int ri = i0 + li, rj = j0 + li;
+            const double* Ar = K + (size_t)(ri < N ? ri : N - 1) * N + k0;
+            const double* Br = K + (size_t)(rj < N ? rj : N - 1) * N + k0;
+            double cold[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                            // the old values travel while the products are formed
+                const int row = i0 + lk + 4 * r, col = j0 + li;
+                cold[r] = (row < N && col <= row) ? K[(size_t)row * N + col] : 0.0;
+            }
+            mfma_kloop<8>(acc, 0, nb, lk, [&](int k) { return ri < N ? Ar[k] : 0.0; }, [&](int k) { return rj < N ? Br[k] : 0.0; });
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + lk + 4 * r, col = j0 + li;
+                if (row < N && col <= row) {
+                    if (special) blk[row - r0][col - r0] = cold[r] - acc[r];
+                    else K[(size_t)row * N + col] = cold[r] - acc[r];
+                }
+            }
+        }
+    }
+    if (!special) return;
+    __syncthreads();
+    // ---- the next panel's diagonal block: potrf_diag_fast_kernel's pivot loop on the block in LDS -----------------------------
+    double* Y = Yall + (size_t)a * N * N;
+    const int nb2 = (N - r0 < NB) ? (N - r0) : NB;
+    const int c = tid >> 5, r = tid & 31;                    // column-major over the wavefronts: wave w <-> columns 2w, 2w + 1
+    double a0 = (r < nb2 && c < nb2 && c <= r) ? blk[r][c] : 0.0;
+    double a1 = (r == c) ? 1.0 : 0.0;
+    if (c == 0) { colb[0][r] = a0; colb[0][NB + r] = a1; }
+    if (tid == 0) {
+        if (!(a0 > 0.0) && info[a] == 0) info[a] = r0 + 1;
+        sinv[0] = inv_sqrt_pos_p(a0);
+    }
+    if (tid >= nb2 && tid < NB) sinv[tid] = 0.0;
+    __syncthreads();
+    for (int k = 0; k + 1 < nb2; ++k) {
+        if (2 * wave + 1 > k) {                              // wave-uniform: both columns of a finished wave are final
+            const double* cb = colb[k & 1];
+            double* cn = colb[(k + 1) & 1];
+            const double inv = sinv[k];
+            if (c > k && c < nb2) {
+                const double lc = cb[c] * inv;
+                a0 = fma(-(cb[r] * inv), lc, a0);
+                a1 = fma(-(cb[NB + r] * inv), lc, a1);
+                if (c == k + 1) {
+                    cn[r] = a0;
+                    cn[NB + r] = a1;
+                    if (r == k + 1) {
+                        if (!(a0 > 0.0) && info[a] == 0) info[a] = r0 + k + 2;
+                        sinv[k + 1] = inv_sqrt_pos_p(a0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const double sc = sinv[c];                               // 0 for c >= nb2
+    if (r < nb2 && c <= r) K[(size_t)(r0 + r) * N + r0 + c] = a0 * sc;
+    if (r < nb2 && c < nb2) Y[(size_t)(r0 + c) * N + r0 + r] = (r <= c) ? a1 * sc : 0.0;       // row r of the identity -> column r of Y11
+}
+
 // Row block k of Y = L^-1:  Y[k, c] = -Ykk * (sum_p L[k, p] Y[p, c]) for column tiles c < k0.
 // blocks > 0: one launch for ALL outer blocks of `blocks` rows (blockIdx.z = outer block K): row block k0 = K + koff of
 // each, columns [K, k0) only -- the diagonal blocks Y_KK of the recursive-doubling inverse below.
@@ -1166,7 +1251,10 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
             // with a rank-32 update of the rest of the outer panel per step)
             const bool ll = OW && h->opt_inner_left != 0;
             const int left = ll ? k0 % OW : 0;
-            if (fast) hipLaunchKernelGGL(potrf_diag_fast_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info, left);
+            // 32-wide path: from the second panel on the diagonal block was factorised by the previous panel's fused trailing update
+            const bool fuse_next = fast && !OW && h->opt_prepare_fuse != 0;
+            if (fuse_next && k0 > 0) { /* done by syrk_trailing_potrf_kernel of the panel before */ }
+            else if (fast) hipLaunchKernelGGL(potrf_diag_fast_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info, left);
             else hipLaunchKernelGGL(potrf_diag_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
             if (overlap_inv && k0 > 0) {
                 // rows <= k of L and Y_kk are final: row block k of the inverse starts now, beside this step's solve and update
@@ -1183,8 +1271,10 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
                 if (OW) { cend = (k0 / OW + 1) * OW; if (cend > N) cend = N; }
                 const int nt = (M + 31) / 32;
                 const int ntx = (cend - (k0 + nb) + 31) / 32;
-                if (ntx > 0 && !ll)
-                    hipLaunchKernelGGL(syrk_trailing_kernel, dim3(ntx < nt ? ntx : nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb, cend);
+                if (ntx > 0 && !ll) {
+                    if (fuse_next) hipLaunchKernelGGL(syrk_trailing_potrf_kernel, dim3(nt, nt, D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
+                    else hipLaunchKernelGGL(syrk_trailing_kernel, dim3(ntx < nt ? ntx : nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb, cend);
+                }
                 if (OW && k0 + nb == cend && cend < N) {             // outer panel [cend - OW, cend) complete: rank-OW update of the rest
                     if (tile128) {
                         if ((rc = outer_update(cend))) return rc;
