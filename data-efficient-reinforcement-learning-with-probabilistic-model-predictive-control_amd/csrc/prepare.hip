@@ -619,6 +619,67 @@ __global__ __launch_bounds__(256) void trinv_row_kernel(const double* __restrict
     }
 }
 
+// Y = L^-1 in ONE launch (32-wide path, round 5 staging): a workgroup per 32-column block c of Y walks the row blocks k = c + 1 ..
+// itself -- Y[k, c] = -Y_kk (sum_{p = c .. k-1} L[k, p] Y[p, c]) -- with its block column of Y resident in LDS (rows c0 .. N: at most 544
+// rows of 32 doubles), so the 15 dependent launches of trinv_row_kernel (and the events that put them on a side stream) become
+// one; the longest chain (c = 0) is 3840 matrix instructions on one CU.  Y_kk is what potrf left in the diagonal blocks.
+__global__ __launch_bounds__(256) void trinv_colblock_kernel(const double* __restrict__ Kall, double* __restrict__ Yall, int N) {
+    extern __shared__ __attribute__((aligned(16))) double sm_inv[];
+    double (*w)[33] = reinterpret_cast<double (*)[33]>(sm_inv);                 // 32 x 33
+    double (*ykk)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(sm_inv + 32 * 33);   // 32 x 33
+    double* ycol = sm_inv + 2 * 32 * 33;                                         // (N - c0) x 32
+    const int a = blockIdx.y;
+    const double* L = Kall + (size_t)a * N * N;
+    double* Y = Yall + (size_t)a * N * N;
+    const int c0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nbc = (N - c0 < NB) ? (N - c0) : NB;
+    // block row c: the diagonal block itself
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+        const int r = idx >> 5, c = idx & 31;
+        ycol[r * 32 + c] = (r < nbc && c < nbc && c <= r) ? Y[(size_t)(c0 + r) * N + c0 + c] : 0.0;
+    }
+    __syncthreads();
+    for (int k0 = c0 + 32; k0 < N; k0 += 32) {
+        const int nb = (N - k0 < NB) ? (N - k0) : NB;
+        {
+            const int c = tid & 31, r0 = tid >> 5;          // four loads in flight (see trsm_panel_mfma_kernel)
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + 8 * u;
+                const int rr = r < nb ? r : nb - 1, cc = c <= rr ? c : rr;
+                v[u] = Y[(size_t)(k0 + rr) * N + (k0 + cc)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + 8 * u;
+                ykk[r][c] = (r < nb && c <= r) ? v[u] : 0.0;
+            }
+        }
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const bool rowin = (wi + li < nb);
+        const double* Ar = L + (size_t)(k0 + (rowin ? wi + li : 0)) * N;
+        const double* Bc = ycol + wj + li - (size_t)c0 * 32;                    // Bc[p * 32] = Y[p, c0 + wj + li] for c0 <= p < k0
+        mfma_kloop<8>(acc, c0, k0, lk, [&](int pk) { return rowin ? Ar[pk] : 0.0; }, [&](int pk) { return Bc[(size_t)pk * 32]; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[wi + lk + 4 * r][wj + li] = acc[r];
+        __syncthreads();
+        for (int idx = tid; idx < 32 * 32; idx += 256) {
+            const int r = idx >> 5, c = idx & 31;
+            double sv = 0.0;
+            if (r < nb && c < nbc) {
+                for (int m = 0; m <= r; ++m) sv = fma(ykk[r][m], w[m][c], sv);
+                Y[(size_t)(k0 + r) * N + c0 + c] = -sv;
+            }
+            ycol[(size_t)(k0 - c0 + r) * 32 + c] = (r < nb && c < nbc) ? -sv : 0.0;
+        }
+        __syncthreads();
+    }
+}
+
 // z = Y y  (wave per row), beta = Y^T z  (thread per column)
 // targets (N, D) -> (D, N): the rows of Y are multiplied with ONE column of the targets; read in place, the 64 lanes of a load
 // touch 64 cache lines (stride D doubles)
@@ -1221,7 +1282,9 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     // not the panel solve and trailing update of step k -- so the inverse's chain of launches runs on a side stream BESIDE the
     // factorisation's (one event per step; every kernel here fills a few CUs).  N = 500: the factorisation chain is 16 x
     // (8.9 + 4.7 + 5.0) us, the inverse chain 15 x 14.3 us (profiles/r04_c3_kernel_trace_stats.txt); in sequence 0.59 ms.
-    const bool overlap_inv = !OW && !factored && h->opt_prepare_overlap != 0 && N > NB;
+    // ... or, up to 544 points (17 row blocks of the block column in LDS), the whole inverse as ONE launch after the factorisation
+    const bool inv_cols = !OW && !factored && h->opt_outer_block != 0 && h->opt_prepare_invcols != 0 && N > NB && N <= 544;
+    const bool overlap_inv = !OW && !factored && !inv_cols && h->opt_prepare_overlap != 0 && N > NB;
     if (overlap_inv && !h->side_stream) {
         GPMPC_HIP_CHECK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
         GPMPC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
@@ -1285,9 +1348,16 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
                 }
             }
         }
-        if (k0 > 0 && !OW && !factored && !overlap_inv) {
+        if (k0 > 0 && !OW && !factored && !overlap_inv && !inv_cols) {
             hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb, 0, 0, 0);
         }
+    }
+    if (inv_cols) {
+        const void* kern = reinterpret_cast<const void*>(trinv_colblock_kernel);
+        if ((rc = allow_full_lds(h, kern))) return rc;
+        const int nblk = (N + NB - 1) / NB;
+        const size_t lds = (size_t)(2 * 32 * 33 + (size_t)nblk * 32 * 32) * sizeof(double);
+        hipLaunchKernelGGL(trinv_colblock_kernel, dim3(nblk, D), dim3(256), lds, s, h->gram.p, h->linv.p, N);
     }
     if (overlap_inv) {                                    // join: what follows reads all of Y
         GPMPC_HIP_CHECK(h, hipEventRecord(h->ev_points, h->side_stream));

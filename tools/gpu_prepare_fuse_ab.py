@@ -8,7 +8,7 @@ import gp_mpc_amd
 from oracle import synth
 from oracle import gpmpc_oracle as orc
 from helpers import rel_err
-shapes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(257, 2, 1), (300, 3, 1), (333, 3, 2), (400, 4, 2), (500, 2, 1), (500, 4, 2), (600, 4, 2), (639, 6, 2)]
+shapes = [tuple(int(v) for v in a.split(":")) for a in sys.argv[1:]] or [(257, 2, 1), (300, 3, 1), (333, 3, 2), (400, 4, 2), (500, 2, 1), (500, 4, 2), (544, 3, 1), (600, 4, 2)]
 eng = gp_mpc_amd.HipEngine(0)
 print("library", gp_mpc_amd.LIB_PATH, "build", eng.build_id)
 eng.set_option("incremental", 0)
@@ -18,16 +18,20 @@ for (N, D, A) in shapes:
     ls, osc, nz = torch.as_tensor(w.lengthscales).cuda(), torch.as_tensor(w.outputscales).cuda(), torch.as_tensor(w.noises).cuda()
     iK0, beta0 = orc.factorize(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
     got = {}
-    for fuse in (1, 0, 1, 0):
+    for fuse, inv in ((1, 1), (1, 0), (0, 0), (1, 1), (1, 0), (0, 0)):
         eng.set_option("prepare_fuse", fuse)
+        eng.set_option("prepare_invcols", inv)
         eng.prepare(X, Y, ls, osc, nz); torch.cuda.synchronize()
         ts = []
         for _ in range(20):
             t0 = time.perf_counter(); eng.prepare(X, Y, ls, osc, nz); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         iK, beta = eng.factors()
-        got[fuse] = (iK.clone(), beta.clone())
-        print(f"N={N} D={D} prepare_fuse={fuse}: {np.median(ts)*1e3:.3f} ms (min {min(ts)*1e3:.3f})  rel err iK {rel_err(iK.cpu().numpy(), iK0):.1e} "
+        got[(fuse, inv)] = (iK.clone(), beta.clone())
+        print(f"N={N} D={D} prepare_fuse={fuse} prepare_invcols={inv}: {np.median(ts)*1e3:.3f} ms (min {min(ts)*1e3:.3f})  rel err iK {rel_err(iK.cpu().numpy(), iK0):.1e} "
               f"beta {rel_err(beta.cpu().numpy(), beta0):.1e}", flush=True)
-    print(f"N={N} D={D}: factors of the two forms identical: {bool(torch.equal(got[0][0], got[1][0]) and torch.equal(got[0][1], got[1][1]))}", flush=True)
+    same = lambda p, q: bool(torch.equal(got[p][0], got[q][0]) and torch.equal(got[p][1], got[q][1]))
+    print(f"N={N} D={D}: factors identical: fused vs separate {same((1, 0), (0, 0))}, one-launch inverse vs row blocks {same((1, 1), (1, 0))}; "
+          f"iK one-launch vs row blocks {rel_err(got[(1, 1)][0].cpu().numpy(), got[(1, 0)][0].cpu().numpy()):.1e}", flush=True)
 eng.set_option("prepare_fuse", 1)
+eng.set_option("prepare_invcols", 1)
 eng.close()
