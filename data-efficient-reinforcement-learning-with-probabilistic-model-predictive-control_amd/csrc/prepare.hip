@@ -680,6 +680,75 @@ __global__ __launch_bounds__(256) void trinv_colblock_kernel(const double* __res
     }
 }
 
+// Row blocks [kb, ke) of Y = L^-1 in one launch (32-wide path, round 5 staging): the workgroup of column tile c walks the row blocks
+// k = max(kb, c + 1) .. ke - 1 in turn; rows of its tile computed by EARLIER launches come from global memory, the rows of this
+// launch stay in LDS.  With four row blocks per launch the inverse's side-stream chain is 4 launches and 8 event operations at N = 500
+// instead of 15 and 30 -- the chain of the 32-wide path is paced by the host's enqueue rate.
+constexpr int kInvBatchMax = 4;                        // 32 KB of rows + 17 KB of scratch: static LDS
+__global__ __launch_bounds__(256) void trinv_rows_batch_kernel(const double* __restrict__ Kall, double* __restrict__ Yall, int N, int kb, int ke) {
+    __shared__ double w[32][33];
+    __shared__ double ykk[NB][NB + 1];
+    __shared__ double yl[kInvBatchMax * 32 * 32];            // rows [kb0, ke0) of this column tile
+    const int a = blockIdx.y;
+    const double* L = Kall + (size_t)a * N * N;
+    double* Y = Yall + (size_t)a * N * N;
+    const int c = blockIdx.x, c0 = c * 32, kb0 = kb * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nbc = (N - c0 < NB) ? (N - c0) : NB;
+    if (c >= kb) {                                           // the tile's diagonal block belongs to this launch's rows: Y_cc from potrf
+        for (int idx = tid; idx < 32 * 32; idx += 256) {
+            const int r = idx >> 5, cc = idx & 31;
+            yl[(size_t)(c0 - kb0 + r) * 32 + cc] = (r < nbc && cc < nbc && cc <= r) ? Y[(size_t)(c0 + r) * N + c0 + cc] : 0.0;
+        }
+    }
+    __syncthreads();
+    for (int k = (kb > c + 1 ? kb : c + 1); k < ke; ++k) {
+        const int k0 = k * 32;
+        const int nb = (N - k0 < NB) ? (N - k0) : NB;
+        {
+            const int cc = tid & 31, r0 = tid >> 5;          // four loads in flight (see trsm_panel_mfma_kernel)
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + 8 * u;
+                const int rr = r < nb ? r : nb - 1, c2 = cc <= rr ? cc : rr;
+                v[u] = Y[(size_t)(k0 + rr) * N + (k0 + c2)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + 8 * u;
+                ykk[r][cc] = (r < nb && cc <= r) ? v[u] : 0.0;
+            }
+        }
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const bool rowin = (wi + li < nb);
+        const double* Ar = L + (size_t)(k0 + (rowin ? wi + li : 0)) * N;
+        const int colg = c0 + wj + li;
+        const bool colin = colg < N;
+        const double* Bg = Y + (colin ? colg : 0);
+        const int split = c0 > kb0 ? c0 : kb0;               // [c0, split): rows of earlier launches; [split, k0): rows of this one (LDS)
+        if (c0 < kb0)
+            mfma_kloop<8>(acc, c0, kb0 < k0 ? kb0 : k0, lk, [&](int pk) { return rowin ? Ar[pk] : 0.0; }, [&](int pk) { return colin ? Bg[(size_t)pk * N] : 0.0; });
+        const double* Bl = yl + wj + li - (size_t)kb0 * 32;
+        mfma_kloop<8>(acc, split, k0, lk, [&](int pk) { return rowin ? Ar[pk] : 0.0; }, [&](int pk) { return Bl[(size_t)pk * 32]; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[wi + lk + 4 * r][wj + li] = acc[r];
+        __syncthreads();
+        for (int idx = tid; idx < 32 * 32; idx += 256) {
+            const int r = idx >> 5, cc = idx & 31;
+            double sv = 0.0;
+            if (r < nb && cc < nbc) {
+                for (int m = 0; m <= r; ++m) sv = fma(ykk[r][m], w[m][cc], sv);
+                Y[(size_t)(k0 + r) * N + c0 + cc] = -sv;
+            }
+            yl[(size_t)(k0 - kb0 + r) * 32 + cc] = (r < nb && cc < nbc) ? -sv : 0.0;
+        }
+        __syncthreads();
+    }
+}
+
 // z = Y y  (wave per row), beta = Y^T z  (thread per column)
 // targets (N, D) -> (D, N): the rows of Y are multiplied with ONE column of the targets; read in place, the 64 lanes of a load
 // touch 64 cache lines (stride D doubles)
@@ -1283,13 +1352,15 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     // factorisation's (one event per step; every kernel here fills a few CUs).  N = 500: the factorisation chain is 16 x
     // (8.9 + 4.7 + 5.0) us, the inverse chain 15 x 14.3 us (profiles/r04_c3_kernel_trace_stats.txt); in sequence 0.59 ms.
     // ... or, up to 544 points (17 row blocks of the block column in LDS), the whole inverse as ONE launch after the factorisation
-    const bool inv_cols = !OW && !factored && h->opt_outer_block != 0 && h->opt_prepare_invcols != 0 && N > NB && N <= 544;
+    const bool inv_cols = !OW && !factored && h->opt_outer_block != 0 && h->opt_prepare_invcols != 0 && N > NB &&
+                          N <= (h->opt_prepare_invcols == 2 ? 544 : 384);       // measured: 0.286 -> 0.254 ms at N = 257, even at 400, slower from 500 on
     const bool overlap_inv = !OW && !factored && !inv_cols && h->opt_prepare_overlap != 0 && N > NB;
     if (overlap_inv && !h->side_stream) {
         GPMPC_HIP_CHECK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
         GPMPC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
         GPMPC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_points, hipEventDisableTiming));
     }
+    int inv_rows_done = 1;                                // row blocks [1, inv_rows_done) of L^-1 are launched (block 0 is its diagonal block)
     for (int k0 = 0; k0 < N; k0 += NB) {
         const int nb = (N - k0 < NB) ? (N - k0) : NB;
         const bool blk128 = OW && tile128 && h->opt_block128 != 0;
@@ -1320,10 +1391,21 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
             else if (fast) hipLaunchKernelGGL(potrf_diag_fast_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info, left);
             else hipLaunchKernelGGL(potrf_diag_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
             if (overlap_inv && k0 > 0) {
-                // rows <= k of L and Y_kk are final: row block k of the inverse starts now, beside this step's solve and update
-                GPMPC_HIP_CHECK(h, hipEventRecord(h->ev_params, s));
-                GPMPC_HIP_CHECK(h, hipStreamWaitEvent(h->side_stream, h->ev_params, 0));
-                hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, h->side_stream, h->gram.p, h->linv.p, N, k0, nb, 0, 0, 0);
+                // rows <= k of L and Y_kk are final: row block k of the inverse can start now, beside this step's solve and update --
+                // in batches of `prepare_inv_batch` row blocks per launch (1: a launch per row block, the round-4 form)
+                const int kp = k0 / NB, last = (N + NB - 1) / NB - 1;
+                int batch = h->opt_prepare_inv_batch < 1 ? 1 : (h->opt_prepare_inv_batch > kInvBatchMax ? kInvBatchMax : h->opt_prepare_inv_batch);
+                if (!fast) batch = 1;
+                if (batch == 1) {
+                    GPMPC_HIP_CHECK(h, hipEventRecord(h->ev_params, s));
+                    GPMPC_HIP_CHECK(h, hipStreamWaitEvent(h->side_stream, h->ev_params, 0));
+                    hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, h->side_stream, h->gram.p, h->linv.p, N, k0, nb, 0, 0, 0);
+                } else if (kp - inv_rows_done + 1 >= batch || kp == last) {
+                    GPMPC_HIP_CHECK(h, hipEventRecord(h->ev_params, s));
+                    GPMPC_HIP_CHECK(h, hipStreamWaitEvent(h->side_stream, h->ev_params, 0));
+                    hipLaunchKernelGGL(trinv_rows_batch_kernel, dim3(kp, D), dim3(256), 0, h->side_stream, h->gram.p, h->linv.p, N, inv_rows_done, kp + 1);
+                    inv_rows_done = kp + 1;
+                }
             }
             const int M = N - k0 - nb;
             if (M > 0) {

@@ -18,20 +18,23 @@ for (N, D, A) in shapes:
     ls, osc, nz = torch.as_tensor(w.lengthscales).cuda(), torch.as_tensor(w.outputscales).cuda(), torch.as_tensor(w.noises).cuda()
     iK0, beta0 = orc.factorize(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
     got = {}
-    for fuse, inv in ((1, 1), (1, 0), (0, 0), (1, 1), (1, 0), (0, 0)):
+    # (fuse, inv): inv = 2 one-launch inverse, 4 / 1 row blocks per side-stream launch with the default crossover switched off
+    for fuse, inv in ((1, 2), (1, 4), (1, 1), (0, 1), (1, 2), (1, 4), (1, 1), (0, 1)):
         eng.set_option("prepare_fuse", fuse)
-        eng.set_option("prepare_invcols", inv)
+        eng.set_option("prepare_invcols", 2 if inv == 2 else 0)
+        eng.set_option("prepare_inv_batch", 4 if inv == 4 else 1)
         eng.prepare(X, Y, ls, osc, nz); torch.cuda.synchronize()
         ts = []
         for _ in range(20):
             t0 = time.perf_counter(); eng.prepare(X, Y, ls, osc, nz); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         iK, beta = eng.factors()
         got[(fuse, inv)] = (iK.clone(), beta.clone())
-        print(f"N={N} D={D} prepare_fuse={fuse} prepare_invcols={inv}: {np.median(ts)*1e3:.3f} ms (min {min(ts)*1e3:.3f})  rel err iK {rel_err(iK.cpu().numpy(), iK0):.1e} "
+        print(f"N={N} D={D} prepare_fuse={fuse} inverse={ {2: 'one launch', 4: '4 row blocks per launch', 1: 'a launch per row block'}[inv] }: {np.median(ts)*1e3:.3f} ms (min {min(ts)*1e3:.3f})  rel err iK {rel_err(iK.cpu().numpy(), iK0):.1e} "
               f"beta {rel_err(beta.cpu().numpy(), beta0):.1e}", flush=True)
     same = lambda p, q: bool(torch.equal(got[p][0], got[q][0]) and torch.equal(got[p][1], got[q][1]))
-    print(f"N={N} D={D}: factors identical: fused vs separate {same((1, 0), (0, 0))}, one-launch inverse vs row blocks {same((1, 1), (1, 0))}; "
-          f"iK one-launch vs row blocks {rel_err(got[(1, 1)][0].cpu().numpy(), got[(1, 0)][0].cpu().numpy()):.1e}", flush=True)
+    print(f"N={N} D={D}: factors identical: fused vs separate {same((1, 1), (0, 1))}, one-launch inverse vs row blocks {same((1, 2), (1, 1))}, "
+          f"batched vs single row blocks {same((1, 4), (1, 1))}", flush=True)
 eng.set_option("prepare_fuse", 1)
 eng.set_option("prepare_invcols", 1)
+eng.set_option("prepare_inv_batch", 4)
 eng.close()
