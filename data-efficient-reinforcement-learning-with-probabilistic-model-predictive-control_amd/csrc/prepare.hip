@@ -1353,7 +1353,7 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     // (8.9 + 4.7 + 5.0) us, the inverse chain 15 x 14.3 us (profiles/r04_c3_kernel_trace_stats.txt); in sequence 0.59 ms.
     // ... or, up to 544 points (17 row blocks of the block column in LDS), the whole inverse as ONE launch after the factorisation
     const bool inv_cols = !OW && !factored && h->opt_outer_block != 0 && h->opt_prepare_invcols != 0 && N > NB &&
-                          N <= (h->opt_prepare_invcols == 2 ? 544 : 384);       // measured: 0.286 -> 0.254 ms at N = 257, even at 400, slower from 500 on
+                          N <= (h->opt_prepare_invcols == 2 ? 544 : 352);       // measured: 0.286 -> 0.254 ms at N = 257, 0.315 -> 0.297 at 300, 0.404 vs 0.420 at 400, slower from 500 on
     const bool overlap_inv = !OW && !factored && !inv_cols && h->opt_prepare_overlap != 0 && N > NB;
     if (overlap_inv && !h->side_stream) {
         GPMPC_HIP_CHECK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
