@@ -368,22 +368,31 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                 __syncthreads();                                   // previous sweep done with the stage
                 fill(0, s_stage);
                 __syncthreads();
-                // row sums of chunk `ch` (written by the active wavefronts before the chunk's barrier) -> r, wavefront by wavefront
-                auto take_rows = [&](int ch) {
-                    if (tid < CHW) {
-                        const int row = ch * CHW + tid;
-                        const double* src = s_rs + (ch & 1) * NW * CHW + tid;
-                        double sacc = 0.0;
-                        for (int w2 = 0; w2 < NW; ++w2)
-                            if (sw * NW + w2 < NT16) sacc += src[w2 * CHW];
-                        if (row < N) s_r[row] += sacc;
-                    }
+                // row sums of chunk `ch` (written by the wavefronts before the chunk's barrier) -> r.  Wavefront w takes rows 8 w .. 8 w + 7:
+                // lane (row = lane >> 3, source wavefront = lane & 7) reads ONE partial at the head of the next chunk's tile loop and the
+                // eight partials of a row are added in lane order (a DPP prefix over the lanes of the group) behind it -- a single
+                // no-return ds_add_f64 per row and chunk, so r's additions have one fixed order and nothing waits for them.
+                auto take_load = [&](int ch) -> double {
+                    return s_rs[((ch & 1) * NW + (lane & 7)) * CHW + wave * 8 + (lane >> 3)];
                 };
+                auto take_add = [&](int ch, double pv) {
+                    pv += dpp_shifted<0x111, 0xf>(pv);      // row_shr:1
+                    pv += dpp_shifted<0x112, 0xf>(pv);      // row_shr:2
+                    pv += dpp_shifted<0x114, 0xf>(pv);      // row_shr:4   -> lane 8 g + 7 holds the sum of lanes 8 g .. 8 g + 7
+                    const int row = ch * CHW + wave * 8 + (lane >> 3);
+                    if ((lane & 7) == 7 && row < N)
+                        (void)__hip_atomic_fetch_add(&s_r[row], pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                };
+                if (rowsum && !act) {                       // an idle wavefront's slots read as zero (both buffers)
+                    s_rs[(0 * NW + wave) * CHW + lane] = 0.0;
+                    s_rs[(1 * NW + wave) * CHW + lane] = 0.0;
+                }
                 for (int ch = 0; ch < nchunk; ++ch) {
                     double nfx[DPT], nfb = 0.0;
                     const bool more = ch + 1 < nchunk;
                     if (more) fill_load(ch + 1, nfx, nfb);
-                    if (rowsum && ch > 0) take_rows(ch - 1);
+                    double prev_rows = 0.0;
+                    if (rowsum && ch > 0) prev_rows = take_load(ch - 1);
                     const double* st = s_stage + (ch & 1) * CHW * RSW;
                     if (act) {
 #pragma unroll 1
@@ -463,10 +472,11 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                             }
                         }
                     }
+                    if (rowsum && ch > 0) take_add(ch - 1, prev_rows);
                     if (more) fill_store(ch + 1, s_stage + ((ch + 1) & 1) * CHW * RSW, nfx, nfb);
                     __syncthreads();
                 }
-                if (rowsum) take_rows(nchunk - 1);             // (the next sweep's first barrier orders it before any new partial)
+                if (rowsum) take_add(nchunk - 1, take_load(nchunk - 1));     // (the next sweep's first barrier orders it before any new partial)
                 if (act) {
                     double csum = (csum0 + csum1) * colf;
                     csum += __shfl_xor(csum, 16, 64);
