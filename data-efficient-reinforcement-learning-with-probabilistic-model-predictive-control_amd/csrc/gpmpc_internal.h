@@ -172,6 +172,9 @@ struct Handle {
     int opt_grad_fuse = 1;           // gradient: form the diagonal pairs' tile moments inside the batch-major forward (0: separate pass, A/B)
     int last_grad_path = 0;          // moment passes of the last gpmpc_rollout_grad: bit 0 separable off-diagonal pairs, bit 1 tile moments of
                                      // the diagonal pairs, bit 2 streaming element-wise pass, bit 3 the wide (8 < D <= 16) pass
+    int opt_prepare_inv_batch = 4;   // 32-wide panel path: row blocks of L^-1 per side-stream launch (1: one launch per row block)
+    int opt_prepare_invcols = 1;     // 32-wide panel path, N <= 352 (measured crossover; option 2: up to 544): L^-1 in one launch after the factorisation (0: row blocks beside / after the panels)
+    int opt_prepare_fuse = 1;        // 32-wide panel path: trailing update fused with the next diagonal block's factorisation (0: separate launches, A/B)
     int opt_prepare_overlap = 1;     // 32-wide panel path: the inverse's launches on a side stream beside the factorisation's (0: one stream, A/B)
     int opt_fused_prepare = 1;       // N <= 256: the whole factorisation in one launch (prepare_small.hip); 0: panel path (A/B, tests)
     int last_prepare_mode = 0;       // 0 full, 1 border update(s), 2 unchanged (cache hit)

@@ -63,10 +63,13 @@ __host__ __device__ inline int wide_nsp(int D, int NX) { return rnd2(1 + D + D *
 constexpr int kWideStageRows = 64;     // rows per staged chunk (two buffers)
 constexpr int kWideRS = 18;            // row record: factor | beta | u (16)  (an odd stride removes the A-operand bank conflicts and is 3 % slower:
                                        // rollout_stream_kernel.h stream_row_stride, profiles/r04c_ab_c5_grad_*.txt)
-constexpr int kWideFold = 2 * 256 + 16 + 16 * 16 + 16;     // per wavefront: V tile | w tile | c_j | extra inputs of the 16 columns | column factors
+// per wavefront: V tile | w tile | c_j | extra inputs of the 16 columns (stride 8 up to 8 extra inputs, else 16) | column factors
+__host__ __device__ inline int wide_fx_stride(int NX) { return NX <= 8 ? 8 : 16; }
+__host__ __device__ inline int wide_fold_words(int NX) { return 2 * 256 + 16 + 16 * wide_fx_stride(NX) + 16; }
+constexpr int kWideRowSlots = 2 * (kWideThreads / 64) * kWideStageRows;     // row sums of a chunk per wavefront, double-buffered
 
 struct WideMomLayout {
-    int aug, Z, m, ila, ilb, ka, kb, exptab, fold, tot, etab, stage, flag, total;
+    int aug, Z, m, ila, ilb, ka, kb, exptab, fold, rs, tot, etab, stage, flag, total;
 };
 
 __host__ __device__ inline WideMomLayout make_wide_mom_layout(int N, int D, int E, int NSP) {
@@ -80,7 +83,8 @@ __host__ __device__ inline WideMomLayout make_wide_mom_layout(int N, int D, int 
     L.ilb = o;    o += rnd2(E);
     L.ka = o;     o += rnd2(N);
     L.kb = o;     o += rnd2(N);
-    L.fold = o;   o += (kWideThreads / 64) * kWideFold;
+    L.fold = o;   o += (kWideThreads / 64) * wide_fold_words(E - D);
+    L.rs = o;     o += (E - D <= 8) ? kWideRowSlots : 0;       // (the space the narrower extra-input tile frees)
     L.etab = o;   o += 2 * kTableHalf + 2;                    // exp(n / 128), |n| <= 1024: the tabulated form of the forward kernel
     // row records of a 64-row chunk, double-buffered; the per-wavefront totals of the epilogue reuse the region
     const int st = 2 * kWideStageRows * kWideRS, tt = (kWideThreads / 64) * NSP;
@@ -114,7 +118,9 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
     double* s_ilb = smem + L.ilb;
     double* s_ka = smem + L.ka;
     double* s_kb = smem + L.kb;
-    double* s_fold = smem + L.fold + wave * kWideFold;
+    double* s_fold = smem + L.fold + wave * wide_fold_words(NX);
+    double* s_rs = smem + L.rs;
+    const int FX = wide_fx_stride(NX);
     double* s_tot = smem + L.tot;
     double* s_etab = smem + L.etab + kTableHalf;           // centre of the table
     double* s_stage = smem + L.stage;
@@ -165,34 +171,42 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
     }
     __syncthreads();
     const bool use_table = __builtin_amdgcn_readfirstlane(s_flag[0]) != 0;
-    // per-point log-factors of both sides:  k' = log var - sum_e nu_e^2 / (2 l_e^2) + x^T Z x / 2,  x = nu / l^2 (state part)
-    for (int pt = tid; pt < N; pt += NT) {
-        double nu[DP];
+    // per-point log-factors:  k' = log var - sum_e nu_e^2 / (2 l_e^2) + x^T Z x / 2,  x = nu / l^2 (state part)
+    auto kprime = [&](int pt, int side) -> double {
+        const double* il = side ? s_ilb : s_ila;
+        double x[DP];
+        double ks = 0.0;
 #pragma unroll
-        for (int d = 0; d < DP; ++d) nu[d] = (d < D) ? p.Xt[(size_t)d * N + pt] - s_m[d] : 0.0;
-        double ea = 0.0, eb = 0.0;
+        for (int d = 0; d < DP; ++d) {
+            const double nu = (d < D) ? p.Xt[(size_t)d * N + pt] - s_m[d] : 0.0;
+            x[d] = (d < D) ? nu * il[d] : 0.0;
+            ks = fma(nu, x[d], ks);
+        }
         for (int e = D; e < E; ++e) {
             const double v = p.Xt[(size_t)e * N + pt] - s_m[e];
-            ea = fma(v * v, s_ila[e], ea);
-            eb = fma(v * v, s_ilb[e], eb);
+            ks = fma(v * v, il[e], ks);
         }
-        for (int side = 0; side < (diag ? 1 : 2); ++side) {
-            const double* il = side ? s_ilb : s_ila;
-            double x[DP];
-            double ks = side ? eb : ea;
-#pragma unroll
-            for (int d = 0; d < DP; ++d) { x[d] = (d < D) ? nu[d] * il[d] : 0.0; ks = fma(nu[d], x[d], ks); }
-            double qq = 0.0;
+        double qq = 0.0;
 #pragma unroll 4
-            for (int i = 0; i < DP; ++i) {
-                double zx = 0.0;
+        for (int i = 0; i < DP; ++i) {
+            double zx = 0.0;
 #pragma unroll
-                for (int j = 0; j < DP; ++j) zx = fma(s_Z[i * 16 + j], x[j], zx);
-                qq = fma(x[i], zx, qq);
-            }
-            const double kv = (side ? p.logvar[b] : p.logvar[a]) - 0.5 * ks + 0.5 * qq;
-            if (side) s_kb[pt] = kv; else { s_ka[pt] = kv; if (diag) s_kb[pt] = kv; }
+            for (int j = 0; j < DP; ++j) zx = fma(s_Z[i * 16 + j], x[j], zx);
+            qq = fma(x[i], zx, qq);
         }
+        return (side ? p.logvar[b] : p.logvar[a]) - 0.5 * ks + 0.5 * qq;
+    };
+    // Row-sum mode (tabulated form, off-diagonal pair, <= 8 extra inputs): ONE orientation.  The second orientation re-evaluated all N^2
+    // weights only for their row sums r_i = sum_j E_ij; here the tiles of the first orientation give them -- every wavefront reduces
+    // its tile's rows over the 16 lanes of a DPP row, the eight wavefronts' partials of a 64-row chunk meet in LDS and are added in a
+    // fixed order into r (which lives where the column side's log-factors were: those are formed per sweep for the wavefront's 16
+    // columns instead).
+    const bool rowsum = use_table && !diag && NX <= 8;
+    double* s_r = s_kb;
+    for (int pt = tid; pt < N; pt += NT) {
+        s_ka[pt] = kprime(pt, 0);
+        if (rowsum) s_r[pt] = 0.0;
+        else s_kb[pt] = diag ? s_ka[pt] : kprime(pt, 1);
     }
     __syncthreads();
 
@@ -204,7 +218,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
     double* f_w = s_fold + 256;            // [col][dim]   column-side monomial vector x_j = nu_j / l^2
     double* f_c = s_fold + 512;            // [col]
     double* f_x = s_fold + 528;            // [col][extra input] nu_jx
-    double* f_cf = s_fold + 784;           // [col] column factor (tabulated form)
+    double* f_cf = s_fold + 528 + 16 * FX; // [col] column factor (tabulated form)
 
     // the 16 columns of a tile folded into the moments (lanes own entries); f_c, f_V, f_w, f_x hold the tile
     auto fold_tile = [&](int orient, const double* il_r, const double* il_c) {
@@ -229,7 +243,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
             }
             if (lane < NX) {
                 double s = 0.0;
-                _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * 16 + lane], s);
+                _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * FX + lane], s);
                 tPe += s * (il_c[D + lane] + (diag ? il_r[D + lane] : 0.0));
             }
             if (lane == 0) {
@@ -248,7 +262,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
             }
             if (lane < NX) {
                 double s = 0.0;
-                _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * 16 + lane], s);
+                _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * FX + lane], s);
                 tPe += s * il_c[D + lane];
             }
         }
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
             const int cc = k / NX, x = k - cc * NX;
             int jj = ct * 16 + cc;
             jj = jj < N ? jj : N - 1;
-            f_x[cc * 16 + x] = p.Xt[(size_t)(D + x) * N + jj] - s_m[D + x];
+            f_x[cc * FX + x] = p.Xt[(size_t)(D + x) * N + jj] - s_m[D + x];
         }
     };
 
@@ -279,7 +293,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
         const int nchunk = (N + CHW - 1) / CHW;
         const int nsweep = (NT16 + NW - 1) / NW;
         constexpr double kShift = 52776558133248.0;                                     // 1.5 * 2^45: see block_mfma_table
-        for (int orient = 0; orient < (diag ? 1 : 2); ++orient) {
+        for (int orient = 0; orient < ((diag || rowsum) ? 1 : 2); ++orient) {
             const int rs = orient ? b : a, cs_ = orient ? a : b;
             const double* il_r = orient ? s_ilb : s_ila;
             const double* il_c = orient ? s_ila : s_ilb;
@@ -347,17 +361,38 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                     }
                 }
                 const double bcj = jin ? beta_c[jc] : 0.0;
-                const double ecj = jin ? fast_exp(k_c[jc], s_exptab) : 0.0;
+                const double ecj = jin ? fast_exp(rowsum ? kprime(jc, 1) : k_c[jc], s_exptab) : 0.0;
                 const double colf = diag ? ecj : ecj * bcj;       // column factor of the sums (diagonal pair: beta_cj sits in the weight)
                 double csum0 = 0.0, csum1 = 0.0;
                 mfma_d4 vc = {0.0, 0.0, 0.0, 0.0};
                 __syncthreads();                                   // previous sweep done with the stage
                 fill(0, s_stage);
                 __syncthreads();
+                // row sums of chunk `ch` (written by the wavefronts before the chunk's barrier) -> r.  Wavefront w takes rows 8 w .. 8 w + 7:
+                // lane (row = lane >> 3, source wavefront = lane & 7) reads ONE partial at the head of the next chunk's tile loop and the
+                // eight partials of a row are added in lane order (a DPP prefix over the lanes of the group) behind it -- a single
+                // no-return ds_add_f64 per row and chunk, so r's additions have one fixed order and nothing waits for them.
+                auto take_load = [&](int ch) -> double {
+                    return s_rs[((ch & 1) * NW + (lane & 7)) * CHW + wave * 8 + (lane >> 3)];
+                };
+                auto take_add = [&](int ch, double pv) {
+                    pv += dpp_shifted<0x111, 0xf>(pv);      // row_shr:1
+                    pv += dpp_shifted<0x112, 0xf>(pv);      // row_shr:2
+                    pv += dpp_shifted<0x114, 0xf>(pv);      // row_shr:4   -> lane 8 g + 7 holds the sum of lanes 8 g .. 8 g + 7
+                    const int row = ch * CHW + wave * 8 + (lane >> 3);
+                    if ((lane & 7) == 7 && row < N)
+                        (void)__hip_atomic_fetch_add(&s_r[row], pv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                };
+                if (rowsum && !act) {                       // an idle wavefront's slots read as zero (both buffers)
+                    s_rs[(0 * NW + wave) * CHW + lane] = 0.0;
+                    s_rs[(1 * NW + wave) * CHW + lane] = 0.0;
+                }
                 for (int ch = 0; ch < nchunk; ++ch) {
                     double nfx[DPT], nfb = 0.0;
                     const bool more = ch + 1 < nchunk;
                     if (more) fill_load(ch + 1, nfx, nfb);
+                    double prev_rows = 0.0;
+                    if (rowsum && ch > 0) prev_rows = take_load(ch - 1);
                     const double* st = s_stage + (ch & 1) * CHW * RSW;
                     if (act) {
 #pragma unroll 1
@@ -412,6 +447,23 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                             for (int e = 0; e < 8; ++e) wt[e] *= qv[e];               // E_ij without the column factor
                             csum0 += (wt[0] + wt[1]) + (wt[2] + wt[3]);
                             csum1 += (wt[4] + wt[5]) + (wt[6] + wt[7]);
+                            if (rowsum) {
+                                // sum over the tile's 16 columns (the lanes of a DPP row) of E_ij WITH the column factor, eight rows at a
+                                // time on the halving exchanges: lane (bit 3, bit 2) of the row ends with the totals of values 4 b3 + 2 b2, + 1
+                                double r4[4], r2[2];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) r4[k] = rot_add8(wt[k] * colf, wt[k + 4] * colf);
+#pragma unroll
+                                for (int k = 0; k < 2; ++k) r2[k] = rot_add4(r4[k], r4[k + 2]);
+                                const double t0 = quad_total(r2[0]), t1 = quad_total(r2[1]);
+                                if ((col16 & 3) == 0) {
+                                    // value index e = 4 b3 + 2 b2 (+ 1): rows 16 rt + 4 e + grp (e < 4), 16 rt + 16 + 4 (e - 4) + grp (e >= 4)
+                                    const int e0 = ((col16 >> 3) & 1) * 4 + ((col16 >> 2) & 1) * 2;
+                                    double* dst = s_rs + ((ch & 1) * NW + wave) * CHW + 16 * rt + grp;
+                                    dst[(e0 < 4) ? 4 * e0 : 16 + 4 * (e0 - 4)] = t0;
+                                    dst[(e0 + 1 < 4) ? 4 * (e0 + 1) : 16 + 4 * (e0 + 1 - 4)] = t1;
+                                }
+                            }
                             if (orient == 0) {
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_mfma_f64_16x16x4f64(wt[r], w0[(size_t)(4 * r) * RSW + 2 + col16], vc, 0, 0, 0);
@@ -420,9 +472,11 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                             }
                         }
                     }
+                    if (rowsum && ch > 0) take_add(ch - 1, prev_rows);
                     if (more) fill_store(ch + 1, s_stage + ((ch + 1) & 1) * CHW * RSW, nfx, nfb);
                     __syncthreads();
                 }
+                if (rowsum) take_add(nchunk - 1, take_load(nchunk - 1));     // (the next sweep's first barrier orders it before any new partial)
                 if (act) {
                     double csum = (csum0 + csum1) * colf;
                     csum += __shfl_xor(csum, 16, 64);
@@ -437,6 +491,21 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                     fold_tile(orient, il_r, il_c);
                     wave_lds_sync();
                 }
+            }
+        }
+        if (rowsum) {
+            // the row-side terms (sum_i r_i u_i u_i^T, sum_i r_i nu_ix / l_ax^2) from the accumulated row sums: what the second
+            // orientation's fold did with its column sums, 16 side-a points at a time
+            __syncthreads();
+            for (int ct = wave; ct < NT16; ct += NW) {
+                load_columns(ct, s_ila);
+                if (lane < 16) {
+                    const int jj = ct * 16 + lane;
+                    f_c[lane] = jj < N ? s_r[jj] : 0.0;
+                }
+                wave_lds_sync();
+                fold_tile(1, s_ilb, s_ila);
+                wave_lds_sync();
             }
         }
     } else
@@ -465,7 +534,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                 const int cc = k / NX, x = k - cc * NX;
                 int jj = ct * 16 + cc;
                 jj = jj < N ? jj : N - 1;
-                f_x[cc * 16 + x] = p.Xt[(size_t)(D + x) * N + jj] - s_m[D + x];
+                f_x[cc * FX + x] = p.Xt[(size_t)(D + x) * N + jj] - s_m[D + x];
             }
             wave_lds_sync();
             double hB[4];
@@ -550,7 +619,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                 }
                 if (lane < NX) {
                     double s = 0.0;
-                    _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * 16 + lane], s);
+                    _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * FX + lane], s);
                     tPe += s * (il_c[D + lane] + (diag ? il_r[D + lane] : 0.0));
                 }
                 if (lane == 0) {
@@ -569,7 +638,7 @@ __global__ __launch_bounds__(kWideThreads) void wide_pair_moments_kernel(const W
                 }
                 if (lane < NX) {
                     double s = 0.0;
-                    _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * 16 + lane], s);
+                    _Pragma("unroll 2") for (int cc = 0; cc < 16; ++cc) s = fma(f_c[cc], f_x[cc * FX + lane], s);
                     tPe += s * il_c[D + lane];
                 }
             }

@@ -478,6 +478,91 @@ __global__ __launch_bounds__(256) void syrk_trailing_kernel(double* __restrict__
     }
 }
 
+// Trailing update of panel k FUSED with the factorisation of panel k + 1's diagonal block (32-wide path, round 5 staging): the
+// workgroup that owns trailing tile (0, 0) -- rows / columns [k0 + nb, k0 + nb + 32): exactly the next diagonal block -- keeps its
+// updated block in LDS instead of writing it back and runs potrf_diag_fast_kernel's register pivot loop on it (all 1024 threads; in
+// the other workgroups wavefronts 4 .. 15 leave at once).  One launch and one dependent launch gap less per panel, and the
+// factorisation of the next block no longer waits for the slowest trailing tile.
+__global__ __launch_bounds__(NB * NB) void syrk_trailing_potrf_kernel(double* __restrict__ Kall, double* __restrict__ Yall,
+                                                                     int N, int k0, int nb, int* __restrict__ info) {
+    __shared__ double blk[NB][NB + 1];
+    __shared__ double colb[2][2 * NB];
+    __shared__ double sinv[NB];
+    const int ti = blockIdx.y, tj = blockIdx.x;
+    if (tj > ti) return;
+    const int a = blockIdx.z;
+    double* K = Kall + (size_t)a * N * N;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool special = (ti == 0 && tj == 0);
+    if (!special && wave >= 4) return;
+    const int r0 = k0 + nb;
+    if (wave < 4) {
+        const int i0 = r0 + ti * 32 + (wave >> 1) * 16;
+        const int j0 = r0 + tj * 32 + (wave & 1) * 16;
+        if (j0 <= i0 + 15) {
+            const int li = lane & 15, lk = lane >> 4;
+            d4 acc = {0.0, 0.0, 0.0, 0.0};
+            const int ri = i0 + li, rj = j0 + li;
+            const double* Ar = K + (size_t)(ri < N ? ri : N - 1) * N + k0;
+            const double* Br = K + (size_t)(rj < N ? rj : N - 1) * N + k0;
+            double cold[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {                            // the old values travel while the products are formed
+                const int row = i0 + lk + 4 * r, col = j0 + li;
+                cold[r] = (row < N && col <= row) ? K[(size_t)row * N + col] : 0.0;
+            }
+            mfma_kloop<8>(acc, 0, nb, lk, [&](int k) { return ri < N ? Ar[k] : 0.0; }, [&](int k) { return rj < N ? Br[k] : 0.0; });
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + lk + 4 * r, col = j0 + li;
+                if (row < N && col <= row) {
+                    if (special) blk[row - r0][col - r0] = cold[r] - acc[r];
+                    else K[(size_t)row * N + col] = cold[r] - acc[r];
+                }
+            }
+        }
+    }
+    if (!special) return;
+    __syncthreads();
+    // ---- the next panel's diagonal block: potrf_diag_fast_kernel's pivot loop on the block in LDS -----------------------------
+    double* Y = Yall + (size_t)a * N * N;
+    const int nb2 = (N - r0 < NB) ? (N - r0) : NB;
+    const int c = tid >> 5, r = tid & 31;                    // column-major over the wavefronts: wave w <-> columns 2w, 2w + 1
+    double a0 = (r < nb2 && c < nb2 && c <= r) ? blk[r][c] : 0.0;
+    double a1 = (r == c) ? 1.0 : 0.0;
+    if (c == 0) { colb[0][r] = a0; colb[0][NB + r] = a1; }
+    if (tid == 0) {
+        if (!(a0 > 0.0) && info[a] == 0) info[a] = r0 + 1;
+        sinv[0] = inv_sqrt_pos_p(a0);
+    }
+    if (tid >= nb2 && tid < NB) sinv[tid] = 0.0;
+    __syncthreads();
+    for (int k = 0; k + 1 < nb2; ++k) {
+        if (2 * wave + 1 > k) {                              // wave-uniform: both columns of a finished wave are final
+            const double* cb = colb[k & 1];
+            double* cn = colb[(k + 1) & 1];
+            const double inv = sinv[k];
+            if (c > k && c < nb2) {
+                const double lc = cb[c] * inv;
+                a0 = fma(-(cb[r] * inv), lc, a0);
+                a1 = fma(-(cb[NB + r] * inv), lc, a1);
+                if (c == k + 1) {
+                    cn[r] = a0;
+                    cn[NB + r] = a1;
+                    if (r == k + 1) {
+                        if (!(a0 > 0.0) && info[a] == 0) info[a] = r0 + k + 2;
+                        sinv[k + 1] = inv_sqrt_pos_p(a0);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    const double sc = sinv[c];                               // 0 for c >= nb2
+    if (r < nb2 && c <= r) K[(size_t)(r0 + r) * N + r0 + c] = a0 * sc;
+    if (r < nb2 && c < nb2) Y[(size_t)(r0 + c) * N + r0 + r] = (r <= c) ? a1 * sc : 0.0;       // row r of the identity -> column r of Y11
+}
+
 // Row block k of Y = L^-1:  Y[k, c] = -Ykk * (sum_p L[k, p] Y[p, c]) for column tiles c < k0.
 // blocks > 0: one launch for ALL outer blocks of `blocks` rows (blockIdx.z = outer block K): row block k0 = K + koff of
 // each, columns [K, k0) only -- the diagonal blocks Y_KK of the recursive-doubling inverse below.
@@ -531,6 +616,136 @@ __global__ __launch_bounds__(256) void trinv_row_kernel(const double* __restrict
             for (int m = 0; m <= r; ++m) s = fma(ykk[r][m], w[m][c], s);
             Y[(size_t)(k0 + r) * N + c0 + c] = -s;
         }
+    }
+}
+
+// Y = L^-1 in ONE launch (32-wide path, round 5 staging): a workgroup per 32-column block c of Y walks the row blocks k = c + 1 ..
+// itself -- Y[k, c] = -Y_kk (sum_{p = c .. k-1} L[k, p] Y[p, c]) -- with its block column of Y resident in LDS (rows c0 .. N: at most 544
+// rows of 32 doubles), so the 15 dependent launches of trinv_row_kernel (and the events that put them on a side stream) become
+// one; the longest chain (c = 0) is 3840 matrix instructions on one CU.  Y_kk is what potrf left in the diagonal blocks.
+__global__ __launch_bounds__(256) void trinv_colblock_kernel(const double* __restrict__ Kall, double* __restrict__ Yall, int N) {
+    extern __shared__ __attribute__((aligned(16))) double sm_inv[];
+    double (*w)[33] = reinterpret_cast<double (*)[33]>(sm_inv);                 // 32 x 33
+    double (*ykk)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(sm_inv + 32 * 33);   // 32 x 33
+    double* ycol = sm_inv + 2 * 32 * 33;                                         // (N - c0) x 32
+    const int a = blockIdx.y;
+    const double* L = Kall + (size_t)a * N * N;
+    double* Y = Yall + (size_t)a * N * N;
+    const int c0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nbc = (N - c0 < NB) ? (N - c0) : NB;
+    // block row c: the diagonal block itself
+    for (int idx = tid; idx < 32 * 32; idx += 256) {
+        const int r = idx >> 5, c = idx & 31;
+        ycol[r * 32 + c] = (r < nbc && c < nbc && c <= r) ? Y[(size_t)(c0 + r) * N + c0 + c] : 0.0;
+    }
+    __syncthreads();
+    for (int k0 = c0 + 32; k0 < N; k0 += 32) {
+        const int nb = (N - k0 < NB) ? (N - k0) : NB;
+        {
+            const int c = tid & 31, r0 = tid >> 5;          // four loads in flight (see trsm_panel_mfma_kernel)
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + 8 * u;
+                const int rr = r < nb ? r : nb - 1, cc = c <= rr ? c : rr;
+                v[u] = Y[(size_t)(k0 + rr) * N + (k0 + cc)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + 8 * u;
+                ykk[r][c] = (r < nb && c <= r) ? v[u] : 0.0;
+            }
+        }
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const bool rowin = (wi + li < nb);
+        const double* Ar = L + (size_t)(k0 + (rowin ? wi + li : 0)) * N;
+        const double* Bc = ycol + wj + li - (size_t)c0 * 32;                    // Bc[p * 32] = Y[p, c0 + wj + li] for c0 <= p < k0
+        mfma_kloop<8>(acc, c0, k0, lk, [&](int pk) { return rowin ? Ar[pk] : 0.0; }, [&](int pk) { return Bc[(size_t)pk * 32]; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[wi + lk + 4 * r][wj + li] = acc[r];
+        __syncthreads();
+        for (int idx = tid; idx < 32 * 32; idx += 256) {
+            const int r = idx >> 5, c = idx & 31;
+            double sv = 0.0;
+            if (r < nb && c < nbc) {
+                for (int m = 0; m <= r; ++m) sv = fma(ykk[r][m], w[m][c], sv);
+                Y[(size_t)(k0 + r) * N + c0 + c] = -sv;
+            }
+            ycol[(size_t)(k0 - c0 + r) * 32 + c] = (r < nb && c < nbc) ? -sv : 0.0;
+        }
+        __syncthreads();
+    }
+}
+
+// Row blocks [kb, ke) of Y = L^-1 in one launch (32-wide path, round 5 staging): the workgroup of column tile c walks the row blocks
+// k = max(kb, c + 1) .. ke - 1 in turn; rows of its tile computed by EARLIER launches come from global memory, the rows of this
+// launch stay in LDS.  With four row blocks per launch the inverse's side-stream chain is 4 launches and 8 event operations at N = 500
+// instead of 15 and 30 -- the chain of the 32-wide path is paced by the host's enqueue rate.
+constexpr int kInvBatchMax = 4;                        // 32 KB of rows + 17 KB of scratch: static LDS
+__global__ __launch_bounds__(256) void trinv_rows_batch_kernel(const double* __restrict__ Kall, double* __restrict__ Yall, int N, int kb, int ke) {
+    __shared__ double w[32][33];
+    __shared__ double ykk[NB][NB + 1];
+    __shared__ double yl[kInvBatchMax * 32 * 32];            // rows [kb0, ke0) of this column tile
+    const int a = blockIdx.y;
+    const double* L = Kall + (size_t)a * N * N;
+    double* Y = Yall + (size_t)a * N * N;
+    const int c = blockIdx.x, c0 = c * 32, kb0 = kb * 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = (wave >> 1) * 16, wj = (wave & 1) * 16;
+    const int li = lane & 15, lk = lane >> 4;
+    const int nbc = (N - c0 < NB) ? (N - c0) : NB;
+    if (c >= kb) {                                           // the tile's diagonal block belongs to this launch's rows: Y_cc from potrf
+        for (int idx = tid; idx < 32 * 32; idx += 256) {
+            const int r = idx >> 5, cc = idx & 31;
+            yl[(size_t)(c0 - kb0 + r) * 32 + cc] = (r < nbc && cc < nbc && cc <= r) ? Y[(size_t)(c0 + r) * N + c0 + cc] : 0.0;
+        }
+    }
+    __syncthreads();
+    for (int k = (kb > c + 1 ? kb : c + 1); k < ke; ++k) {
+        const int k0 = k * 32;
+        const int nb = (N - k0 < NB) ? (N - k0) : NB;
+        {
+            const int cc = tid & 31, r0 = tid >> 5;          // four loads in flight (see trsm_panel_mfma_kernel)
+            double v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + 8 * u;
+                const int rr = r < nb ? r : nb - 1, c2 = cc <= rr ? cc : rr;
+                v[u] = Y[(size_t)(k0 + rr) * N + (k0 + c2)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = r0 + 8 * u;
+                ykk[r][cc] = (r < nb && cc <= r) ? v[u] : 0.0;
+            }
+        }
+        d4 acc = {0.0, 0.0, 0.0, 0.0};
+        const bool rowin = (wi + li < nb);
+        const double* Ar = L + (size_t)(k0 + (rowin ? wi + li : 0)) * N;
+        const int colg = c0 + wj + li;
+        const bool colin = colg < N;
+        const double* Bg = Y + (colin ? colg : 0);
+        const int split = c0 > kb0 ? c0 : kb0;               // [c0, split): rows of earlier launches; [split, k0): rows of this one (LDS)
+        if (c0 < kb0)
+            mfma_kloop<8>(acc, c0, kb0 < k0 ? kb0 : k0, lk, [&](int pk) { return rowin ? Ar[pk] : 0.0; }, [&](int pk) { return colin ? Bg[(size_t)pk * N] : 0.0; });
+        const double* Bl = yl + wj + li - (size_t)kb0 * 32;
+        mfma_kloop<8>(acc, split, k0, lk, [&](int pk) { return rowin ? Ar[pk] : 0.0; }, [&](int pk) { return Bl[(size_t)pk * 32]; });
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w[wi + lk + 4 * r][wj + li] = acc[r];
+        __syncthreads();
+        for (int idx = tid; idx < 32 * 32; idx += 256) {
+            const int r = idx >> 5, cc = idx & 31;
+            double sv = 0.0;
+            if (r < nb && cc < nbc) {
+                for (int m = 0; m <= r; ++m) sv = fma(ykk[r][m], w[m][cc], sv);
+                Y[(size_t)(k0 + r) * N + c0 + cc] = -sv;
+            }
+            yl[(size_t)(k0 - kb0 + r) * 32 + cc] = (r < nb && cc < nbc) ? -sv : 0.0;
+        }
+        __syncthreads();
     }
 }
 
@@ -1136,12 +1351,16 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     // not the panel solve and trailing update of step k -- so the inverse's chain of launches runs on a side stream BESIDE the
     // factorisation's (one event per step; every kernel here fills a few CUs).  N = 500: the factorisation chain is 16 x
     // (8.9 + 4.7 + 5.0) us, the inverse chain 15 x 14.3 us (profiles/r04_c3_kernel_trace_stats.txt); in sequence 0.59 ms.
-    const bool overlap_inv = !OW && !factored && h->opt_prepare_overlap != 0 && N > NB;
+    // ... or, up to 544 points (17 row blocks of the block column in LDS), the whole inverse as ONE launch after the factorisation
+    const bool inv_cols = !OW && !factored && h->opt_outer_block != 0 && h->opt_prepare_invcols != 0 && N > NB &&
+                          N <= (h->opt_prepare_invcols == 2 ? 544 : 352);       // measured: 0.286 -> 0.254 ms at N = 257, 0.315 -> 0.297 at 300, 0.404 vs 0.420 at 400, slower from 500 on
+    const bool overlap_inv = !OW && !factored && !inv_cols && h->opt_prepare_overlap != 0 && N > NB;
     if (overlap_inv && !h->side_stream) {
         GPMPC_HIP_CHECK(h, hipStreamCreateWithFlags(&h->side_stream, hipStreamNonBlocking));
         GPMPC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_params, hipEventDisableTiming));
         GPMPC_HIP_CHECK(h, hipEventCreateWithFlags(&h->ev_points, hipEventDisableTiming));
     }
+    int inv_rows_done = 1;                                // row blocks [1, inv_rows_done) of L^-1 are launched (block 0 is its diagonal block)
     for (int k0 = 0; k0 < N; k0 += NB) {
         const int nb = (N - k0 < NB) ? (N - k0) : NB;
         const bool blk128 = OW && tile128 && h->opt_block128 != 0;
@@ -1166,13 +1385,27 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
             // with a rank-32 update of the rest of the outer panel per step)
             const bool ll = OW && h->opt_inner_left != 0;
             const int left = ll ? k0 % OW : 0;
-            if (fast) hipLaunchKernelGGL(potrf_diag_fast_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info, left);
+            // 32-wide path: from the second panel on the diagonal block was factorised by the previous panel's fused trailing update
+            const bool fuse_next = fast && !OW && h->opt_prepare_fuse != 0;
+            if (fuse_next && k0 > 0) { /* done by syrk_trailing_potrf_kernel of the panel before */ }
+            else if (fast) hipLaunchKernelGGL(potrf_diag_fast_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info, left);
             else hipLaunchKernelGGL(potrf_diag_kernel, dim3(D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
             if (overlap_inv && k0 > 0) {
-                // rows <= k of L and Y_kk are final: row block k of the inverse starts now, beside this step's solve and update
-                GPMPC_HIP_CHECK(h, hipEventRecord(h->ev_params, s));
-                GPMPC_HIP_CHECK(h, hipStreamWaitEvent(h->side_stream, h->ev_params, 0));
-                hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, h->side_stream, h->gram.p, h->linv.p, N, k0, nb, 0, 0, 0);
+                // rows <= k of L and Y_kk are final: row block k of the inverse can start now, beside this step's solve and update --
+                // in batches of `prepare_inv_batch` row blocks per launch (1: a launch per row block, the round-4 form)
+                const int kp = k0 / NB, last = (N + NB - 1) / NB - 1;
+                int batch = h->opt_prepare_inv_batch < 1 ? 1 : (h->opt_prepare_inv_batch > kInvBatchMax ? kInvBatchMax : h->opt_prepare_inv_batch);
+                if (!fast) batch = 1;
+                if (batch == 1) {
+                    GPMPC_HIP_CHECK(h, hipEventRecord(h->ev_params, s));
+                    GPMPC_HIP_CHECK(h, hipStreamWaitEvent(h->side_stream, h->ev_params, 0));
+                    hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, h->side_stream, h->gram.p, h->linv.p, N, k0, nb, 0, 0, 0);
+                } else if (kp - inv_rows_done + 1 >= batch || kp == last) {
+                    GPMPC_HIP_CHECK(h, hipEventRecord(h->ev_params, s));
+                    GPMPC_HIP_CHECK(h, hipStreamWaitEvent(h->side_stream, h->ev_params, 0));
+                    hipLaunchKernelGGL(trinv_rows_batch_kernel, dim3(kp, D), dim3(256), 0, h->side_stream, h->gram.p, h->linv.p, N, inv_rows_done, kp + 1);
+                    inv_rows_done = kp + 1;
+                }
             }
             const int M = N - k0 - nb;
             if (M > 0) {
@@ -1183,8 +1416,10 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
                 if (OW) { cend = (k0 / OW + 1) * OW; if (cend > N) cend = N; }
                 const int nt = (M + 31) / 32;
                 const int ntx = (cend - (k0 + nb) + 31) / 32;
-                if (ntx > 0 && !ll)
-                    hipLaunchKernelGGL(syrk_trailing_kernel, dim3(ntx < nt ? ntx : nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb, cend);
+                if (ntx > 0 && !ll) {
+                    if (fuse_next) hipLaunchKernelGGL(syrk_trailing_potrf_kernel, dim3(nt, nt, D), dim3(NB * NB), 0, s, h->gram.p, h->linv.p, N, k0, nb, h->info);
+                    else hipLaunchKernelGGL(syrk_trailing_kernel, dim3(ntx < nt ? ntx : nt, nt, D), dim3(256), 0, s, h->gram.p, N, k0, nb, cend);
+                }
                 if (OW && k0 + nb == cend && cend < N) {             // outer panel [cend - OW, cend) complete: rank-OW update of the rest
                     if (tile128) {
                         if ((rc = outer_update(cend))) return rc;
@@ -1195,9 +1430,16 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
                 }
             }
         }
-        if (k0 > 0 && !OW && !factored && !overlap_inv) {
+        if (k0 > 0 && !OW && !factored && !overlap_inv && !inv_cols) {
             hipLaunchKernelGGL(trinv_row_kernel, dim3((k0 + 31) / 32, D), dim3(256), 0, s, h->gram.p, h->linv.p, N, k0, nb, 0, 0, 0);
         }
+    }
+    if (inv_cols) {
+        const void* kern = reinterpret_cast<const void*>(trinv_colblock_kernel);
+        if ((rc = allow_full_lds(h, kern))) return rc;
+        const int nblk = (N + NB - 1) / NB;
+        const size_t lds = (size_t)(2 * 32 * 33 + (size_t)nblk * 32 * 32) * sizeof(double);
+        hipLaunchKernelGGL(trinv_colblock_kernel, dim3(nblk, D), dim3(256), lds, s, h->gram.p, h->linv.p, N);
     }
     if (overlap_inv) {                                    // join: what follows reads all of Y
         GPMPC_HIP_CHECK(h, hipEventRecord(h->ev_points, h->side_stream));

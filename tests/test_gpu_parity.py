@@ -156,6 +156,35 @@ def test_factorisation_ragged_sizes(engine, N, D, A):
     assert rel_err(beta.cpu().numpy(), beta0) < 1e-8
 
 
+@pytest.mark.parametrize("N,D,A", [(65, 2, 1), (257, 2, 1), (300, 3, 1), (352, 3, 2), (353, 2, 1), (400, 4, 2), (500, 2, 1), (544, 3, 1), (545, 2, 1), (639, 6, 2)])
+def test_panel_chain_forms_agree_bit_for_bit(N, D, A):
+    """The 32-wide panel path (240 < N < 640) in its forms (round 5): trailing update fused with the next diagonal block's factorisation
+    (`prepare_fuse`), L^-1 in one launch after the factorisation (`prepare_invcols`: 1 = up to N = 352, 2 = up to 544), row blocks of
+    L^-1 per side-stream launch (`prepare_inv_batch` 1 / 4), one or two streams (`prepare_overlap`) -- the same arithmetic in another
+    launch structure: identical factors, and the oracle's to 1e-8.  Sizes at the form boundaries and with a ragged last panel."""
+    import torch
+    import gp_mpc_amd
+    w = synth.make_workload(N, D, A, 3, 2, seed=N)
+    iK0, beta0 = orc.factorize(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    eng = gp_mpc_amd.HipEngine(0)
+    try:
+        eng.set_option("incremental", 0)
+        eng.set_option("fused_prepare", 0)                    # the panel chain also below its crossover with the single-launch kernel
+        ref = None
+        for fuse, invcols, batch, overlap in [(0, 0, 1, 0), (0, 0, 1, 1), (1, 0, 1, 1), (1, 0, 4, 1), (1, 0, 3, 1), (1, 2, 1, 1), (1, 1, 4, 1), (0, 2, 4, 0)]:
+            for k, v in (("prepare_fuse", fuse), ("prepare_invcols", invcols), ("prepare_inv_batch", batch), ("prepare_overlap", overlap)):
+                eng.set_option(k, v)
+            eng.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+            iK, beta = eng.factors()
+            if ref is None:
+                ref = (iK.clone(), beta.clone())
+                assert rel_err(iK.cpu().numpy(), iK0) < 1e-8 and rel_err(beta.cpu().numpy(), beta0) < 1e-8
+            else:
+                assert torch.equal(iK, ref[0]) and torch.equal(beta, ref[1]), (fuse, invcols, batch, overlap)
+    finally:
+        eng.close()
+
+
 LARGE = [(1024, 2, {}), (1025, 1, {}), (1151, 9, {}), (1300, 2, {}), (1300, 2, {"block128": 0}),
          (1300, 2, {"block128": 0, "inner_left": 0}), (1300, 2, {"tile128": 0}), (1300, 2, {"outer2": 0}),
          (1300, 2, {"outer2": 3}), (1300, 2, {"outer_block": 0}), (1700, 3, {"outer2": 1})]
