@@ -156,6 +156,8 @@ def main():
                     help="N > 1: how the per-rank winner records meet -- 'rccl_side' (default): one RCCL all_gather per step over xGMI "
                          "on a side stream behind an event, the compute stream never waits for it; 'host': after the device-to-host "
                          "copy, between the hosts over gloo (nothing on the GPU streams); 'rccl': the all_gather on the compute stream")
+    ap.add_argument("--no-batch-check", action="store_true",
+                    help="skip the alone-vs-in-batch bitwise check of the last candidate (config 5: one more 28 s launch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option for an A/B run (gpmpc_set_option; recorded in config.engine_options)")
@@ -275,31 +277,59 @@ def main():
         pend, out = launch(k)
         pend.result()
     use_dist = dist.is_initialized()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    inflight, read_host_s = [], []
-    for k in range(args.steps):
-        pend, out = launch(k)
-        inflight.append(pend)
-        if len(inflight) > depth:
+    if use_dist and world == 1 and exchange_note is None:
+        exchange_note = ("world 1: the exchange has no peer -- this line exercises the N > 1 code path only; at one rank the default "
+                         "'rccl_side' costs a few per cent per step (the single-rank gather's copy kernel competes with the next "
+                         "launch for a CU; DESIGN section 5), which says nothing about world > 1")
+    read_host_s = []
+
+    def timed_window():
+        """EXACTLY args.steps steps bracketed by barrier + synchronize on both sides; returns (max over ranks, local) seconds."""
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        inflight = []
+        last = None
+        for k in range(args.steps):
+            pend, _ = launch(k)
+            inflight.append(pend)
+            if len(inflight) > depth:
+                p0 = inflight.pop(0)
+                last = p0.result()
+                read_host_s.append(p0.host_seconds)
+        while inflight:
             p0 = inflight.pop(0)
-            best_J, best_i, best_act = p0.result()
+            last = p0.result()
             read_host_s.append(p0.host_seconds)
-    while inflight:
-        p0 = inflight.pop(0)
-        best_J, best_i, best_act = p0.result()
-        read_host_s.append(p0.host_seconds)
-    torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        el_max = el
+        if use_dist:
+            tmax = torch.tensor([el], dtype=torch.float64, device=device)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el_max = float(tmax.item())
+        return el_max, el, last
+
+    # The timed region of the contract is ONE window of --steps steps.  With sub-millisecond steps that window is a few
+    # milliseconds and one slow launch moves the line by several per cent (VERDICT r4, weak 11), so short windows are repeated
+    # inside the same run and the line reports the MEDIAN window (`windows` holds every window and their spread); every rank
+    # takes the same decision from the same estimate (rank-0's, broadcast).
+    n_windows = 1
+    est = torch.tensor([est_step_ms], dtype=torch.float64, device=device)
     if use_dist:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed_local = elapsed
-    if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        dist.broadcast(est, src=0)
+    if float(est.item()) * args.steps < 400.0:
+        n_windows = 5
+    windows = []
+    for _ in range(n_windows):
+        el_max, el_loc, (best_J, best_i, best_act) = timed_window()
+        windows.append((el_max, el_loc))
+    order = sorted(range(n_windows), key=lambda i: windows[i][0])
+    elapsed, elapsed_local = windows[order[n_windows // 2]]
+    out = bufs["out"]
 
     # the same step with the winner read BEFORE the next launch is enqueued (depth 0): what a closed-loop user pays
     closed_loop_ms = None
@@ -388,6 +418,10 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            # every timed window of --steps steps of this run (ms per step, max over ranks, in run order); `value` and
+            # `ms_per_step` are the median window
+            "windows": {"n": n_windows, "ms_per_step": [wd[0] / args.steps * 1e3 for wd in windows],
+                        "spread": (max(wd[0] for wd in windows) - min(wd[0] for wd in windows)) / elapsed},
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
@@ -487,6 +521,20 @@ def main():
                                     "vs": f"CPU oracle (validated against reference goldens), {len(sub)} candidate(s)"}
         except Exception as e:   # the bench number must not depend on the checker
             result["parity"] = {"error": repr(e)}
+        # batch independence at THIS batch size: the last candidate of the launch, launched alone, must give the same trajectory
+        # bit for bit (the tests check it at small shapes; config 5 at its per-GPU batch was only ever compared on candidate 0)
+        try:
+            if not args.no_batch_check and Bg > 1:
+                in_batch = {k: out[k][Bg - 1].clone() for k in ("mu", "Sig", "J")}
+                alone = eng.rollout(actions[Bg - 1:Bg].contiguous(), w.mu0, w.S0, w.include_time, w.time0)
+                result["parity"]["batch_independence"] = {
+                    "candidate": Bg - 1, "batch": Bg,
+                    "bitwise_equal_alone_vs_in_batch": bool(all(torch.equal(alone[k][0], in_batch[k]) for k in ("mu", "Sig", "J")))}
+                assert result["parity"]["batch_independence"]["bitwise_equal_alone_vs_in_batch"], "candidate differs alone vs in the batch"
+        except AssertionError:
+            raise
+        except Exception as e:   # noqa: BLE001
+            result["parity"]["batch_independence"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             from oracle.unfused_torch import time_rollouts
             default_threads = torch.get_num_threads()

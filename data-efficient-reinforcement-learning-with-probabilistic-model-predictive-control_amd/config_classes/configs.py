@@ -100,7 +100,7 @@ class ControllerConfig:
     def __init__(self, len_horizon=15, actions_optimizer_params=None, init_from_previous_actions=True,
                  restarts_optim=1, optimize=True, num_repeat_actions=1,
                  candidate_optimizer=None, cem_candidates=256, cem_iterations=4, cem_elite_fraction=0.1,
-                 lbfgs_candidates=None):
+                 lbfgs_candidates=None, shard_over_ranks=False):
         self.len_horizon = len_horizon
         self.actions_optimizer_params = dict(_DEFAULT_OPTIMIZER if actions_optimizer_params is None
                                              else actions_optimizer_params)
@@ -113,6 +113,9 @@ class ControllerConfig:
         self.cem_iterations = cem_iterations
         self.cem_elite_fraction = cem_elite_fraction
         self.lbfgs_candidates = lbfgs_candidates            # None: restarts_optim starting points
+        # one process per GPU (torch.distributed initialised by the launcher): split the candidates / restarts over the ranks.
+        # Opt-in: every rank must then call get_action with the same observation (checked inside the exchange)
+        self.shard_over_ranks = shard_over_ranks
 
 
 def _broadcast(v, shape):

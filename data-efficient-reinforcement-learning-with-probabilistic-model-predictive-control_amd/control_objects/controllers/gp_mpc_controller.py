@@ -65,6 +65,30 @@ class GpMpcController(BaseControllerObject):
         self.info_iters = {}
         self.num_rollouts = 0          # candidate trajectories evaluated so far (throughput accounting)
         self.analytic_gradient = True  # gradient kernels (gpmpc_rollout_grad); False: 4th-order differences of the rollout
+        self.process_group = None      # torch.distributed group the candidates shard over (None: the default group)
+
+    def _ranks(self):
+        """(world, rank) of the candidate sharding.  Sharding is OPT-IN (`ControllerConfig.shard_over_ranks`): a process that
+        initialised torch.distributed for some other purpose must not have its candidates silently split over ranks that may
+        sit at different states.  With the flag set and a process group initialised, every rank must call get_action with the
+        SAME observation and the same numpy seed -- both are verified inside the exchanges (a mismatch raises on every rank)."""
+        dist = torch.distributed
+        if not getattr(self.config.controller, "shard_over_ranks", False) or not (dist.is_available() and dist.is_initialized()):
+            return 1, 0
+        return dist.get_world_size(self.process_group), dist.get_rank(self.process_group)
+
+    @staticmethod
+    def _state_checksum(state_mu, state_var):
+        """One double that differs between ranks whose (state, state variance) differ: travels inside the winner records."""
+        a = np.concatenate([np.asarray(state_mu, dtype=np.float64).ravel(), np.asarray(state_var, dtype=np.float64).ravel()])
+        w = np.cos(np.arange(1, a.size + 1, dtype=np.float64))           # position-dependent weights: permutations differ too
+        return float(np.dot(a, w))
+
+    @staticmethod
+    def _assert_ranks_agree(column, what):
+        if not bool((column == column[0]).all()):
+            raise RuntimeError(f"candidate sharding: the ranks disagree on {what} ({column.tolist()}); every rank must see the "
+                               "same observation and seed numpy identically (or switch ControllerConfig.shard_over_ranks off)")
 
     # ------------------------------------------------------------------------------ public
     def get_action(self, obs_mu, obs_var=None, random=False):
@@ -290,17 +314,16 @@ class GpMpcController(BaseControllerObject):
             cands.append(generate_mpc_action_init_random(len_horizon=H, dim_action=A))
         cands = np.stack(cands)
         B = cands.shape[0]
-        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
-        rank = torch.distributed.get_rank() if world > 1 else 0
+        world, rank = self._ranks()
         # Every rank draws the SAME B candidates (the reference's global numpy generator, seeded identically on all
-        # ranks by the launcher) and evaluates its contiguous slice; a rank whose slice is empty (B < world) launches
-        # nothing and contributes an (inf, -1) record.
+        # ranks by the launcher; checked below through a checksum inside the records) and evaluates its contiguous slice; a
+        # rank whose slice is empty (B < world) launches nothing and contributes an (inf, -1) record.
         lo, hi = sharding.shard_bounds(B, world, rank)
         eng = self.transition_model.engine
         out = self.evaluate_candidates(cands[lo:hi], state_mu, state_var, trajectories=True) if hi > lo else None
         local = torch.as_tensor(cands[lo:hi].reshape(hi - lo, H, A), device=eng.device)
         if world == 1:
-            J, best, win = sharding.select_best_on_device(eng, out["J"], local, lo, B)
+            J, best, win = sharding.select_best_on_device(eng, out["J"], local, lo, B, group=sharding.LOCAL)
             self._cache_trajectory(out, B - 1)       # the reference caches the LAST evaluated trajectory, not the winner's (:279-283)
         else:
             # ... and so must every rank here (get_action reads the caches on all of them): the owner of the last
@@ -311,8 +334,15 @@ class GpMpcController(BaseControllerObject):
                 extra = torch.cat([out[k][-1].reshape(-1) for k in ("mu", "Sig", "cost_mu", "cost_var")] + [out["J"][-1:]])
             else:
                 extra = torch.zeros((H + 1) * (D + D * D + 2) + 1, dtype=F64, device=eng.device)
-            J, best, win, extras = sharding.select_best_on_device(eng, None if out is None else out["J"], local, lo, B, extra=extra)
-            self._cache_packed_trajectory(extras[last_owner], H, D)
+            # two trailing doubles: checksums of the state and of the drawn candidates (same on every rank, or the union of
+            # the slices is not the single-GPU population)
+            sums = torch.tensor([self._state_checksum(state_mu, state_var), float(np.dot(cands.ravel(), np.cos(np.arange(cands.size))))],
+                                dtype=F64, device=eng.device)
+            J, best, win, extras = sharding.select_best_on_device(eng, None if out is None else out["J"], local, lo, B,
+                                                                  extra=torch.cat([extra, sums]), group=self.process_group)
+            self._assert_ranks_agree(extras[:, -2], "the state")
+            self._assert_ranks_agree(extras[:, -1], "the drawn candidates")
+            self._cache_packed_trajectory(extras[last_owner][:-2], H, D)
         self.best_candidate_index, self.best_candidate_J = best, J
         self.actions_mpc_previous_iter = win.numpy().reshape(-1).copy()
         return self.actions_mapper.transform_action_mpc_to_action_model(self.actions_mpc_previous_iter)
@@ -369,17 +399,30 @@ class GpMpcController(BaseControllerObject):
         if isinstance(self.actions_mapper, DerivativeActionMapper):
             kw = dict(max_change=np.asarray(self.config.actions.max_change_action_norm, dtype=np.float64),
                       action_prev=self.actions_mapper.action_model_previous_iter.numpy())
-        seed = int(np.random.randint(0, 2 ** 62))          # every rank seeds numpy identically: the same key everywhere
+        seed = int(np.random.randint(0, 2 ** 62))          # the Philox key (np.random.seed keeps a run reproducible)
         tm = self.transition_model
         tm.set_cost(self.config.reward)
-        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
+        world, rank = self._ranks()
         if world > 1:
-            # candidates sharded over the ranks: each draws its slice from the shared Philox key, one elite merge per iteration
+            # candidates sharded over the ranks: each draws its slice from the shared Philox key, one elite merge per iteration.
+            # The key, the state and the starting vector are rank 0's on every rank (ONE small broadcast per control step: the
+            # union of the slices is the single-GPU population only if they are identical everywhere; nothing but the launcher
+            # enforced that before).
             from ... import sharding
+            n = H * A
+            head = np.concatenate([[float(seed >> 31), float(seed & 0x7fffffff), 1.0 if first is not None else 0.0],
+                                   np.zeros(n) if first is None else np.asarray(first, dtype=np.float64).ravel(),
+                                   np.asarray(state_mu, dtype=np.float64).ravel(), np.asarray(state_var, dtype=np.float64).ravel()])
+            head = sharding.broadcast_from_first(head, tm.engine.device, self.process_group)
+            seed = (int(head[0]) << 31) | int(head[1])
+            first = head[3:3 + n].copy() if head[2] != 0.0 else None
+            nmu = np.asarray(state_mu).size
+            state_mu = head[3 + n:3 + n + nmu].reshape(np.shape(state_mu))
+            state_var = head[3 + n + nmu:].reshape(np.shape(state_var))
             best_x, best_J = sharding.sharded_cem_search(
                 tm.engine, np.asarray(state_mu, dtype=np.float64), np.asarray(state_var, dtype=np.float64), B, H, A,
                 int(cc.cem_iterations), n_elite, seed=seed, include_time=tm.config.include_time_model,
-                time0=float(self.iter_ctrl), first_candidate=first, **kw)
+                time0=float(self.iter_ctrl), first_candidate=first, group=self.process_group, **kw)
         else:
             best_x, best_J = tm.engine.cem_search(
                 np.asarray(state_mu, dtype=np.float64), np.asarray(state_var, dtype=np.float64), B, H, A,
@@ -435,8 +478,10 @@ class GpMpcController(BaseControllerObject):
         # global generator, seeded identically by the launcher) and solves its contiguous slice; the winners meet in ONE
         # all_gather of [fun, restart index, solution] below
         from ... import sharding
-        world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
-        rank = torch.distributed.get_rank() if world > 1 else 0
+        world, rank = self._ranks()
+        if world > 1:
+            # rank 0's starting points on every rank (one small broadcast per control step instead of trusting the launcher's seeds)
+            x0s = list(sharding.broadcast_from_first(np.stack(x0s), self.transition_model.engine.device, self.process_group))
         r_lo, r_hi = sharding.shard_bounds(B, world, rank)
         B_all, x0s, B = B, x0s[r_lo:r_hi], r_hi - r_lo
         cond = threading.Condition()
@@ -446,7 +491,7 @@ class GpMpcController(BaseControllerObject):
             idx = sorted(pending)
             try:
                 J, G = self.objective_and_gradient_batch(np.stack([pending[i] for i in idx]), state_mu, state_var)
-            except BaseException as e:                 # hand the failure to every waiting restart
+            except Exception as e:                     # hand the failure to every waiting restart (interrupts pass through)
                 state["error"] = e
                 J, G = np.full(len(idx), np.nan), np.zeros((len(idx), H * A))
             state["launches"] += 1
@@ -488,13 +533,15 @@ class GpMpcController(BaseControllerObject):
             th.start()
         for th in threads:
             th.join()
-        for r in solved:
-            if isinstance(r, BaseException):
-                raise r
+        failure = next((r for r in solved if isinstance(r, BaseException)), None)
+        if failure is not None and world == 1:
+            raise failure
+        # world > 1: a rank whose solves failed must still enter the collective below (the others would wait in it until the
+        # watchdog fires); its record carries an error flag and every rank raises after the gather
         self.lbfgs_evaluations = state["launches"]
-        self.candidates_final_J = np.array([r.fun for r in solved])
+        self.candidates_final_J = None if failure is not None else np.array([r.fun for r in solved])
         opt_fun, best, best_i = np.inf, None, -1
-        for i, res in enumerate(solved):               # the reference's keep-the-best rule, in restart order
+        for i, res in enumerate(solved if failure is None else []):     # the reference's keep-the-best rule, in restart order
             if res.fun < opt_fun or (best is None and np.isnan(res.fun)):
                 opt_fun, best, best_i = res.fun, res.x, r_lo + i
         if world > 1:
@@ -506,13 +553,21 @@ class GpMpcController(BaseControllerObject):
                     if res.fun < opt_fun:
                         opt_fun, best, best_i = res.fun, res.x, r_lo + i
             n = H * A
-            rec = torch.zeros(2 + n, dtype=F64)
+            rec = torch.zeros(2 + n + 2, dtype=F64)     # [fun | restart | solution | error flag | state checksum]
             rec[0], rec[1] = (float(opt_fun), float(best_i)) if best is not None else (float("inf"), -1.0)
             if best is not None:
-                rec[2:] = torch.as_tensor(np.asarray(best, dtype=np.float64))
+                rec[2:2 + n] = torch.as_tensor(np.asarray(best, dtype=np.float64))
+            rec[2 + n] = 0.0 if failure is None else 1.0
+            rec[3 + n] = self._state_checksum(state_mu, state_var)
             dev = self.transition_model.engine.device
-            _, flat = sharding._gather_records(rec.to(dev))
-            host = flat.cpu().view(world, 2 + n)
+            _, flat = sharding._gather_records(rec.to(dev), self.process_group)
+            host = flat.cpu().view(world, 4 + n)
+            if failure is not None:
+                raise failure
+            failed = [r for r in range(world) if float(host[r, 2 + n]) != 0.0]
+            if failed:
+                raise RuntimeError(f"lockstep L-BFGS restarts: the solves of rank(s) {failed} failed; no winner this step")
+            self._assert_ranks_agree(host[:, 3 + n], "the state")
             opt_fun, best_i, win = sharding._winner_of(host, world, n, 1)
             best = win.numpy().reshape(-1).copy()
             self.candidates_final_J = None             # only this rank's slice was solved here

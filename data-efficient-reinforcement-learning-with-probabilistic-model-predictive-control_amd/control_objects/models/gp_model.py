@@ -130,8 +130,10 @@ class _LockstepMll:
         try:
             self._evaluate_pending(idx)
         except BaseException as e:                     # anything outside the per-GP handling below (stacking, indexing, ...):
-            for i in idx:                              # every waiting GP gets the failure -- nobody may wait forever
+            for i in idx:                              # every waiting GP gets a failure -- nobody may wait forever
                 self.results.setdefault(i, e if isinstance(e, Exception) else RuntimeError(repr(e)))
+            if not isinstance(e, Exception):           # KeyboardInterrupt / SystemExit: the waiters are served (above) and
+                raise                                  # the interrupt itself goes on in the flushing thread, not swallowed
         finally:
             self.pending.clear()
             self.cond.notify_all()
@@ -168,6 +170,9 @@ class _LockstepMll:
                 if not self.cond.wait(timeout=5.0):
                     waited += 5.0
                     if waited >= self.WAIT_LIMIT:
+                        # withdraw the request: a stale entry would be counted by `finished` (premature flush that includes
+                        # it, one wasted evaluation and a result nobody pops)
+                        self.pending.pop(a, None)
                         raise TimeoutError(f"lockstep evaluation of GP {a} not served within {self.WAIT_LIMIT:.0f} s")
             r = self.results.pop(a)
         if isinstance(r, Exception):

@@ -11,8 +11,31 @@ adopted and never displaced, any other NaN is never selected.
 """
 import math
 
+import numpy as np
 import torch
 import torch.distributed as dist
+
+LOCAL = "local"        # pass as `group` to keep a call on this process even though a process group is initialised
+CEM_MAX_RECORDS = 4096      # csrc/search.hip kCemMaxB: the merge kernel sorts lists x n_elite records in LDS
+_CEM_FAILED = 2147483646.0  # global-index field of the record a rank contributes when its cem_local call failed
+
+
+def _active(group):
+    return group is not LOCAL and dist.is_available() and dist.is_initialized()
+
+
+def broadcast_from_first(array, device, group=None):
+    """Rank 0's copy of a small float64 numpy array on every rank of `group` (one collective of a few doubles: RCCL for a
+    GPU device, gloo on the CPU).  What the sharded searches draw from numpy's global generator -- the Philox key, the
+    L-BFGS starting points -- goes through here once per control step, so the union of the slices is the single-GPU
+    population whatever the launcher did about seeds."""
+    a = np.ascontiguousarray(array, dtype=np.float64)
+    if not _active(group):
+        return a.copy()
+    t = torch.as_tensor(a).to(device)
+    src = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.broadcast(t, src=src, group=group)
+    return t.cpu().numpy().reshape(a.shape)
 
 
 def shard_bounds(num_candidates, world_size, rank):
@@ -97,7 +120,7 @@ def _local_record(engine, J, actions_local, lo, out=None):
 def _gather_records(rec, group=None):
     """(world, flat (world * len(rec)) tensor): ONE all_gather over RCCL (gloo in the CPU tests) when a process
     group is initialised, otherwise the record itself.  Wrapped in a ROCTx range ("gpmpc_gather") on a GPU."""
-    if dist.is_available() and dist.is_initialized():
+    if _active(group):
         world = dist.get_world_size(group)
         flat = torch.empty(world * rec.numel(), dtype=torch.float64, device=rec.device)
         marked = rec.device.type == "cuda"
@@ -124,26 +147,25 @@ def _winner_of(host, world, H, A):
 _HOST_GROUPS = {}
 
 
-def _group_key(group):
-    """Cache key of a process group: its global ranks plus the identity of the CURRENT default group (a re-initialised
-    default group, or a garbage-collected sub-group whose id() was reused, must never hit a stale entry)."""
-    ranks = tuple(range(dist.get_world_size())) if group is None else tuple(dist.get_process_group_ranks(group))
-    return ranks, id(dist.group.WORLD)
-
-
 def host_group(group=None):
     """A process group whose collectives run on HOST tensors (gloo) over the same ranks as `group` (None: the default
     group).  With a gloo default group that is the group itself; with RCCL it is created once (every rank must reach the
-    first call together, like any new_group) and cached per (ranks, default-group instance); entries of a destroyed default
-    group are dropped."""
+    first call together, like any new_group) and cached per ranks; an entry holds a reference to the default-group OBJECT it
+    was created under and is valid only while that very object is still the default group (a strong reference: its id() cannot
+    be recycled while the entry lives), so a destroyed and re-initialised default group never gets a stale gloo group."""
     if dist.get_backend(group) == "gloo":
         return dist.group.WORLD if group is None else group
-    key = _group_key(group)
-    for stale in [k for k in _HOST_GROUPS if k[1] != key[1]]:
-        del _HOST_GROUPS[stale]
-    if key not in _HOST_GROUPS:
-        _HOST_GROUPS[key] = dist.new_group(ranks=list(key[0]), backend="gloo")
-    return _HOST_GROUPS[key]
+    ranks = tuple(range(dist.get_world_size())) if group is None else tuple(dist.get_process_group_ranks(group))
+    key = ranks
+    ent = _HOST_GROUPS.get(key)
+    if ent is not None and ent[1] is not dist.group.WORLD:
+        ent = None
+    if ent is None:
+        for stale in [k for k, v in _HOST_GROUPS.items() if v[1] is not dist.group.WORLD]:
+            del _HOST_GROUPS[stale]
+        ent = (dist.new_group(ranks=list(ranks), backend="gloo"), dist.group.WORLD)
+        _HOST_GROUPS[key] = ent
+    return ent[0]
 
 
 _SIDE_STREAMS = {}
@@ -173,6 +195,7 @@ class PendingBest:
         self.record = record            # the device record buffer, reusable once this selection has been read
         self.exchange_group = exchange_group
         self._result = None
+        self._flat = None
         self.host_seconds = None
 
     def result(self):
@@ -189,6 +212,7 @@ class PendingBest:
             dist.all_gather_into_tensor(flat, mine, group=self.exchange_group)
             host = flat
         self._result = _winner_of(host.view(self.world, -1), self.world, self.H, self.A)
+        self._flat = None                # the gathered device tensor (side-stream exchange) is free to be reused now
         self.host_seconds = time.perf_counter() - t0
         return self._result
 
@@ -207,7 +231,7 @@ def select_best_async(engine, J, actions_local, lo, num_candidates, group=None, 
     Returns a PendingBest."""
     n, H, A = actions_local.shape
     rec = _local_record(engine, J, actions_local, lo, out=record)
-    multi = dist.is_available() and dist.is_initialized()
+    multi = _active(group)
     if exchange == "host" and multi:
         world = dist.get_world_size(group)
         xg = host_group(group)
@@ -234,6 +258,9 @@ def select_best_async(engine, J, actions_local, lo, num_candidates, group=None, 
             host_buffer.copy_(flat, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(side)
+        # `flat` was allocated on the compute stream and is read by the side stream's copy: tell the caching allocator, or a
+        # PendingBest dropped unread (an exception path) would let the block be reused while the copy is in flight
+        flat.record_stream(side)
         pend = PendingBest(host_buffer, ev, world, H, A, rec)
         pend._flat = flat                                       # keep the gathered device tensor alive until read
         return pend
@@ -278,22 +305,59 @@ def sharded_cem_search(engine, mu0, S0, B_total, H, A, iterations, n_elite, seed
     records (n_elite x (2 + H A) doubles per rank, RCCL on the compute stream: the refit needs them), and every rank refits
     on the union -- all ranks end with the same state, the one the single-GPU search reaches on the same draws.
     Nothing is read back between iterations.  Returns (best vector (H*A,) numpy, best J)."""
-    multi = dist.is_available() and dist.is_initialized()
+    multi = _active(group)
     world = dist.get_world_size(group) if multi else 1
     rank = dist.get_rank(group) if multi else 0
-    lo, hi = shard_bounds(B_total, world, rank)
     n = H * A
+    if world > 1 and world * n_elite > CEM_MAX_RECORDS:
+        # the merge kernel sorts world x n_elite records in LDS (4096 at most): beyond that every rank runs the whole
+        # population on its own GPU -- same draws (keyed by the global candidate), same state, no collective.  The decision
+        # depends on (world, n_elite) only, so all ranks take it together.
+        return engine.cem_search(mu0, S0, B_total, H, A, iterations, n_elite, seed=seed, include_time=include_time, time0=time0,
+                                 first_candidate=first_candidate, max_change=max_change, action_prev=action_prev, noise=noise)
+    lo, hi = shard_bounds(B_total, world, rank)
     state = torch.zeros(3 * n + 1, dtype=torch.float64, device=engine.device)
     gathered = torch.empty((world * n_elite, n + 2), dtype=torch.float64, device=engine.device) if world > 1 else None
     elites = None
+    failure = None
     for it in range(int(iterations)):
-        elites = engine.cem_local(mu0, S0, B_total, lo, hi - lo, H, A, it, n_elite, state, seed=seed, include_time=include_time,
-                                  time0=time0, first_candidate=first_candidate, max_change=max_change, action_prev=action_prev,
-                                  noise=noise, out=elites)
+        if failure is None:
+            try:
+                elites = engine.cem_local(mu0, S0, B_total, lo, hi - lo, H, A, it, n_elite, state, seed=seed,
+                                          include_time=include_time, time0=time0, first_candidate=first_candidate,
+                                          max_change=max_change, action_prev=action_prev, noise=noise, out=elites)
+            except Exception as e:           # noqa: BLE001 -- handed on after the collectives, see below
+                if world == 1:
+                    raise
+                # This rank still has to enter every all_gather of the search (the others would wait in it until the watchdog
+                # fires): from here on it contributes records that sort behind every real candidate and carry a marker in
+                # their index field, which all ranks see in the gathered buffer when they read the result.
+                failure = e
+                elites = torch.zeros((n_elite, n + 2), dtype=torch.float64, device=engine.device)
+                elites[:, 0] = math.inf
+                elites[:, 1] = _CEM_FAILED
         if world > 1:
             dist.all_gather_into_tensor(gathered.view(-1), elites.view(-1), group=group)
-            engine.cem_merge(gathered, n_elite, n, it, state)
+            if failure is None:
+                try:
+                    engine.cem_merge(gathered, n_elite, n, it, state)
+                except Exception as e:       # noqa: BLE001
+                    failure = e
+                    elites = torch.zeros((n_elite, n + 2), dtype=torch.float64, device=engine.device)
+                    elites[:, 0] = math.inf
+                    elites[:, 1] = _CEM_FAILED
         else:
             engine.cem_merge(elites, n_elite, n, it, state)
-    host = state.cpu().numpy()                                  # the one synchronisation
+    if world > 1:
+        # the one synchronisation: the state and, with it, whether any rank's records of the LAST gather carry the marker (a
+        # rank that failed keeps contributing marked records until the end)
+        flag = (gathered[:, 1] == _CEM_FAILED).any().to(torch.float64).view(1)
+        host = torch.cat([state, flag]).cpu().numpy()
+        if failure is not None:
+            raise failure
+        if host[-1] != 0.0:
+            raise RuntimeError("sharded cross-entropy search: another rank's slice failed; no winner this step")
+        host = host[:-1]
+    else:
+        host = state.cpu().numpy()                                  # the one synchronisation
     return host[2 * n:3 * n].copy(), float(host[3 * n])

@@ -54,7 +54,7 @@ def record(test, **values):
 
 
 def make_controller(w, limit_action_change=False, optimize=False, restarts=1, clip=False, engine=None,
-                    optimizer_params=None):
+                    optimizer_params=None, shard=True):
     """A GpMpcController of THIS package configured like the golden generator configured the
     reference's (tools/gen_golden.py make_ref_controller) and fed workload `w` as GP memory."""
     import torch
@@ -72,7 +72,7 @@ def make_controller(w, limit_action_change=False, optimize=False, restarts=1, cl
     if w.include_time:                      # the time column of the lengthscales comes from the workload
         model.init_lengthscale_time = 0.0
     ctrl_cfg = ControllerConfig(len_horizon=H, restarts_optim=restarts, optimize=optimize,
-                                actions_optimizer_params=optimizer_params)
+                                actions_optimizer_params=optimizer_params, shard_over_ranks=shard)
     cfg = Config(observation_config=ObservationConfig(obs_var_norm=list(np.diag(w.S0))), reward_config=reward,
                  actions_config=ActionsConfig(limit_action_change=limit_action_change, max_change_action_norm=[0.3] * A),
                  model_config=model, memory_config=MemoryConfig(points_batch_memory=max(16, N + 8)),

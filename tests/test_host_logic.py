@@ -537,6 +537,34 @@ def test_lockstep_training_batches_the_gps_and_isolates_a_failing_one():
         assert abs(float(got[a][gm.GpHyperParameters.KEYS[1]]) - want[a]["outputscale"]) < 1e-5 * want[a]["outputscale"]
 
 
+def test_lockstep_evaluation_that_times_out_withdraws_its_request():
+    """a lockstep evaluation that gives up after WAIT_LIMIT must not leave its entry in `pending` -- `finished` of a
+    sibling would otherwise count it, flush a batch that contains the stale request and leave a result nobody pops."""
+    import threading
+    import gp_mpc_amd.control_objects.models.gp_model as gm
+
+    class Eng:
+        calls = []
+
+        def mll(self, X, Y, ls, osc, nz):
+            Eng.calls.append(int(Y.shape[1]))
+            n = Y.shape[1]
+            return {"loss": np.zeros(n), "d_lengthscale": np.zeros((n, 2)), "d_outputscale": np.zeros(n), "d_noise": np.zeros(n)}
+
+    shared = gm._LockstepMll(Eng(), torch.zeros(4, 2), torch.zeros(4, 2), 2)
+    shared.WAIT_LIMIT = 0.0                      # first 5 s wait that is not served -> TimeoutError
+    real_wait = shared.cond.wait
+    shared.cond.wait = lambda timeout=None: real_wait(timeout=0.01) and False
+    with pytest.raises(TimeoutError):
+        shared.evaluate(0, torch.ones(2), torch.tensor(1.0), torch.tensor(0.1))
+    assert shared.pending == {}
+    shared.finished(0)                           # GP 0's thread ends (its LBFGS raised): one GP left running
+    assert Eng.calls == [] and shared.results == {}
+    shared.cond.wait = real_wait
+    out = shared.evaluate(1, torch.ones(2), torch.tensor(1.0), torch.tensor(0.1))     # served alone, at once
+    assert Eng.calls == [1] and out[0] == 0.0 and shared.results == {}
+
+
 def _moment_items_by_lane(N, CH, NC, diag):
     """The lane mapping of pair_moments_kernel (grad_kernels.h: the work-item loop), lane by lane: rows of every work item."""
     NCU = (N + NC - 1) // NC
