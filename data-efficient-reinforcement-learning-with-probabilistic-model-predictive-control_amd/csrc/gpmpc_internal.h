@@ -59,6 +59,7 @@ struct RolloutArgs {
     int RC;       // row chunks per column
     unsigned magic_N;        // ceil(2^32 / NC):  x / NC  == umulhi(x, magic_N), NC = N (or ceil(N / 2) with cols2)
     unsigned magic_wpp;      // ceil(2^32 / wpp): x / wpp == umulhi(x, magic_wpp)
+    unsigned magic_pt;       // ceil(2^32 / N):   x / N   == umulhi(x, magic_pt)  (per-point pass: item -> (problem, point))
     // batch-major path (pair_tile_kernel.h): the per-candidate kernel runs the horizon slice [t_begin, t_end) from the
     // state stored in mu_out / Sig_out and takes the diagonal pairs' sums from tile_part (B, D, ntiles)
     int tiled;               // host side: 1 = launch the TILED instantiation

@@ -270,7 +270,8 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     if (!gs) {
         // X^T in LDS when it is small next to the budget (<= 32 KiB) and the layout still fits
         for (int xl = ((size_t)E * N * 8 <= 32 * 1024) ? 1 : 0; xl >= 0 && G == 0; --xl) {
-            for (int g = Pg; g >= 1; --g) {
+            // (at most 48 pairs per group: one wavefront builds the step's work-item list, a lane per pair and per mean sum)
+            for (int g = Pg < 48 ? Pg : 48; g >= 1; --g) {
                 chunking(g);
                 const int wpp = (RC * NCu + 63) / 64;
                 Layout L = make_layout(N, D, A, E, g, DP, wpp, CM, CH, a.H * A, xl != 0);
@@ -280,7 +281,7 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
                 }
             }
             // prefer all pairs in one group over the X^T copy
-            if (G != 0 && G < Pg && xl == 1) { G = 0; }
+            if (G != 0 && G < (Pg < 48 ? Pg : 48) && xl == 1) { G = 0; }
         }
         if (G == 0) { gs = true; tiled = false; }
     }
@@ -312,8 +313,13 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         auto magic = [](unsigned d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ULL + d - 1) / d); };
         a.magic_N = magic((unsigned)NCf);
         a.magic_wpp = magic(wppv);
-        if ((unsigned long long)RC * NCf * NCf >= 0x100000000ULL || (unsigned long long)G * wppv * wppv >= 0x100000000ULL) {
+        a.magic_pt = magic((unsigned)N);
+        if ((unsigned long long)RC * NCf * NCf >= 0x100000000ULL || (unsigned long long)G * wppv * wppv >= 0x100000000ULL ||
+            (!gs && (unsigned long long)(D + 2 * P) * N * N >= 0x100000000ULL)) {      // magic_pt: the fused-horizon kernel only
             h->err = "rollout: index range too large for the multiply-high division"; return GPMPC_ERR_LIMIT;
+        }
+        if (!gs && (unsigned long long)G * wppv >= 65000ULL) {     // 16-bit entries of the step's work-item list
+            h->err = "rollout: too many work-item slots for the 16-bit item list"; return GPMPC_ERR_LIMIT;
         }
     }
 

@@ -101,8 +101,10 @@ constexpr int kMaxMono = 256;      // most monomials of the separable (off-diago
 
 // ------------------------------------------------------------------------------------------
 // LDS / scratch layout (offsets in doubles), shared by host (sizing) and device (carving).
+constexpr int kLaneMapSlots = 32;  // most work-item slots of a diagonal pair whose lane assignment is tabulated in LDS
+
 struct Layout {
-    int mu, Sig, m, M, cc, s1, Vs, Sp, misc, rdet, aug, part, mom, ints;
+    int mu, Sig, m, M, cc, s1, Vs, Sp, misc, rdet, aug, part, mom, ints, lmap;
     int c_ils2, c_logvar, c_var, c_xr, c_act, c_exptab, c_monow, c_monoe, c_X;    // read-only tables copied to LDS once
     int lds_total;     // doubles of LDS
     // per-point arrays (LDS)
@@ -130,7 +132,12 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     L.aug = o;  o += (D + G) * 2 * D * D;       // D mean problems + G pair problems, [A | RHS]
     L.part = o; o += rnd2(G * wpp);
     L.mom = o;  o += G * 2 * rnd2(CM);
-    L.ints = o; o += rnd2((2 * P + 2 * G + 6 + 16 + ((N + 15) / 16 + 2) + 1) / 2);   // pa[P], pb[P], K[G], counter, noff, off[G], mcum[16], tri[RC+1] (ints)
+    // pa[P], pb[P], K[G], counter, noff, off[G], mcum[16], tri[RC+1], nslot[G], nitems (ints); then the step's work-item list
+    // (16-bit entries: D mean items + at most G * wpp pair items)
+    L.ints = o; o += rnd2((2 * P + 3 * G + 8 + 16 + ((N + 15) / 16 + 2) + 1) / 2) + rnd2((D + G * wpp + 3) / 4);
+    // lane map of the diagonal pairs' work items: (row chunk, column unit) per (slot, lane) + rows per slot, for up to
+    // kLaneMapSlots slots (state-independent: filled once per launch)
+    L.lmap = o; o += rnd2(((wpp < kLaneMapSlots ? wpp : kLaneMapSlots) * 65 + 1) / 2);
     L.c_ils2 = o;   o += rnd2(D * E);
     L.c_logvar = o; o += rnd2(D);
     L.c_var = o;    o += rnd2(D);
@@ -764,13 +771,22 @@ __device__ inline void sep3_band(int lane, int N, int side, const double* rec0, 
                 wx *= x0;
             }
         }
+        // lane partials -> totals, sixteen (eight) at a time on the permlane / DPP exchange network (wave_reduce16: 57 vector
+        // instructions, no LDS round trip; the ds_bpermute butterflies of wave_sum8 took ~70 instructions and six dependent LDS
+        // round trips per EIGHT values -- the reductions were more than half of a low-degree item)
         static constexpr Sep3Canon<KS, B> canon{};
-        const int mm = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
+        const int mq = lane >> 2;
 #pragma unroll
-        for (int g8 = 0; g8 < NP; g8 += 8) {
+        for (int g16 = 0; g16 + 16 <= NP; g16 += 16) {
+            const double(&grp)[16] = *reinterpret_cast<const double(*)[16]>(&acc[g16]);
+            const double tot = wave_reduce16(grp);
+            if ((lane & 3) == 0 && g16 + mq < NBm) mom[canon.v[g16 + mq]] = tot;
+        }
+        if constexpr (NP % 16 != 0) {
+            constexpr int g8 = NP - 8;
             const double(&grp)[8] = *reinterpret_cast<const double(*)[8]>(&acc[g8]);
-            const double tot = wave_sum8(grp, lane);
-            if (lane < 8 && g8 + mm < NBm) mom[canon.v[g8 + mm]] = tot;
+            const double tot = wave_reduce8(grp);
+            if ((lane & 3) == 0 && lane < 32 && g8 + mq < NBm) mom[canon.v[g8 + mq]] = tot;
         }
     }
 }
@@ -855,7 +871,22 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     int* s_off = s_noff + 1;
     int* s_mcum = s_off + G;                // monomials of degree <= k (copy of the launch argument: LDS instead of a kernarg load on the serial path)
     int* s_tri = s_mcum + 16;               // diagonal pairs: column units of row chunks < r that can hold an element i <= j
+    int* s_nslot = s_tri + ((N + 15) / 16 + 2);     // work-item slots of each pair of the group that hold work at this step
+    int* s_nitems = s_nslot + G;            // length of the step's work-item list
+    // The work-item list of the step (built by one thread beside the per-point pass, read by the queue of P3): only slots
+    // that hold work -- a diagonal pair uses the slots of its triangle, a separable pair one slot per (side, monomial band) --
+    // long items (element-wise pairs) first, the short mean sums last.  Entry = pair slot index gq * wpp + slot, or
+    // 0xffff - a for the mean sums of output a.  (Until round 5 the queue walked all G * wpp slots: at config 2, 36 of 69
+    // pulls per step found nothing to do, each after the lane set-up of an item.)
+    unsigned short* s_items = reinterpret_cast<unsigned short*>(
+        smem + L.ints + rnd2((2 * P + 3 * G + 8 + 16 + ((N + 15) / 16 + 2) + 1) / 2));
 
+    // Lane map of a diagonal pair's work items (slot, lane) -> (row chunk | column unit << 8), -1 = no element, and the row count
+    // of each slot: the triangle's enumeration does not depend on the state, so the per-item binary search over s_tri and the
+    // wavefront maximum of the lanes' row counts are done ONCE per launch (at config 2 they were ~70 of an item's ~250 set-up
+    // instructions, 18 items per step).
+    [[maybe_unused]] int* s_lmap = reinterpret_cast<int*>(smem + L.lmap);
+    [[maybe_unused]] int* s_lrows = s_lmap + (wpp < kLaneMapSlots ? wpp : kLaneMapSlots) * 64;
     double* ppbase = smem;                  // per-point arrays live in LDS (large N: rollout_stream_kernel.h)
     double* a_nu = ppbase + L.nu;           // [d][p]
     double* a_lb = ppbase + L.lb;           // [a][p]
@@ -914,6 +945,40 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
         }
     }
     __syncthreads();
+#if !defined(GPMPC_NO_LANEMAP)
+    bool use_lmap = false;
+    if constexpr (!TILED) {
+        const int wtri = (s_tri[p.RC] + 63) >> 6;
+        use_lmap = wtri <= kLaneMapSlots && wtri <= wpp;
+        if (use_lmap) {
+            for (int slot = tid >> 6; slot < wtri; slot += NW) {
+                const int flat = slot * 64 + (tid & 63);
+                const bool valid = flat < s_tri[p.RC];
+                int lo = 0, hi = p.RC;                         // invariant: s_tri[lo] <= flat < s_tri[hi]
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_tri[mid] <= flat) lo = mid; else hi = mid;
+                }
+                const int r = valid ? lo : 0;
+                const int first = C2 ? (r * p.CH) / 2 : r * p.CH;
+                const int jc = valid ? first + (flat - s_tri[r]) : 0;
+                const int j = C2 ? 2 * jc : jc;
+                const int jl = (C2 && (j + 1 < N)) ? j + 1 : j;
+                const int i0 = r * p.CH;
+                int i1 = i0 + p.CH;
+                if (i1 > N) i1 = N;
+                if (i1 > jl + 1) i1 = jl + 1;
+                const int len = (valid && i1 > i0) ? (i1 - i0) : 0;
+                const int nrows = (wave_max_i32(len) + 3) & ~3;
+                s_lmap[flat] = valid ? (r | (jc << 8)) : -1;
+                if ((tid & 63) == 0) s_lrows[slot] = nrows;
+            }
+        }
+        __syncthreads();
+    }
+#else
+    constexpr bool use_lmap = false;
+#endif
     GPMPC_TRACE(1);
     if constexpr (!TILED) {
         for (int i = tid; i < D; i += NT) p.mu_out[((size_t)c * (H + 1)) * D + i] = s_mu[i];
@@ -1120,8 +1185,49 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
             // mean part (output a), row side of a pair (u, g = Z^T u, ka'), column side of an off-diagonal pair (w, kb');
             // for a diagonal pair the column factor is the row factor.
             const int n_off = *s_noff;
-            for (int it = tid; it < (nmean + Gc + n_off) * N; it += NT) {
-                const int prob = it / N, pt = it - prob * N;
+            if (wave == NW - 1) {
+                // Work-item list of this group (the Taylor degrees / evaluation forms of P1 are visible after the barrier), built
+                // by the lanes of ONE wavefront in parallel: lane l < Gc owns pair l, the next nmean lanes a mean-sum item each
+                // (Gc + nmean <= 64: the host caps G).  Classes in list order: element-wise pairs, separable pairs, mean sums.
+                // (A first version built the list on one thread: ~40 dependent LDS round trips, 4.3 k cycles per step.)
+                const int wtri = (s_tri[p.RC] + 63) >> 6;
+                const int R = Gc + nmean;
+                int ns = 0, cls = 3, code0 = 0;
+                if (lane < Gc) {
+                    const int Kr = s_K[lane];
+                    const bool sep = (Kr & 64) != 0;
+                    if (sep) {
+                        const int Ks = Kr & 63;
+                        const int two = (DX == 3) ? 2 * sep3_bands(Ks <= 3 ? 3 : Ks) : 2 * ((s_mcum[Ks] + 7) >> 3);
+                        ns = two < wpp ? two : wpp;
+                    } else {
+                        ns = (s_pa[q0 + lane] == s_pb[q0 + lane]) ? wtri : wpp;
+                    }
+                    cls = sep ? 1 : 0;
+                    code0 = lane * wpp;
+                    s_nslot[lane] = ns;
+                } else if (lane < R) {
+                    ns = 1; cls = 2; code0 = 0xffff - (lane - Gc);
+                }
+                // start = items of all entries that come before this lane's in (class, lane) order
+                int start = 0, total_items = 0;
+                for (int m = 0; m < R; ++m) {
+                    const int nsm = __builtin_amdgcn_readlane(ns, m);
+                    const int clm = __builtin_amdgcn_readlane(cls, m);
+                    start += (clm < cls || (clm == cls && m < lane)) ? nsm : 0;
+                    total_items += nsm;
+                }
+                for (int k = 0; k < ns; ++k) s_items[start + k] = (unsigned short)(cls == 2 ? code0 : code0 + k);
+                if (lane == 0) *s_nitems = total_items;
+            }
+            // The per-point items go to all wavefronts but the last one, which builds the work-item list above beside them (with
+            // items of its own it was the last to reach the barrier: + 1.9 k cycles per step at config 2); narrow workgroups
+            // (fewer than 8 wavefronts) share the items among all.
+            const int p2_threads = (NW >= 8) ? NT - 64 : NT;
+#if defined(GPMPC_P2_SERIAL)
+            for (int it = tid; it < (nmean + Gc + n_off) * N && tid < p2_threads; it += p2_threads) {
+                const int prob = p.magic_pt ? (int)__umulhi((unsigned)it, p.magic_pt) : it;      // it / N
+                const int pt = it - prob * N;
                 double nu[DP];
 #pragma unroll
                 for (int d = 0; d < DP; ++d) nu[d] = (d < D) ? (Xs[d * N + pt] - s_m[d]) : 0.0;
@@ -1205,22 +1311,181 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     }
                 }
             }
+#else
+            // Three items per thread and trip -- two pair-side items (row / column side of a pair: u, g = Z^T u, u^T Z u, one exp)
+            // and one mean-part item (nu^T A^-1 nu, one exp) -- written stage by stage for all three, so that their dependent
+            // chains interleave.  A dependent fp64 instruction issues only every ~40 cycles (tools/microbench/mfma_f64_rate), a
+            // chain is ~45 of them, and with one item at a time the pass ran at 36 % of its issue rate: 2.3 rounds of ~2.3 k
+            // cycles each at config 2.  Per item the operations and their order are those of the serial form (-DGPMPC_P2_SERIAL),
+            // so the results are bitwise the same.
+            {
+                const int npi = (Gc + n_off) * N, nmi = nmean * N;
+                for (int base = tid; (base < npi || base < nmi) && tid < p2_threads; base += 2 * p2_threads) {
+                    // ---- indices
+                    int ptv[2], gqv[2], cv[2], Kv[2];
+                    bool rowv[2], diagv[2], actv[2];
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        int it = base + s * p2_threads;
+                        actv[s] = it < npi;
+                        it = actv[s] ? it : 0;                             // an idle slot repeats item 0 (no stores)
+                        const int prob = p.magic_pt ? (int)__umulhi((unsigned)it, p.magic_pt) : it;      // it / N
+                        ptv[s] = it - prob * N;
+                        rowv[s] = prob < Gc;
+                        const int gq = (rowv[s] || n_off == 0) ? (rowv[s] ? prob : 0) : s_off[prob - Gc];
+                        const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
+                        diagv[s] = (a == b);
+                        cv[s] = rowv[s] ? a : b;                           // the output whose lengthscales scale nu
+                        Kv[s] = s_K[gq] & 63;
+                        gqv[s] = gq;
+                    }
+                    // the mean item of this trip: items base, base + 2 p2_threads, ... of the nmi mean items go to the same
+                    // thread as the pair-side items of the trip (second half of the trip's index range: base + p2_threads)
+                    const int itm0 = base, itm1 = base + p2_threads;
+                    // (two mean items per trip would be a fourth chain; the mean items of [p2_threads, 2 p2_threads) are taken by
+                    //  a second, short loop below -- at config 2: 600 items, none left)
+                    const bool actm = itm0 < nmi;
+                    const int itm = actm ? itm0 : 0;
+                    const int am = p.magic_pt ? (int)__umulhi((unsigned)itm, p.magic_pt) : itm;
+                    const int ptm = itm - am * N;
+                    (void)itm1;
+                    // ---- nu, u, ks (pair sides); nu (mean)
+                    double u[2][DP], g[2][DP], ks[2], qq[2], kk[2], bc[2], ex[2];
+                    double num[DP], qm = 0.0;
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) num[d] = (d < D) ? (Xs[d * N + ptm] - s_m[d]) : 0.0;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        ks[s] = 0.0;                                       // sum_e nu_e^2 / l_e^2
+                        qq[s] = 0.0;
+#pragma unroll
+                        for (int d = 0; d < DP; ++d) {
+                            const double nud = (d < D) ? (Xs[d * N + ptv[s]] - s_m[d]) : 0.0;
+                            u[s][d] = nud * ((d < D) ? c_ils2[cv[s] * E + d] : 0.0);
+                            ks[s] = fma(nud, u[s][d], ks[s]);
+                            g[s][d] = 0.0;
+                        }
+                    }
+                    // ---- quadratic forms: i outer, the three chains inside
+                    const double* Ai = s_aug + am * (D * LD) + D;          // A_a^-1 of the mean item
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) {
+                        if (i < D) {
+                            double zu[2] = {0.0, 0.0};
+                            double r = 0.0;
+#pragma unroll
+                            for (int j = 0; j < DP; ++j)
+                                if (j < D) {
+                                    r = fma(Ai[i * LD + j], num[j], r);
+#pragma unroll
+                                    for (int s = 0; s < 2; ++s) {
+                                        const double z = s_aug[(D + gqv[s]) * (D * LD) + D + i * LD + j];
+                                        zu[s] = fma(z, u[s][j], zu[s]);
+                                        g[s][j] = fma(z, u[s][i], g[s][j]);      // g = Z^T u: cross term u^T Z w = g . w
+                                    }
+                                }
+                            qm = fma(num[i], r, qm);
+#pragma unroll
+                            for (int s = 0; s < 2; ++s) qq[s] = fma(u[s][i], zu[s], qq[s]);
+                        }
+                    }
+                    for (int e = D; e < E; ++e) {
+                        const double vm = Xs[e * N + ptm] - s_m[e];
+                        qm = fma(vm * vm, c_ils2[am * E + e], qm);
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) {
+                            const double v = Xs[e * N + ptv[s]] - s_m[e];
+                            ks[s] = fma(v * v, c_ils2[cv[s] * E + e], ks[s]);
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        kk[s] = c_logvar[cv[s]] - 0.5 * ks[s] + 0.5 * qq[s];             // k (:168) + u^T Q u
+                        bc[s] = p.beta[cv[s] * N + ptv[s]];
+                    }
+                    const double bm = p.beta[am * N + ptm];
+                    // ---- the three exponentials (the pair-side ones unused, and harmless, for K == 0)
+                    const double exm = fast_exp(-0.5 * qm, c_exptab);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) ex[s] = fast_exp(kk[s], c_exptab);
+                    // ---- stores
+                    if (actm) {
+                        a_lb[am * N + ptm] = exm * bm;                                       // lb (:148)
+                        if (am == 0) {
+#pragma unroll
+                            for (int d = 0; d < DP; ++d)
+                                if (d < D) a_nu[d * N + ptm] = num[d];
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        if (!actv[s]) continue;
+                        const int gq = gqv[s], pt = ptv[s];
+                        const bool tay = Kv[s] > 0;
+                        if (rowv[s]) {
+                            double* rec = a_rows + ((size_t)gq * NR + pt) * RS;
+#pragma unroll
+                            for (int d = 0; d < DP; ++d) rec[REC::G + d] = g[s][d];
+                            rec[REC::EA] = tay ? ex[s] : kk[s];
+                            rec[REC::RA] = tay ? ex[s] * bc[s] : bc[s];
+                            if (diagv[s]) a_kb[gq * N + pt] = tay ? ex[s] : kk[s];
+                            if constexpr (REC::RS > DP + 2) rec[DP + 2] = 0.0;          // the pad travels with the 16-byte reads
+                        } else {
+                            a_kb[gq * N + pt] = tay ? ex[s] * bc[s] : kk[s];
+                        }
+                    }
+                }
+                // mean items the trips above did not reach (their index step is 2 p2_threads): [p2_threads, 2 p2_threads), ...
+                for (int base = tid; base < nmi && tid < p2_threads; base += 2 * p2_threads) {
+                    const int it = base + p2_threads;
+                    if (it >= nmi) break;
+                    const int a = p.magic_pt ? (int)__umulhi((unsigned)it, p.magic_pt) : it;
+                    const int pt = it - a * N;
+                    double nu[DP];
+#pragma unroll
+                    for (int d = 0; d < DP; ++d) nu[d] = (d < D) ? (Xs[d * N + pt] - s_m[d]) : 0.0;
+                    const double* Aj = s_aug + a * (D * LD) + D;
+                    double q = 0.0;
+#pragma unroll
+                    for (int i = 0; i < DP; ++i) {
+                        if (i < D) {
+                            double r = 0.0;
+#pragma unroll
+                            for (int j = 0; j < DP; ++j)
+                                if (j < D) r = fma(Aj[i * LD + j], nu[j], r);
+                            q = fma(nu[i], r, q);
+                        }
+                    }
+                    for (int e = D; e < E; ++e) {
+                        const double v = Xs[e * N + pt] - s_m[e];
+                        q = fma(v * v, c_ils2[a * E + e], q);
+                    }
+                    a_lb[a * N + pt] = fast_exp(-0.5 * q, c_exptab) * p.beta[a * N + pt];
+                    if (a == 0) {
+#pragma unroll
+                        for (int d = 0; d < DP; ++d)
+                            if (d < D) a_nu[d * N + pt] = nu[d];
+                    }
+                }
+            }
+#endif
             __syncthreads();
             GPMPC_TRACE(3);
 
             // ---- P3: work queue: pairwise items, moment sums, mean sums, stage cost ----------------
-            const int npair = Gc * wpp;
-            const int nextra = first ? D : 0;                // items 0..D-1: mean sums (pulled first)
-            const int total = nextra + npair;
+            const int total = *s_nitems;
             auto pull_item = [&]() -> int {
                 int pulled = 0;
-                if (lane == 0) pulled = __hip_atomic_fetch_add(s_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) {
+                    pulled = __hip_atomic_fetch_add(s_counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    pulled = (pulled < total) ? (int)s_items[pulled] : -1;
+                }
                 return __builtin_amdgcn_readfirstlane(pulled);       // wave-uniform (SGPR) work item
             };
-            for (int wq = pull_item(); wq < total; wq = pull_item()) {
-                if (wq < nextra) {
+            for (int wq = pull_item(); wq >= 0; wq = pull_item()) {
+                if (wq >= 0xffff - 15) {
                     // s1[a][0] = sum_p lb, s1[a][1+d] = sum_p lb nu_d  (fixed order)
-                    const int a = wq;
+                    const int a = 0xffff - wq;
                     for (int dd = 0; dd <= D; ++dd) {
                         double v = 0.0;
                         if (dd == 0) { for (int pt = lane; pt < N; pt += 64) v += a_lb[a * N + pt]; }
@@ -1230,7 +1495,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     }
                     continue;
                 }
-                const int wi = wq - nextra;
+                const int wi = wq;
                 const int gq = p.magic_wpp ? (int)__umulhi((unsigned)wi, p.magic_wpp) : wi;   // wi / wpp (magic 0: wpp == 1)
                 const int slot = wi - gq * wpp;
                 const int a = __builtin_amdgcn_readfirstlane(s_pa[q0 + gq]);
@@ -1295,16 +1560,23 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                                 acc[m] += t;
                             }
                         }
-                        const double tot = wave_sum8(acc, lane);
-                        const int mm = ((lane & 1) << 2) | (lane & 2) | ((lane >> 2) & 1);
-                        if (lane < 8 && al0 + mm < C) s_mom[(gq * 2 + side) * rnd2(CM) + al0 + mm] = tot;
+                        const double tot = wave_reduce8(acc);          // lanes 4 m .. 4 m + 3 (m < 8) hold the total of value m
+                        const int mm = lane >> 2;
+                        if ((lane & 3) == 0 && lane < 32 && al0 + mm < C) s_mom[(gq * 2 + side) * rnd2(CM) + al0 + mm] = tot;
                     }
                     continue;
                 }
                 const int flat = slot * 64 + lane;
                 bool valid;
                 int r, jc;
-                if (diag) {
+                int nrows_tab = -1;
+                if (diag && use_lmap) {
+                    const int packed = s_lmap[flat];
+                    valid = packed >= 0;
+                    r = valid ? (packed & 255) : 0;
+                    jc = valid ? (packed >> 8) : 0;
+                    nrows_tab = __builtin_amdgcn_readfirstlane(s_lrows[slot]);
+                } else if (diag) {
                     // only the (row chunk, column unit) combinations that contain an element i <= j are enumerated:
                     // s_tri[r] = number of such combinations in chunks < r (lanes binary-search their chunk)
                     valid = flat < s_tri[p.RC];
@@ -1328,8 +1600,11 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                 int i1 = i0 + p.CH;
                 if (i1 > N) i1 = N;
                 if (diag && i1 > jl + 1) i1 = jl + 1;
-                const int len = (valid && i1 > i0) ? (i1 - i0) : 0;
-                const int nrows = (wave_max_i32(len) + 3) & ~3;    // wave-uniform, zero padding absorbs the overshoot
+                int nrows = nrows_tab;                             // wave-uniform, zero padding absorbs the overshoot
+                if (nrows_tab < 0) {
+                    const int len = (valid && i1 > i0) ? (i1 - i0) : 0;
+                    nrows = (wave_max_i32(len) + 3) & ~3;
+                }
                 double acc = 0.0;
                 if (nrows > 0) {
                     double w[DP];
@@ -1339,10 +1614,13 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     const double* rec = a_rows + ((size_t)gq * NR + i0) * RS;
                     const double* Tp = p.Tm + ((size_t)a * (N + kTPad) + i0) * N + j;
                     if constexpr (C2) {
+                        // second column: always read (jl is a valid column) and masked by a factor -- four `valid1 ? load : 0`
+                        // became four exec-mask branches with a wait each in every item's set-up
                         double w1[DP];
+                        const double m1 = valid1 ? 1.0 : 0.0;
 #pragma unroll
-                        for (int d = 0; d < DP; ++d) w1[d] = (d < D && valid1) ? a_nu[d * N + j + 1] * c_ils2[b * E + d] : 0.0;
-                        const double kb1 = valid1 ? a_kb[gq * N + j + 1] : 0.0;
+                        for (int d = 0; d < DP; ++d) w1[d] = (d < D) ? a_nu[d * N + jl] * (c_ils2[b * E + d] * m1) : 0.0;
+                        const double kb1 = a_kb[gq * N + jl] * m1;
                         double acc0, acc1;
                         if (K == 0) {
                             item_exp2<DP>(rec, nrows, w, w1, kbj, kb1, diag, Tp, N, c_exptab, acc0, acc1);
@@ -1397,7 +1675,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     const double* Wm = Gm + rnd2(CM);
                     for (int al = lane; al < C; al += 64) v = fma(Gm[al] * Wm[al], c_monow[al], v);
                 } else {
-                    for (int k = lane; k < wpp; k += 64) v += s_part[gq * wpp + k];
+                    const int ns = s_nslot[gq];              // the slots the list held (the others were empty: exact zeros before)
+                    for (int k = lane; k < ns; k += 64) v += s_part[gq * wpp + k];
                 }
                 v = wave_sum(v);
                 if constexpr (TILED) {
