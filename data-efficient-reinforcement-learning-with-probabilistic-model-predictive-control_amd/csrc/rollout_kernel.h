@@ -1224,7 +1224,11 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
             // items of its own it was the last to reach the barrier: + 1.9 k cycles per step at config 2); narrow workgroups
             // (fewer than 8 wavefronts) share the items among all.
             const int p2_threads = (NW >= 8) ? NT - 64 : NT;
-#if defined(GPMPC_P2_SERIAL)
+            // (Measured and not adopted, round 5: two pair-side items per thread and trip, and two pair-side + one mean item,
+            //  written stage by stage so that the dependent chains interleave -- no gain for two (0.427 vs 0.428 ms at config 2),
+            //  slower for three (0.400 -> 0.415 ms; pass 6.5 k -> 7.9 k cycles per step; config 1 -10 %, B = 4096 per GPU -38 % with
+            //  the spills of the wider live set): the pass is not bound by the latency of one thread's chain.
+            //  profiles/r05c_forward_ab.txt, profiles/r05e_p2_three_chains_*.txt)
             for (int it = tid; it < (nmean + Gc + n_off) * N && tid < p2_threads; it += p2_threads) {
                 const int prob = p.magic_pt ? (int)__umulhi((unsigned)it, p.magic_pt) : it;      // it / N
                 const int pt = it - prob * N;
@@ -1311,164 +1315,6 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     }
                 }
             }
-#else
-            // Three items per thread and trip -- two pair-side items (row / column side of a pair: u, g = Z^T u, u^T Z u, one exp)
-            // and one mean-part item (nu^T A^-1 nu, one exp) -- written stage by stage for all three, so that their dependent
-            // chains interleave.  A dependent fp64 instruction issues only every ~40 cycles (tools/microbench/mfma_f64_rate), a
-            // chain is ~45 of them, and with one item at a time the pass ran at 36 % of its issue rate: 2.3 rounds of ~2.3 k
-            // cycles each at config 2.  Per item the operations and their order are those of the serial form (-DGPMPC_P2_SERIAL),
-            // so the results are bitwise the same.
-            {
-                const int npi = (Gc + n_off) * N, nmi = nmean * N;
-                for (int base = tid; (base < npi || base < nmi) && tid < p2_threads; base += 2 * p2_threads) {
-                    // ---- indices
-                    int ptv[2], gqv[2], cv[2], Kv[2];
-                    bool rowv[2], diagv[2], actv[2];
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        int it = base + s * p2_threads;
-                        actv[s] = it < npi;
-                        it = actv[s] ? it : 0;                             // an idle slot repeats item 0 (no stores)
-                        const int prob = p.magic_pt ? (int)__umulhi((unsigned)it, p.magic_pt) : it;      // it / N
-                        ptv[s] = it - prob * N;
-                        rowv[s] = prob < Gc;
-                        const int gq = (rowv[s] || n_off == 0) ? (rowv[s] ? prob : 0) : s_off[prob - Gc];
-                        const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
-                        diagv[s] = (a == b);
-                        cv[s] = rowv[s] ? a : b;                           // the output whose lengthscales scale nu
-                        Kv[s] = s_K[gq] & 63;
-                        gqv[s] = gq;
-                    }
-                    // the mean item of this trip: items base, base + 2 p2_threads, ... of the nmi mean items go to the same
-                    // thread as the pair-side items of the trip (second half of the trip's index range: base + p2_threads)
-                    const int itm0 = base, itm1 = base + p2_threads;
-                    // (two mean items per trip would be a fourth chain; the mean items of [p2_threads, 2 p2_threads) are taken by
-                    //  a second, short loop below -- at config 2: 600 items, none left)
-                    const bool actm = itm0 < nmi;
-                    const int itm = actm ? itm0 : 0;
-                    const int am = p.magic_pt ? (int)__umulhi((unsigned)itm, p.magic_pt) : itm;
-                    const int ptm = itm - am * N;
-                    (void)itm1;
-                    // ---- nu, u, ks (pair sides); nu (mean)
-                    double u[2][DP], g[2][DP], ks[2], qq[2], kk[2], bc[2], ex[2];
-                    double num[DP], qm = 0.0;
-#pragma unroll
-                    for (int d = 0; d < DP; ++d) num[d] = (d < D) ? (Xs[d * N + ptm] - s_m[d]) : 0.0;
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        ks[s] = 0.0;                                       // sum_e nu_e^2 / l_e^2
-                        qq[s] = 0.0;
-#pragma unroll
-                        for (int d = 0; d < DP; ++d) {
-                            const double nud = (d < D) ? (Xs[d * N + ptv[s]] - s_m[d]) : 0.0;
-                            u[s][d] = nud * ((d < D) ? c_ils2[cv[s] * E + d] : 0.0);
-                            ks[s] = fma(nud, u[s][d], ks[s]);
-                            g[s][d] = 0.0;
-                        }
-                    }
-                    // ---- quadratic forms: i outer, the three chains inside
-                    const double* Ai = s_aug + am * (D * LD) + D;          // A_a^-1 of the mean item
-#pragma unroll
-                    for (int i = 0; i < DP; ++i) {
-                        if (i < D) {
-                            double zu[2] = {0.0, 0.0};
-                            double r = 0.0;
-#pragma unroll
-                            for (int j = 0; j < DP; ++j)
-                                if (j < D) {
-                                    r = fma(Ai[i * LD + j], num[j], r);
-#pragma unroll
-                                    for (int s = 0; s < 2; ++s) {
-                                        const double z = s_aug[(D + gqv[s]) * (D * LD) + D + i * LD + j];
-                                        zu[s] = fma(z, u[s][j], zu[s]);
-                                        g[s][j] = fma(z, u[s][i], g[s][j]);      // g = Z^T u: cross term u^T Z w = g . w
-                                    }
-                                }
-                            qm = fma(num[i], r, qm);
-#pragma unroll
-                            for (int s = 0; s < 2; ++s) qq[s] = fma(u[s][i], zu[s], qq[s]);
-                        }
-                    }
-                    for (int e = D; e < E; ++e) {
-                        const double vm = Xs[e * N + ptm] - s_m[e];
-                        qm = fma(vm * vm, c_ils2[am * E + e], qm);
-#pragma unroll
-                        for (int s = 0; s < 2; ++s) {
-                            const double v = Xs[e * N + ptv[s]] - s_m[e];
-                            ks[s] = fma(v * v, c_ils2[cv[s] * E + e], ks[s]);
-                        }
-                    }
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        kk[s] = c_logvar[cv[s]] - 0.5 * ks[s] + 0.5 * qq[s];             // k (:168) + u^T Q u
-                        bc[s] = p.beta[cv[s] * N + ptv[s]];
-                    }
-                    const double bm = p.beta[am * N + ptm];
-                    // ---- the three exponentials (the pair-side ones unused, and harmless, for K == 0)
-                    const double exm = fast_exp(-0.5 * qm, c_exptab);
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) ex[s] = fast_exp(kk[s], c_exptab);
-                    // ---- stores
-                    if (actm) {
-                        a_lb[am * N + ptm] = exm * bm;                                       // lb (:148)
-                        if (am == 0) {
-#pragma unroll
-                            for (int d = 0; d < DP; ++d)
-                                if (d < D) a_nu[d * N + ptm] = num[d];
-                        }
-                    }
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) {
-                        if (!actv[s]) continue;
-                        const int gq = gqv[s], pt = ptv[s];
-                        const bool tay = Kv[s] > 0;
-                        if (rowv[s]) {
-                            double* rec = a_rows + ((size_t)gq * NR + pt) * RS;
-#pragma unroll
-                            for (int d = 0; d < DP; ++d) rec[REC::G + d] = g[s][d];
-                            rec[REC::EA] = tay ? ex[s] : kk[s];
-                            rec[REC::RA] = tay ? ex[s] * bc[s] : bc[s];
-                            if (diagv[s]) a_kb[gq * N + pt] = tay ? ex[s] : kk[s];
-                            if constexpr (REC::RS > DP + 2) rec[DP + 2] = 0.0;          // the pad travels with the 16-byte reads
-                        } else {
-                            a_kb[gq * N + pt] = tay ? ex[s] * bc[s] : kk[s];
-                        }
-                    }
-                }
-                // mean items the trips above did not reach (their index step is 2 p2_threads): [p2_threads, 2 p2_threads), ...
-                for (int base = tid; base < nmi && tid < p2_threads; base += 2 * p2_threads) {
-                    const int it = base + p2_threads;
-                    if (it >= nmi) break;
-                    const int a = p.magic_pt ? (int)__umulhi((unsigned)it, p.magic_pt) : it;
-                    const int pt = it - a * N;
-                    double nu[DP];
-#pragma unroll
-                    for (int d = 0; d < DP; ++d) nu[d] = (d < D) ? (Xs[d * N + pt] - s_m[d]) : 0.0;
-                    const double* Aj = s_aug + a * (D * LD) + D;
-                    double q = 0.0;
-#pragma unroll
-                    for (int i = 0; i < DP; ++i) {
-                        if (i < D) {
-                            double r = 0.0;
-#pragma unroll
-                            for (int j = 0; j < DP; ++j)
-                                if (j < D) r = fma(Aj[i * LD + j], nu[j], r);
-                            q = fma(nu[i], r, q);
-                        }
-                    }
-                    for (int e = D; e < E; ++e) {
-                        const double v = Xs[e * N + pt] - s_m[e];
-                        q = fma(v * v, c_ils2[a * E + e], q);
-                    }
-                    a_lb[a * N + pt] = fast_exp(-0.5 * q, c_exptab) * p.beta[a * N + pt];
-                    if (a == 0) {
-#pragma unroll
-                        for (int d = 0; d < DP; ++d)
-                            if (d < D) a_nu[d * N + pt] = nu[d];
-                    }
-                }
-            }
-#endif
             __syncthreads();
             GPMPC_TRACE(3);
 

@@ -24,10 +24,10 @@ run() {  # lib workload tag extra-args
   (GPMPC_LIB=$L timeout 200 python bench.py --workload $2 --no-cpu-baseline --no-gradient --steps 20 --warmup 3 $4 2>$OUT/${T}_last.err | line "$1 $2 $3") >> $F
 }
 for wl in c2 c1 c3 c4; do
-  for lib in base new base new; do run $lib $wl ab; done
+  for lib in v4 new v4 new; do run $lib $wl ab; done
 done
 run new c2 B4096 "--candidates-per-gpu 4096"
-run base c2 B4096 "--candidates-per-gpu 4096"
+run v4 c2 B4096 "--candidates-per-gpu 4096"
 cat $F
 echo "== fused-horizon kernel, config 2, B = 256: cycles per phase summed over the 25 horizon steps (workgroup 0, prof build)" > $OUT/${T}_c2_phases.txt
 GPMPC_LIB=$REPO/gpurun_dbg/libgpmpc_hip_prof.so timeout 120 python tools/gpu_grad_profile.py c2 256 1 2>&1 | grep -a "PROF cycles\|PROF wave0" | head -3 >> $OUT/${T}_c2_phases.txt
