@@ -188,6 +188,13 @@ __device__ inline void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// (Measured and not adopted, round 5 -- the serial phases of a horizon step, P1 3.6 k + P4 1.5 k + P5 1.4 k of 33 k cycles at config 2:
+//  (i) 1 / x and 1 / sqrt(x) of the small algebra from the hardware seed + Newton steps instead of the IEEE division and
+//  sqrt-then-divide: 0.3738 ms per 256 rollouts either way, P1 unchanged -- the phase is not bound by those chains;
+//  (ii) "fused tail": the wavefront that finishes a pair's last work item forms the pair's total, the one that forms the step's
+//  last total updates the state, three barriers per step instead of five: P4 + P5 2.9 k -> 0.4 k cycles, but the queue phase
+//  + 2.3 k and P1 + 0.7 k -- the chain last item -> total -> state update is serial wherever it runs; 0.411 vs 0.409 ms, and the
+//  two-workgroups-per-CU regime (B = 4096) lost its second workgroup to the registers.  profiles/r05f_*, r05g_*.)
 // Gaussian elimination with partial pivoting on an augmented [A | RHS] block (row stride ld).
 // The solution replaces the RHS; returns det(A).  Same algorithm class (LU, partial pivoting)
 // as the torch.linalg.solve / torch.det calls of the reference (gp_model.py:146,150,163,176).
