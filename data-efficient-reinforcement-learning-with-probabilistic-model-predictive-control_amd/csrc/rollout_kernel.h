@@ -913,6 +913,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
 
     [[maybe_unused]] int t_dbg = -1;
 #if defined(GPMPC_PROF_ON)
+    long long prof_x[3] = {0, 0, 0};
     long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_last = __builtin_readcyclecounter();
 #endif
@@ -1016,6 +1017,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
             // (mean problems on wave 0, pair problems on wave 1: the two instruction streams are long dependent fp64
             //  chains and would run one after the other as divergent branches of one wavefront)
             constexpr int kPairBase = (NT >= 256) ? 64 : 0;
+#if defined(GPMPC_PROF_ON)
+            const long long prof_p1 = __builtin_readcyclecounter();
+#endif
             if (first) {
                 // input mean of this step: [mu, a_t, (time)]  (gp_model.py:98-102)
                 for (int i = tid; i < E; i += NT) {
@@ -1176,6 +1180,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
             }
 #if defined(GPMPC_PROF_ON)
             if (threadIdx.x == 0 && blockIdx.x == 0) { long long now_ = __builtin_readcyclecounter(); prof_acc[7] += now_ - prof_last; }
+            if (blockIdx.x == 0 && threadIdx.x == 64) prof_x[0] += __builtin_readcyclecounter() - prof_p1;     // pair problems done
 #endif
             if (tid == NT - 1) {
                 *s_counter = 0;
@@ -1183,6 +1188,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                 for (int gq = 0; gq < Gc; ++gq)
                     if (s_pa[q0 + gq] != s_pb[q0 + gq]) s_off[no++] = gq;
                 *s_noff = no;
+#if defined(GPMPC_PROF_ON)
+                if (blockIdx.x == 0) prof_x[1] += __builtin_readcyclecounter() - prof_p1;                        // last thread's bookkeeping done
+#endif
             }
             __syncthreads();
             GPMPC_TRACE(2);
@@ -1327,6 +1335,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
 
             // ---- P3: work queue: pairwise items, moment sums, mean sums, stage cost ----------------
             const int total = *s_nitems;
+#if defined(GPMPC_PROF_ON)
+            const long long prof_p3 = __builtin_readcyclecounter();
+#endif
             auto pull_item = [&]() -> int {
                 int pulled = 0;
                 if (lane == 0) {
@@ -1515,6 +1526,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                 acc = wave_sum(acc);
                 if (lane == 0) s_part[wi] = acc;
             }
+#if defined(GPMPC_PROF_ON)
+            if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) prof_x[2] += __builtin_readcyclecounter() - prof_p3;     // this wavefront left the queue
+#endif
             __syncthreads();
             GPMPC_TRACE(4);
 
@@ -1583,6 +1597,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     }
 #if defined(GPMPC_PROF_ON)
     if (threadIdx.x == 0 && blockIdx.x == 0) printf("PROF wave0 small algebra cycles %lld\n", prof_acc[7]);
+    if (blockIdx.x == 0 && threadIdx.x == 64) printf("PROF P1 pair problems done after %lld cycles (summed over steps)\n", prof_x[0]);
+    if (blockIdx.x == 0 && threadIdx.x == NT - 1) printf("PROF P1 last thread done after %lld\n", prof_x[1]);
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) printf("PROF P3 wave %d left the queue after %lld\n", (int)(threadIdx.x >> 6), prof_x[2]);
     if (threadIdx.x == 0 && blockIdx.x == 0)
         printf("PROF cycles: init %lld | P1 %lld | P2 %lld | P3 %lld | P4 %lld | P5 %lld\n", prof_acc[1], prof_acc[2],
                prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6]);

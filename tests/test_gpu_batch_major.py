@@ -53,7 +53,7 @@ def test_reference_goldens_through_the_batch_major_path(engine, name):
     engine.set_cost(w.target, w.W, w.W_T, w.kappa, clip, smin, g["state_max"] if smin is not None else None)
     out, path = _rollout(engine, w, 1)
     assert path == TILES
-    tol = {"traj_c3": 2e-5, "traj_c2": 2e-6, "traj_c4": 5e-6, "traj_c4_n1000": 5e-6}.get(name, 1e-7)
+    tol = {"traj_c3": 1e-5, "traj_c2": 1e-6, "traj_c4": 1e-6, "traj_c4_n1000": 1e-6}.get(name, 1e-7)      # as tests/test_gpu_parity.py SIG_TOL
     e_mu, e_S, e_J = rel_err(out["mu"], g["mu"]), rel_err(out["Sig"], g["Sig"]), rel_err(out["J"], g["J"])
     record(f"batch_major_vs_reference[{name}]", mu=e_mu, Sig=e_S, J=e_J)
     assert e_mu < 1e-8 and e_S < tol and e_J < 1e-7
@@ -168,7 +168,7 @@ def _full_size(engine, name, sub, path, sig_tol):
 
 def test_full_size_c3_batch(engine):
     """BASELINE configs[2] at full size (N = 500, D = 2, H = 40, B = 1024): the fused-horizon kernel (tables L2-resident)."""
-    _full_size(engine, "c3", [0, 1, 511, 1023], FUSED, 2e-5)
+    _full_size(engine, "c3", [0, 1, 511, 1023], FUSED, 1e-5)        # vs the numpy oracle (itself 8e-6 from the exact values): 5.3e-6 achieved
 
 
 def test_full_size_c4_batch(engine):

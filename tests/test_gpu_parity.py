@@ -15,7 +15,11 @@ from oracle import synth
 
 pytestmark = pytest.mark.gpu
 
-SIG_TOL = {"traj_c3": 2e-5, "traj_c2": 2e-6, "traj_c4": 5e-6, "traj_c4_n1000": 5e-6}
+# covariance tolerances against the reference goldens, relative to max|Sigma|.  The north-star bound is 1e-5; config 3 sits just
+# inside it because the REFERENCE's own fp64 rounding is 9.41e-6 away from the exact (extended-precision) covariances there (the HIP
+# path: 4.3e-6, test_covariances_against_extended_precision) -- achieved |HIP - reference| 9.41e-6 on every build of rounds 3-5
+# (profiles/*parity_report.json); the smaller memories are at their noise floor of 1e-7 ... 3e-7
+SIG_TOL = {"traj_c3": 1e-5, "traj_c2": 1e-6, "traj_c4": 1e-6, "traj_c4_n1000": 1e-6}
 TRAJ = ["traj_c1", "traj_c2", "traj_c3", "traj_c4", "traj_c4_n1000", "traj_c4_time", "traj_c5class", "traj_n1_dummy",
         "traj_clip", "traj_constraints", "traj_bigvar"]
 
