@@ -256,7 +256,11 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         // config 2), but at least ~2 items per wave so that the queue can balance
         long long want = (cols2 ? 4LL : 2LL) * nw * 64;      // two-column items are twice as heavy: aim at twice as many
         long long rc = (want + (long long)g * NCu - 1) / ((long long)g * NCu);
-        const long long rc64 = (N + 63) / 64;
+        // longest chunk: 64 rows, or 48 in the two-column form -- once the queue walks a list of real items (round 5) shorter
+        // chunks cost less than they did and fill the last round of the 16 wavefronts better (N = 500, D = 2: 36 items of 64 rows
+        // = 2.25 rounds against 46 of 48 rows = 2.9; measured 206 -> 213 k rollouts/s, profiles/r05i_chunk_and_share_cu_sweeps.txt)
+        const int chmax = cols2 ? 48 : 64;
+        const long long rc64 = (N + chmax - 1) / chmax;
         if (rc < rc64) rc = rc64;
         int maxrc = (N + 15) / 16;
         if (rc > maxrc) rc = maxrc;
