@@ -44,6 +44,18 @@ def table(name, X, ls, mus, Sigs, D):
                 hist_old[degree(co)] += 1; hist_new[degree(cn)] += 1
                 rows.append((t, a, b, co, cn))
     r = np.array(rows)
+    if "--by-step" in sys.argv:
+        # K per (pair, step) for the first trajectory of the set: one line per horizon step, pairs in (a, b) order, "old>new"
+        H1 = int(os.environ.get("KTABLE_STEPS", "0")) or len({int(x[0]) for x in rows})
+        P = D * (D + 1) // 2
+        print(f"# {name}: Taylor degree per (pair, step), bound from the input mean > bound from the box centre; 99 = beyond the Taylor range; first trajectory")
+        for t in range(min(H1, len(rows) // P)):
+            cells = []
+            for q in range(P):
+                _, a, b, co, cn = rows[t * P + q]
+                ko, kn = degree(co), degree(cn)
+                cells.append(f"{ko}>{kn}" if ko != kn else f"{ko}")
+            print(f"t={t:2d} " + " ".join(cells))
     print(name, "pairs*steps", len(rows), "cmax old median %.3g max %.3g | new median %.3g max %.3g | ratio median %.2f" % (
         np.median(r[:,3]), r[:,3].max(), np.median(r[:,4]), r[:,4].max(), np.median(r[:,3]/r[:,4])))
     print("  K hist old", sorted(hist_old.items())); print("  K hist new", sorted(hist_new.items()))
