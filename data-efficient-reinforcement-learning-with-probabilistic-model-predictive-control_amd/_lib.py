@@ -43,6 +43,7 @@ SIGNATURES = {
     "gpmpc_last_prepare_mode": (C.c_int, [_P]),
     "gpmpc_last_rollout_path": (C.c_int, [_P]),
     "gpmpc_last_grad_path": (C.c_int, [_P]),
+    "gpmpc_last_cluster": (C.c_int, [_P]),
     "gpmpc_build_id": (C.c_char_p, []),
     "gpmpc_mll": (C.c_int, [_P, _P, _P, _P, _P, _P, _I, _I, _I, C.POINTER(_D), _P]),
     "gpmpc_set_option": (C.c_int, [_P, C.c_char_p, C.c_longlong]),
@@ -58,7 +59,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 
 def load(path=LIB_PATH):

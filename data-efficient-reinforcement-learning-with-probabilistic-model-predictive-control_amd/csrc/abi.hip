@@ -53,7 +53,7 @@ static void free_buf(Buf& b) {
 
 extern "C" {
 
-int gpmpc_abi_version(void) { return 10; }
+int gpmpc_abi_version(void) { return 11; }
 
 int gpmpc_create(gpmpc_t** out, int device_id) {
     if (!out) return GPMPC_ERR_ARG;
@@ -81,7 +81,7 @@ int gpmpc_destroy(gpmpc_t* g) {
     (void)hipSetDevice(h->device);
     Buf* all[] = {&h->Xt, &h->beta, &h->iK, &h->Tm, &h->ils2, &h->var, &h->logvar, &h->gram,
                   &h->linv, &h->zvec, &h->cost, &h->best, &h->xrange, &h->mono_w, &h->traj, &h->Xc, &h->Yc,
-                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws, &h->cemws, &h->tilews, &h->sepw, &h->tgradws};
+                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws, &h->cemws, &h->tilews, &h->sepw, &h->tgradws, &h->xch};
     for (Buf* b : all) free_buf(*b);
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);
@@ -134,6 +134,11 @@ int gpmpc_set_option(gpmpc_t* g, const char* name, long long value) {
     else if (!strcmp(name, "pair_tiles")) h->opt_pair_tiles = (int)value;
     else if (!strcmp(name, "tile_chunk")) h->opt_tile_chunk = (int)value;
     else if (!strcmp(name, "tile_overlap")) h->opt_tile_overlap = (int)value;
+    else if (!strcmp(name, "cluster_debug")) h->opt_cl_dbg = (int)value;
+    else if (!strcmp(name, "cluster")) {
+        if (value < 0 || value > 32) { h->err = "cluster: 0 (auto), 1 (never) or 2..32 workgroups per candidate"; return GPMPC_ERR_ARG; }
+        h->opt_cluster = (int)value;
+    }
     else return bad(g, "unknown option");
     return GPMPC_OK;
 }
@@ -195,6 +200,7 @@ int gpmpc_mll(gpmpc_t* g, const double* X, const double* Y, const double* ls, co
 int gpmpc_last_prepare_mode(gpmpc_t* g) { return g ? g->h.last_prepare_mode : GPMPC_ERR_ARG; }
 
 int gpmpc_last_rollout_path(gpmpc_t* g) { return g ? g->h.last_rollout_path : GPMPC_ERR_ARG; }
+int gpmpc_last_cluster(gpmpc_t* g) { return g ? g->h.last_cluster : GPMPC_ERR_ARG; }
 
 int gpmpc_last_grad_path(gpmpc_t* g) { return g ? g->h.last_grad_path : GPMPC_ERR_ARG; }
 

@@ -72,6 +72,13 @@ struct RolloutArgs {
     double* grad_mom;        // (B, H, P, NSP) moment array, or NULL
     int* grad_done;          // (B, H, P) flags
     int grad_NSP, grad_NXP;
+    // few-candidate cooperative form (rollout_kernel<..., CL = true>): `cluster` workgroups share one candidate's horizon step
+    // and exchange their partial sums as tagged 8-byte granules through `xch` (per candidate: 2 buffers x xch_n values x 2 words)
+    int cluster;                 // workgroups per candidate (1: the plain kernel)
+    int xch_n;                   // values per exchange
+    unsigned xch_tag0;           // tags of this launch: xch_tag0 + step + 1 (unique over the life of the buffer)
+    unsigned long long* xch;
+    int cl_dbg;                  // timing experiments of the exchange (-DGPMPC_CL_DEBUG builds only)
     // initial state distribution
     double mu0[kMaxD];
     double S0[kMaxD * kMaxD];
@@ -122,6 +129,11 @@ struct Handle {
     int* mismatch = nullptr;     // device flag of the prefix comparison
     int inc_updates = 0;         // border updates since the last full factorisation
     bool have_state = false;     // Xc / Yc / hyp describe the cached factors
+    Buf xch;      // exchange granules of the cooperative few-candidate kernel (zeroed when (re)allocated, tags never repeat)
+    unsigned xch_epoch = 0;      // launches that used `xch` since it was last zeroed
+    int opt_cluster = 0;         // workgroups per candidate of the few-candidate path: 0 auto, 1 never, n >= 2 fixed
+    int opt_cl_dbg = 0;
+    int last_cluster = 1;        // what the last fused-horizon launch used
     Buf mono_w;   // (CM) 1 / alpha!
     int* mono_exp = nullptr;    // (CM, 4)
     int mono_D = -1;            // state dimension the monomial tables were built for

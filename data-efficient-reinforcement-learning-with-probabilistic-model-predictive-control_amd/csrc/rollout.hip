@@ -251,6 +251,7 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     }
     const int Pg = tiled ? (P - D > 0 ? P - D : 1) : P;           // pairs the per-candidate kernel keeps row records for
     const int NCu = cols2 ? (N + 1) / 2 : N;     // column units per row chunk
+    bool cl_chunks = false;          // cooperative form: short row chunks (many items: its wavefronts are spread over several CUs)
     auto chunking = [&](int g) {
         // row chunks of up to 64 rows (fewer, longer items amortise the per-item prologue: 0.76 vs 0.80 ms at
         // config 2), but at least ~2 items per wave so that the queue can balance
@@ -265,20 +266,35 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         int maxrc = (N + 15) / 16;
         if (rc > maxrc) rc = maxrc;
         if (rc < 1) rc = 1;
+        // Cooperative form: an item of a lone wavefront is latency-bound (set-up ~2 k cycles, a trip of 2 rows ~400: 32 rows take
+        // ~10 k cycles whether 1 or 4 wavefronts share the SIMD), so the members' 8 x cluster wavefronts want about one short item
+        // each.  Measured at B = 1 (profiles/r06_cluster_sweep.txt): N = 200: 16 rows 0.216 ms against 0.222 (8) and 0.234 (32);
+        // N = 500: 32 rows 0.495 against 0.557 (16) at 16 members.  The chunk length depends on nothing but N (not on B or the
+        // cluster size): every few-candidate launch sums in the same order.
+        if (cl_chunks) rc = (N + (N < 384 ? 16 : 32) - 1) / (N < 384 ? 16 : 32);
         if (h->opt_rows_per_chunk > 0) rc = (N + h->opt_rows_per_chunk - 1) / h->opt_rows_per_chunk;
         CH = (N + (int)rc - 1) / (int)rc;
         CH = (CH + 3) & ~3;                      // rows are processed in groups of 4
         if (CH > 64) CH = 64;                    // T_a carries 64 zero padding rows
         RC = (N + CH - 1) / CH;
     };
-    if (!gs) {
+    // Few candidates (the reference's own regime: restarts_optim 1-2, one candidate per objective evaluation,
+    // gp_mpc_controller.py:125-141): a cluster of workgroups per candidate (rollout_kernel<..., CL>) while clusters x candidates
+    // fit the chip one workgroup per CU -- every member must be resident, they wait for each other once per horizon step.
+    // Candidates are placed in groups of 8 (one per XCD), so the grid is 8 x cluster x ceil(B / 8) workgroups.
+    int cluster = 1;
+    const int groups8 = (a.B + 7) / 8;
+    bool want_cluster = !gs && !tiled && cols2 && DP <= 4 && !share_cu && h->opt_lds_kb == 0 &&
+                        h->opt_cluster != 1 && a.H < 8191 && 8 * groups8 * 2 <= h->num_cu;
+    auto choose_layout = [&](bool cl) {
+        G = 0;
         // X^T in LDS when it is small next to the budget (<= 32 KiB) and the layout still fits
         for (int xl = ((size_t)E * N * 8 <= 32 * 1024) ? 1 : 0; xl >= 0 && G == 0; --xl) {
             // (at most 48 pairs per group: one wavefront builds the step's work-item list, a lane per pair and per mean sum)
             for (int g = Pg < 48 ? Pg : 48; g >= 1; --g) {
                 chunking(g);
                 const int wpp = (RC * NCu + 63) / 64;
-                Layout L = make_layout(N, D, A, E, g, DP, wpp, CM, CH, a.H * A, xl != 0);
+                Layout L = make_layout(N, D, A, E, g, DP, wpp, CM, CH, a.H * A, xl != 0, cl);
                 if ((size_t)L.lds_total * 8 <= lds_cap) {
                     G = g; lds_bytes = (size_t)L.lds_total * 8; a.x_in_lds = xl;
                     break;
@@ -287,8 +303,34 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
             // prefer all pairs in one group over the X^T copy
             if (G != 0 && G < (Pg < 48 ? Pg : 48) && xl == 1) { G = 0; }
         }
-        if (G == 0) { gs = true; tiled = false; }
+    };
+    if (!gs) {
+        if (want_cluster) {
+            cl_chunks = true;
+            choose_layout(true);
+            if (G != P) want_cluster = false;              // the cooperative form keeps all pairs in one group
+        }
+        cl_chunks = want_cluster;
+        if (!want_cluster) choose_layout(false);
+        if (G == 0) { gs = true; tiled = false; want_cluster = false; }
     }
+    if (want_cluster) {
+        // slots of a diagonal pair's triangle (the kernel's s_tri): the element-wise items that are always there
+        int tri = 0;
+        for (int r = 0; r < RC; ++r) { const int first = (r * CH) / 2; tri += first < NCu ? NCu - first : 0; }
+        const int wtri = (tri + 63) / 64;
+        // ~4 element-wise items per member; below ~24 items the exchange costs what the spread gains (N = 50: 0.122 against 0.127 ms,
+        // N = 100: 0.130 / 0.141, N = 130: equal)
+        int cs = h->opt_cluster >= 2 ? h->opt_cluster : (D * wtri >= 24 ? (D * wtri + 3) / 4 : 1);
+        if (cs > 32) cs = 32;
+        const int cap = h->num_cu / (8 * groups8);
+        if (cs > cap) cs = cap;
+        if (cs >= 2) cluster = cs;
+        // members of 8 wavefronts (no register spills: 145 VGPRs) from 8 members on; few, wide members otherwise (measured: B = 64,
+        // 4 members: 0.267 / 0.270 ms with 1024 / 512 threads; B = 128, 2 members: 0.323 / 0.354; 16 members: 0.240 / 0.216)
+        if (cluster > 1 && h->opt_threads == 0) nt = cluster >= 8 ? 512 : 1024;
+    }
+    if (cluster == 1 && want_cluster) { cl_chunks = false; choose_layout(false); }          // the plain layout and chunking
     if (gs) {
         // large-N variant (rollout_stream_kernel.h): column factors + a double-buffered 64-row stage in LDS
         // matrix-core pair pass (DP = 8 / 16): chunks of 64 / 128 / 256 rows = 4 / 8 / 16 row tiles per (chunk, 16-column
@@ -352,6 +394,26 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
             default: return launch_rollout_dp16(h, a, nt, gs, lds_bytes, s);
         }
     };
+    a.cl_dbg = h->opt_cl_dbg;
+    a.cluster = cluster; a.xch = nullptr; a.xch_n = 0; a.xch_tag0 = 0;
+    h->last_cluster = cluster;
+    if (cluster > 1) {
+        const unsigned wppv = (unsigned)((RC * NCu + 63) / 64);
+        a.xch_n = G * (int)wppv + G + D * (D + 1) + 32;       // item slots | separable pairs | mean sums | the members' XCD ids
+        const size_t words = (size_t)8 * groups8 * 4 * a.xch_n;
+        // tags never repeat while the buffer lives: 8192 per launch, the buffer is zeroed when it is (re)allocated and before the
+        // 32-bit tag would wrap
+        const bool fresh = !h->xch.p || words > h->xch.cap;
+        int rcx = grow(h, h->xch, words);
+        if (rcx) return rcx;
+        if (fresh || h->xch_epoch >= (1u << 19) - 1) {
+            GPMPC_HIP_CHECK(h, hipMemsetAsync(h->xch.p, 0, h->xch.cap * sizeof(double), s));
+            h->xch_epoch = 0;
+        }
+        a.xch_tag0 = h->xch_epoch * 8192u;
+        h->xch_epoch += 1;
+        a.xch = reinterpret_cast<unsigned long long*>(h->xch.p);
+    }
     h->last_rollout_path = gs ? 1 : (tiled ? 2 : 0);
     // the batch-major state of a (possibly re-used) argument block is set on EVERY call, never inherited from an earlier one
     a.tiled = tiled ? 1 : 0;

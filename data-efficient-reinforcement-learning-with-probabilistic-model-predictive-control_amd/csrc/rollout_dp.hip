@@ -37,6 +37,20 @@ static int launch_variant(Handle* h, RolloutArgs& a, bool global_scratch, size_t
         }
     }
     if (a.tiled) { h->err = "rollout: batch-major path asked for an unsupported kernel variant"; return GPMPC_ERR_ARG; }
+    if (a.cluster > 1) {
+        // few-candidate cooperative form: a.cluster workgroups per candidate, candidates in groups of 8 (one per XCD)
+        if constexpr (DP <= 4) {
+            if (!a.cols2) { h->err = "rollout: the cooperative form needs the two-column pair pass"; return GPMPC_ERR_ARG; }
+            auto ck = exact ? rollout_kernel<DP, NT, DP, true, false, true> : rollout_kernel<DP, NT, 0, true, false, true>;
+            int rc = allow_full_lds(h, reinterpret_cast<const void*>(ck));
+            if (rc) return rc;
+            hipLaunchKernelGGL(ck, dim3(8 * a.cluster * ((a.B + 7) / 8)), dim3(NT), lds_bytes, s, a);
+            GPMPC_HIP_CHECK(h, hipGetLastError());
+            return GPMPC_OK;
+        } else {
+            h->err = "rollout: cooperative form asked for an unsupported kernel variant"; return GPMPC_ERR_ARG;
+        }
+    }
     auto kern = a.cols2 ? (exact ? rollout_kernel<DP, NT, DP, true> : rollout_kernel<DP, NT, 0, true>)
                         : (exact ? rollout_kernel<DP, NT, DP, false> : rollout_kernel<DP, NT, 0, false>);
     {

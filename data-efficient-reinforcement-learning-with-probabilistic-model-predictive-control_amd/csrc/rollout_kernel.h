@@ -37,7 +37,8 @@
 #if defined(GPMPC_PROF_ON)
 // phase profile of workgroup 0 (debug build only): cycles between consecutive trace points, summed over steps
 #define GPMPC_TRACE(id) do { if (threadIdx.x == 0 && blockIdx.x == 0) { long long now_ = __builtin_readcyclecounter(); \
-    prof_acc[id] += now_ - prof_last; prof_last = now_; } } while (0)
+    prof_acc[id] += now_ - prof_last; prof_last = now_; } \
+    if (CL && threadIdx.x == 0 && (blockIdx.x & 7) == 0) { long long w_ = wall_clock64(); prof_wall[id] += w_ - prof_wlast; prof_wlast = w_; } } while (0)
 #elif defined(GPMPC_TRACE_ON)
 #define GPMPC_TRACE(id) do { if (threadIdx.x == 0 && blockIdx.x == 0) printf("trace %d t=%d\n", id, t_dbg); } while (0)
 #else
@@ -102,9 +103,11 @@ constexpr int kMaxMono = 256;      // most monomials of the separable (off-diago
 // ------------------------------------------------------------------------------------------
 // LDS / scratch layout (offsets in doubles), shared by host (sizing) and device (carving).
 constexpr int kLaneMapSlots = 32;  // most work-item slots of a diagonal pair whose lane assignment is tabulated in LDS
+constexpr int kLaneMapSlotsCluster = 192;      // ... in the cooperative form, whose row chunks are short (many slots per pair)
+__host__ __device__ inline int tri_ints(int N) { return (N + 7) / 8 + 2; }      // s_tri: row chunks of >= 8 rows, + 1, + 1 spare
 
 struct Layout {
-    int mu, Sig, m, M, cc, s1, Vs, Sp, misc, rdet, aug, part, mom, ints, lmap;
+    int mu, Sig, m, M, cc, s1, Vs, Sp, misc, rdet, aug, part, mom, ints, lmap, cl;
     int c_ils2, c_logvar, c_var, c_xr, c_act, c_exptab, c_monow, c_monoe, c_X;    // read-only tables copied to LDS once
     int lds_total;     // doubles of LDS
     // per-point arrays (LDS)
@@ -114,8 +117,10 @@ struct Layout {
 
 __host__ __device__ inline int rnd2(int x) { return (x + 1) & ~1; }
 
+constexpr int kClusterScratch = 16 * 64 / 8;     // the cooperative form's per-wavefront problem lists (16 wavefronts x 64 bytes)
+
 __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G, int DP, int wpp, int CM, int CH, int HA,
-                                              bool x_in_lds) {
+                                              bool x_in_lds, bool cluster = false) {
     Layout L;
     const int P = D * (D + 1) / 2;
     int o = 0;
@@ -134,10 +139,17 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     L.mom = o;  o += G * 2 * rnd2(CM);
     // pa[P], pb[P], K[G], counter, noff, off[G], mcum[16], tri[RC+1], nslot[G], nitems (ints); then the step's work-item list
     // (16-bit entries: D mean items + at most G * wpp pair items)
-    L.ints = o; o += rnd2((2 * P + 3 * G + 8 + 16 + ((N + 15) / 16 + 2) + 1) / 2) + rnd2((D + G * wpp + 3) / 4);
+    L.ints = o; o += rnd2((2 * P + 3 * G + 8 + 16 + tri_ints(N) + 1) / 2) + rnd2((D + G * wpp + 3) / 4);
     // lane map of the diagonal pairs' work items: (row chunk, column unit) per (slot, lane) + rows per slot, for up to
     // kLaneMapSlots slots (state-independent: filled once per launch)
-    L.lmap = o; o += rnd2(((wpp < kLaneMapSlots ? wpp : kLaneMapSlots) * 65 + 1) / 2);
+    const int lms = cluster ? kLaneMapSlotsCluster : kLaneMapSlots;
+    L.lmap = o; o += rnd2(((wpp < lms ? wpp : lms) * 65 + 1) / 2);
+    // cooperative form: totals of the separable pairs [G] | ordinals of the pairs among the diagonal / off-diagonal ones (ints) [G] |
+    // failure flag + spare (ints) [2] | per-wavefront problem lists of the per-point pass
+    // | static owner tables (bytes): item slots [G * wpp], separable pairs [G], pairs needed in element-wise form [G], mean sums [16]
+    // | this member's items of the step (16-bit codes) [G * wpp + 16] + their number
+    L.cl = o;       o += cluster ? rnd2(G) + rnd2((G + 1) / 2) + 2 + kClusterScratch + rnd2((G * wpp + 2 * G + 16 + 7) / 8) +
+                                   rnd2((G * wpp + 16 + 4 + 3) / 4) : 0;
     L.c_ils2 = o;   o += rnd2(D * E);
     L.c_logvar = o; o += rnd2(D);
     L.c_var = o;    o += rnd2(D);
@@ -833,9 +845,18 @@ __device__ inline int wave_max_i32(int v) {
 // TILED = one step of the per-candidate part of the batch-major path (pair_tile_kernel.h): the horizon slice
 // [p.t_begin, p.t_end) starts from the state stored in the trajectory arrays, the diagonal output pairs are not
 // processed here -- their N x N sums arrive as per-tile partial sums in p.tile_part and are added in a fixed order.
-template <int DP, int NT, int DX, bool C2, bool TILED = false>
+// CL = the few-candidate cooperative form (the reference's own regime: restarts_optim 1-2, one candidate per objective
+// evaluation, gp_mpc_controller.py:125-141): p.cluster workgroups share ONE candidate.  Every member keeps the whole state and runs
+// the small algebra, the state update and the horizon loop itself; the step's work items (element-wise N x N items, separable
+// pairs, mean sums) have a static owner among the members, a member runs the per-point pass only for the output pairs it owns
+// items of, and the items' results travel once per step as tagged granules through L2 / the fabric (two 8-byte agent-scope atomic
+// stores {tag | low word}, {tag | high word} per value: each half is single-copy atomic, a reader accepts a value when both tags
+// are this step's -- no fences, MI355X_MICROARCH.md "handoff-1to1").  Every value is formed by the same instruction sequence as in
+// the plain kernel and summed in the same order: the trajectory is bit-identical to the one-workgroup result.
+template <int DP, int NT, int DX, bool C2, bool TILED = false, bool CL = false>
 __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     static_assert(!TILED || (DP <= 4 && NT >= 256), "the batch-major path is built for D <= 4");
+    static_assert(!CL || (!TILED && DP <= 4 && NT >= 256), "the cooperative form is built for D <= 4");
     extern __shared__ __attribute__((aligned(16))) double smem[];
     if constexpr (TILED) {
         // batch-major path: this kernel only takes the candidates point_pass_kernel left (element-wise off-diagonal pairs)
@@ -845,7 +866,12 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     using REC = RowRecAligned<DP>;          // row record: g_i (DP) | ea_i or ka'_i | ra_i or beta_ai | pad, 16-byte aligned
     constexpr int RS = REC::RS;
     const int tid = threadIdx.x;
-    const int c = blockIdx.x;
+    // cooperative form: workgroup b is member (b / 8) % cluster of candidate (b % 8) + 8 (b / (8 cluster)) -- the members of a
+    // candidate are 8 apart in dispatch order, i.e. on one XCD where the dispatcher places block b on XCD b % 8 (speed only)
+    const int CS = CL ? p.cluster : 1;
+    const int member = CL ? (int)(blockIdx.x >> 3) % CS : 0;
+    const int c = CL ? (int)(blockIdx.x & 7) + 8 * ((int)(blockIdx.x >> 3) / CS) : (int)blockIdx.x;
+    if constexpr (CL) { if (c >= p.B) return; }
     const int D = (DX > 0) ? DX : p.D;
     const int N = p.N, A = p.A, E = p.E, H = p.H, G = p.G, CM = p.CM;
     const int P = TILED ? D * (D - 1) / 2 : D * (D + 1) / 2;      // output pairs whose N x N work is done here
@@ -855,7 +881,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     const int wpp = (p.RC * NC + 63) / 64;  // work-item slots per output pair
     const int SD2 = rnd2(D * D);
 
-    const Layout L = make_layout(N, D, A, E, G, DP, wpp, CM, p.CH, H * A, p.x_in_lds != 0);     // the host sized it with the same wpp
+    const Layout L = make_layout(N, D, A, E, G, DP, wpp, CM, p.CH, H * A, p.x_in_lds != 0, CL);     // the host sized it with the same wpp
     const int NR = N + p.CH;                // rows per pair in the row-record array (data + zero padding)
     double* s_mu = smem + L.mu;
     double* s_Sig2 = smem + L.Sig;
@@ -878,7 +904,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     int* s_off = s_noff + 1;
     int* s_mcum = s_off + G;                // monomials of degree <= k (copy of the launch argument: LDS instead of a kernarg load on the serial path)
     int* s_tri = s_mcum + 16;               // diagonal pairs: column units of row chunks < r that can hold an element i <= j
-    int* s_nslot = s_tri + ((N + 15) / 16 + 2);     // work-item slots of each pair of the group that hold work at this step
+    int* s_nslot = s_tri + tri_ints(N);     // work-item slots of each pair of the group that hold work at this step
     int* s_nitems = s_nslot + G;            // length of the step's work-item list
     // The work-item list of the step (built by one thread beside the per-point pass, read by the queue of P3): only slots
     // that hold work -- a diagonal pair uses the slots of its triangle, a separable pair one slot per (side, monomial band) --
@@ -886,14 +912,29 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     // 0xffff - a for the mean sums of output a.  (Until round 5 the queue walked all G * wpp slots: at config 2, 36 of 69
     // pulls per step found nothing to do, each after the lane set-up of an item.)
     unsigned short* s_items = reinterpret_cast<unsigned short*>(
-        smem + L.ints + rnd2((2 * P + 3 * G + 8 + 16 + ((N + 15) / 16 + 2) + 1) / 2));
+        smem + L.ints + rnd2((2 * P + 3 * G + 8 + 16 + tri_ints(N) + 1) / 2));
 
     // Lane map of a diagonal pair's work items (slot, lane) -> (row chunk | column unit << 8), -1 = no element, and the row count
     // of each slot: the triangle's enumeration does not depend on the state, so the per-item binary search over s_tri and the
     // wavefront maximum of the lanes' row counts are done ONCE per launch (at config 2 they were ~70 of an item's ~250 set-up
     // instructions, 18 items per step).
+    // cooperative form
+    [[maybe_unused]] double* s_sepv = smem + L.cl;                                          // totals of the separable pairs
+    [[maybe_unused]] int* s_ord = reinterpret_cast<int*>(smem + L.cl + rnd2(G));            // ordinal of a pair among the diagonal / off-diagonal pairs
+    [[maybe_unused]] int* s_fail = reinterpret_cast<int*>(smem + L.cl + rnd2(G) + rnd2((G + 1) / 2));
+    [[maybe_unused]] unsigned char* s_needw = reinterpret_cast<unsigned char*>(smem + L.cl + rnd2(G) + rnd2((G + 1) / 2) + 2);
+    [[maybe_unused]] unsigned char* s_own = s_needw + kClusterScratch * 8;      // owner of item slot gq * wpp + slot (element-wise form)
+    [[maybe_unused]] unsigned char* s_sepown = s_own + G * wpp;                 // owner of pair gq when it is separable
+    [[maybe_unused]] unsigned char* s_elneed = s_sepown + G;                    // 1: this member owns a slot of pair gq's element-wise form
+    [[maybe_unused]] unsigned char* s_meanown = s_elneed + G;                   // owner of the mean sums of output a
+    [[maybe_unused]] unsigned short* s_mine = reinterpret_cast<unsigned short*>(       // this member's items of the step, [0] = their number
+        smem + L.cl + rnd2(G) + rnd2((G + 1) / 2) + 2 + kClusterScratch + rnd2((G * wpp + 2 * G + 16 + 7) / 8));
+    [[maybe_unused]] unsigned long long* xbuf = CL ? p.xch + (size_t)c * 4 * p.xch_n : nullptr;    // [buffer][value][2]
+    [[maybe_unused]] const int x_sep = G * wpp, x_mean = G * wpp + G;                       // value index: item slots | separable pairs | mean sums
+    [[maybe_unused]] const int x_xcc = x_mean + D * (D + 1);                                // ... | the members' XCD ids (prologue)
     [[maybe_unused]] int* s_lmap = reinterpret_cast<int*>(smem + L.lmap);
-    [[maybe_unused]] int* s_lrows = s_lmap + (wpp < kLaneMapSlots ? wpp : kLaneMapSlots) * 64;
+    constexpr int LMS = CL ? kLaneMapSlotsCluster : kLaneMapSlots;
+    [[maybe_unused]] int* s_lrows = s_lmap + (wpp < LMS ? wpp : LMS) * 64;
     double* ppbase = smem;                  // per-point arrays live in LDS (large N: rollout_stream_kernel.h)
     double* a_nu = ppbase + L.nu;           // [d][p]
     double* a_lb = ppbase + L.lb;           // [a][p]
@@ -914,8 +955,10 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     [[maybe_unused]] int t_dbg = -1;
 #if defined(GPMPC_PROF_ON)
     long long prof_x[3] = {0, 0, 0};
-    long long prof_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     long long prof_last = __builtin_readcyclecounter();
+    long long prof_wall[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long prof_wlast = wall_clock64();
 #endif
     // ---- init -----------------------------------------------------------------------
     if constexpr (TILED) {
@@ -942,8 +985,14 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     if (tid >= 64 && tid < 80) s_mcum[tid - 64] = p.mono_cum[tid - 64];
     if (tid == 0) {
         int q = 0;
+        [[maybe_unused]] int nd_ = 0, no_ = 0;
         for (int a = 0; a < D; ++a)
-            for (int b = TILED ? a + 1 : a; b < D; ++b) { s_pa[q] = a; s_pb[q] = b; ++q; }
+            for (int b = TILED ? a + 1 : a; b < D; ++b) {
+                s_pa[q] = a; s_pb[q] = b;
+                if constexpr (CL) s_ord[q] = (a == b) ? nd_++ : no_++;
+                ++q;
+            }
+        if constexpr (CL) *s_fail = 0;
         // a column unit (one column, or the pair (2 jc, 2 jc + 1)) is useful for row chunk r if its last column >= r CH
         int run = 0;
         for (int r = 0; r <= p.RC; ++r) {
@@ -957,7 +1006,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     bool use_lmap = false;
     if constexpr (!TILED) {
         const int wtri = (s_tri[p.RC] + 63) >> 6;
-        use_lmap = wtri <= kLaneMapSlots && wtri <= wpp;
+        use_lmap = wtri <= LMS && wtri <= wpp;
         if (use_lmap) {
             for (int slot = tid >> 6; slot < wtri; slot += NW) {
                 const int flat = slot * 64 + (tid & 63);
@@ -988,9 +1037,105 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     constexpr bool use_lmap = false;
 #endif
     GPMPC_TRACE(1);
-    if constexpr (!TILED) {
+    if (!TILED && member == 0) {
         for (int i = tid; i < D; i += NT) p.mu_out[((size_t)c * (H + 1)) * D + i] = s_mu[i];
         for (int i = tid; i < D * D; i += NT) p.Sig_out[((size_t)c * (H + 1)) * D * D + i] = s_Sig2[i];
+    }
+
+    // ---- cooperative form: static owners of the step's work items ------------------------------------------------------
+    // diagonal pairs (always element-wise): their D * wtri items in order, an equal contiguous share per member; an off-diagonal
+    // pair in element-wise form: its wpp slots spread over all members (rotated by the pair's ordinal); a separable pair as a
+    // whole and a mean-sum item: one member each, counted down from the last member.
+    [[maybe_unused]] const int wtri_c = CL ? (s_tri[p.RC] + 63) >> 6 : 0;
+    if constexpr (CL) {
+        // the owners do not depend on the state: tabulated once per launch (the divisions by run-time values cost ~40 vector
+        // instructions each -- per step and wavefront they were ~5 k cycles)
+        for (int i = tid; i < P * wpp; i += NT) {
+            const int gq = i / wpp, slot = i - gq * wpp, ord = s_ord[gq];
+            int o;
+            if (s_pa[gq] == s_pb[gq]) o = slot < wtri_c ? ((ord * wtri_c + slot) * CS) / (D * wtri_c) : 255;
+            else o = ((slot * CS) / wpp + ord) % CS;
+            s_own[i] = (unsigned char)o;
+        }
+        for (int gq = tid; gq < P; gq += NT) {
+            const int ord = s_ord[gq];
+            s_sepown[gq] = (unsigned char)(CS - 1 - ord % CS);
+            bool need;
+            if (s_pa[gq] == s_pb[gq]) {
+                const int den = D * wtri_c;
+                need = (ord * wtri_c * CS) / den <= member && member <= (((ord + 1) * wtri_c - 1) * CS) / den;
+            } else {
+                const int mp = (member - ord % CS + CS) % CS;
+                const int s0 = (mp * wpp + CS - 1) / CS;
+                need = s0 < wpp && (s0 * CS) / wpp == mp;
+            }
+            s_elneed[gq] = need ? 1 : 0;
+        }
+        for (int a = tid; a < D; a += NT) s_meanown[a] = (unsigned char)(CS - 1 - ((P - D + a) % CS));
+        __syncthreads();
+    }
+    [[maybe_unused]] auto item_owner = [&](int code) -> int {
+        if (code >= 0xffff - 15) return s_meanown[0xffff - code];
+        const int gq = p.magic_wpp ? (int)__umulhi((unsigned)code, p.magic_wpp) : code;
+        return (s_K[gq] & 64) ? s_sepown[gq] : s_own[code];
+    };
+    // does this member own an item of pair gq (then it needs the pair's per-point factors)?
+    [[maybe_unused]] auto pair_needed = [&](int gq) -> bool { return (s_K[gq] & 64) ? s_sepown[gq] == member : s_elneed[gq] != 0; };
+    // one value of the step's exchange: two 8-byte words {tag | low}, {tag | high}
+    // Stores: write-through to the fabric (sc1) in general.  When every member of the candidate sits on ONE XCD -- verified below
+    // from HW_REG_XCC_ID, not assumed from the dispatch order -- they share that XCD's L2: a store that stays in L2 (sc0) is then
+    // visible to the other members' L1-bypassing (sc1) loads after one L2 round trip instead of a trip through the fabric
+    // (measured per horizon step: ~3 us -> see DESIGN).  A different placement changes the speed, never the protocol's validity.
+    [[maybe_unused]] unsigned x_tag = 0;
+    [[maybe_unused]] unsigned long long* x_cur = xbuf;
+    [[maybe_unused]] bool same_xcd = false;
+    [[maybe_unused]] auto publish = [&](int vi, double v) {
+        unsigned long long* g = x_cur + 2 * (size_t)vi;
+        const unsigned long long hi_tag = (unsigned long long)x_tag << 32;
+        if (same_xcd) {
+            __hip_atomic_store(g, hi_tag | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_store(g + 1, hi_tag | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            __hip_atomic_store(g, hi_tag | (unsigned)__double2loint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(g + 1, hi_tag | (unsigned)__double2hiint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    [[maybe_unused]] auto acquire = [&](int vi) -> double {
+        const unsigned long long* g = x_cur + 2 * (size_t)vi;
+#if defined(GPMPC_CL_DEBUG)
+        if (p.cl_dbg & 1) return 0.0;                                  // timing experiments: no wait at all / one read, no check
+        if (p.cl_dbg & 2) { const unsigned long long a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return (double)a; }
+#endif
+        for (int spins = 0; spins < (1 << 21); ++spins) {           // bounded: a member that never arrives must not hang the GPU
+            const unsigned long long a = __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned long long b = __hip_atomic_load(g + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(a >> 32) == x_tag && (unsigned)(b >> 32) == x_tag) return __hiloint2double((int)(unsigned)b, (int)(unsigned)a);
+            __builtin_amdgcn_s_sleep(1);
+        }
+        *s_fail = 1;
+        return __builtin_nan("");
+    };
+
+    if constexpr (CL) {
+        // prologue: the members' XCD ids through the placement-independent form (second buffer, tag of "step -1")
+        x_tag = p.xch_tag0;
+        x_cur = xbuf + (size_t)2 * p.xch_n;
+        const int my_xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));       // hwreg(HW_REG_XCC_ID, 0, 4)
+        if (tid == 0) publish(x_xcc + member, (double)my_xcc);
+        if (tid < 64) {
+            const bool differs = tid < CS && acquire(x_xcc + tid) != (double)my_xcc;
+            const unsigned long long any_differs = __ballot(differs);
+            if (tid == 0) s_fail[1] = (any_differs == 0 && !(p.cl_dbg & 4)) ? 1 : 0;        // (cluster_debug 4: the general form anyway, A/B)
+        }
+        __syncthreads();
+        same_xcd = s_fail[1] != 0;
+        if (*s_fail) {                                 // a member never arrived (bounded wait): poison the trajectory
+            if (member == 0) {
+                for (int i = tid; i < H * D; i += NT) p.mu_out[((size_t)c * (H + 1) + 1) * D + i] = __builtin_nan("");
+                for (int i = tid; i < H * D * D; i += NT) p.Sig_out[((size_t)c * (H + 1) + 1) * D * D + i] = __builtin_nan("");
+            }
+            return;
+        }
     }
 
     int cur = 0;
@@ -1007,6 +1152,11 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
         const int wave = tid >> 6;
         const double* s_Sig = s_Sig2 + cur * SD2;
         double* s_SigNext = s_Sig2 + (cur ^ 1) * SD2;
+        if constexpr (CL) {
+            // two exchange buffers by step parity: a member writes step t + 2 only after every member published t + 1, i.e. read t
+            x_tag = p.xch_tag0 + (unsigned)t + 1u;
+            x_cur = xbuf + (size_t)(t & 1) * 2 * p.xch_n;
+        }
 
         for (int q0 = 0; q0 < P || (TILED && q0 == 0); q0 += G) {       // TILED, D = 1: no pair, the mean part still runs
             const int Gc = (P - q0 < G) ? (P - q0) : G;
@@ -1234,6 +1384,20 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                 }
                 for (int k = 0; k < ns; ++k) s_items[start + k] = (unsigned short)(cls == 2 ? code0 : code0 + k);
                 if (lane == 0) *s_nitems = total_items;
+                if constexpr (CL) {
+                    // ... and, beside the per-point pass as well, the items of the list this member owns (lanes test 64 entries at a time)
+                    wave_lds_sync();
+                    int cnt = 0;
+                    for (int base = 0; base < total_items; base += 64) {
+                        const int k = base + lane;
+                        const int code = s_items[k < total_items ? k : 0];
+                        const bool mine = k < total_items && item_owner(code) == member;
+                        const unsigned long long mask = __ballot(mine);
+                        if (mine) s_mine[1 + cnt + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned short)code;
+                        cnt += __popcll(mask);
+                    }
+                    if (lane == 0) s_mine[0] = (unsigned short)cnt;
+                }
             }
             // The per-point items go to all wavefronts but the last one, which builds the work-item list above beside them (with
             // items of its own it was the last to reach the barrier: + 1.9 k cycles per step at config 2); narrow workgroups
@@ -1244,12 +1408,37 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
             //  slower for three (0.400 -> 0.415 ms; pass 6.5 k -> 7.9 k cycles per step; config 1 -10 %, B = 4096 per GPU -38 % with
             //  the spills of the wider live set): the pass is not bound by the latency of one thread's chain.
             //  profiles/r05c_forward_ab.txt, profiles/r05e_p2_three_chains_*.txt)
-            for (int it = tid; it < (nmean + Gc + n_off) * N && tid < p2_threads; it += p2_threads) {
-                const int prob = p.magic_pt ? (int)__umulhi((unsigned)it, p.magic_pt) : it;      // it / N
+            int p2_items = (nmean + Gc + n_off) * N;
+            if constexpr (CL) {
+                // only the problems this member owns items of, compacted per wavefront (lane = problem; 255 = nu alone, when
+                // the mean problem of output 0, which stores nu, is another member's)
+                const int nall = nmean + Gc + n_off;
+                bool need = false;
+                int code = lane;
+                if (lane < nmean) need = s_meanown[lane] == member;
+                else if (lane < nmean + Gc) need = pair_needed(lane - nmean);
+                else if (lane < nall) need = pair_needed(s_off[lane - nmean - Gc]);
+                else if (lane == nall) { need = s_meanown[0] != member; code = 255; }
+                const unsigned long long mask = __ballot(need);
+                if (need) s_needw[wave * 64 + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned char)code;
+                p2_items = __popcll(mask) * N;
+                wave_lds_sync();
+            }
+            for (int it = tid; it < p2_items && tid < p2_threads; it += p2_threads) {
+                int prob = p.magic_pt ? (int)__umulhi((unsigned)it, p.magic_pt) : it;      // it / N
                 const int pt = it - prob * N;
                 double nu[DP];
 #pragma unroll
                 for (int d = 0; d < DP; ++d) nu[d] = (d < D) ? (Xs[d * N + pt] - s_m[d]) : 0.0;
+                if constexpr (CL) {
+                    prob = s_needw[wave * 64 + prob];
+                    if (prob == 255) {
+#pragma unroll
+                        for (int d = 0; d < DP; ++d)
+                            if (d < D) a_nu[d * N + pt] = nu[d];
+                        continue;
+                    }
+                }
                 if (prob < nmean) {
                     const int a = prob;
                     const double* Ai = s_aug + a * (D * LD) + D;          // A_a^-1
@@ -1346,7 +1535,19 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                 }
                 return __builtin_amdgcn_readfirstlane(pulled);       // wave-uniform (SGPR) work item
             };
-            for (int wq = pull_item(); wq >= 0; wq = pull_item()) {
+            // cooperative form: no queue -- the j-th item this member owns (listed beside the per-point pass) goes to wavefront j mod NW
+            [[maybe_unused]] int cl_next = wave;
+            [[maybe_unused]] const int cl_count = CL ? (int)s_mine[0] : 0;
+            auto next_item = [&]() -> int {
+                if constexpr (!CL) return pull_item();
+                else {
+                    if (cl_next >= cl_count) return -1;
+                    const int code = __builtin_amdgcn_readfirstlane((int)s_mine[1 + cl_next]);
+                    cl_next += NW;
+                    return code;
+                }
+            };
+            for (int wq = next_item(); wq >= 0; wq = next_item()) {
                 if (wq >= 0xffff - 15) {
                     // s1[a][0] = sum_p lb, s1[a][1+d] = sum_p lb nu_d  (fixed order)
                     const int a = 0xffff - wq;
@@ -1355,7 +1556,10 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                         if (dd == 0) { for (int pt = lane; pt < N; pt += 64) v += a_lb[a * N + pt]; }
                         else { for (int pt = lane; pt < N; pt += 64) v = fma(a_lb[a * N + pt], a_nu[(dd - 1) * N + pt], v); }
                         v = wave_sum(v);
-                        if (lane == 0) s_s1[a * (D + 1) + dd] = v;
+                        if (lane == 0) {
+                            s_s1[a * (D + 1) + dd] = v;
+                            if constexpr (CL) publish(x_mean + a * (D + 1) + dd, v);
+                        }
                     }
                     continue;
                 }
@@ -1524,7 +1728,49 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     acc = valid ? acc : 0.0;
                 }
                 acc = wave_sum(acc);
-                if (lane == 0) s_part[wi] = acc;
+                if (lane == 0) {
+                    s_part[wi] = acc;
+                    if constexpr (CL) publish(wi, acc);
+                }
+            }
+#if defined(GPMPC_PROF_ON) && defined(GPMPC_PROF_BARRIER)
+            if constexpr (CL) __syncthreads();           // prof A/B: "items" then ends when the member's LAST wavefront is done
+#endif
+            GPMPC_TRACE(8);
+            if constexpr (CL) {
+                // totals of the separable pairs this member owns (its wavefronts filled the pair's moments), then every value of the
+                // step from whichever member formed it
+                const bool own_sep = __ballot(lane < Gc && (s_K[lane < Gc ? lane : 0] & 64) && s_sepown[lane < Gc ? lane : 0] == member) != 0;
+                if (own_sep) {
+                    __syncthreads();
+                    for (int gq = wave; gq < Gc; gq += NW) {
+                        const int Kraw = s_K[gq];
+                        if (!(Kraw & 64) || s_sepown[gq] != member) continue;
+                        const int C = s_mcum[Kraw & 63];
+                        const double* Gm = s_mom + (gq * 2) * rnd2(CM);
+                        const double* Wm = Gm + rnd2(CM);
+                        double v = 0.0;
+                        for (int al = lane; al < C; al += 64) v = fma(Gm[al] * Wm[al], c_monow[al], v);
+                        v = wave_sum(v);
+                        if (lane == 0) publish(x_sep + gq, v);
+                    }
+                }
+                // one value per lane: the list's pair items (the mean sums are its last nmean entries), then the nmean (D + 1) mean
+                // sums -- every lane runs the SAME wait loop once (divergent classes would queue their round trips one after another)
+                const int npair = total - nmean;
+                for (int k = tid; k < npair + nmean * (D + 1); k += NT) {
+                    int vi = -1;
+                    double* dst = nullptr;
+                    if (k < npair) {
+                        const int code = s_items[k];
+                        const int gq = p.magic_wpp ? (int)__umulhi((unsigned)code, p.magic_wpp) : code;
+                        if (!(s_K[gq] & 64)) { vi = code; dst = s_part + code; }
+                        else if (code == gq * wpp) { vi = x_sep + gq; dst = s_sepv + gq; }
+                    } else {
+                        vi = x_mean + (k - npair); dst = s_s1 + (k - npair);
+                    }
+                    if (vi >= 0) *dst = acquire(vi);
+                }
             }
 #if defined(GPMPC_PROF_ON)
             if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) prof_x[2] += __builtin_readcyclecounter() - prof_p3;     // this wavefront left the queue
@@ -1536,16 +1782,20 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
             for (int gq = wave; gq < Gc; gq += NW) {
                 const int Kraw = s_K[gq];
                 double v = 0.0;
-                if (Kraw & 64) {
-                    const int C = s_mcum[Kraw & 63];
-                    const double* Gm = s_mom + (gq * 2) * rnd2(CM);
-                    const double* Wm = Gm + rnd2(CM);
-                    for (int al = lane; al < C; al += 64) v = fma(Gm[al] * Wm[al], c_monow[al], v);
+                if ((Kraw & 64) && CL) {
+                    v = s_sepv[gq];                          // summed by the owning member in this very order
                 } else {
-                    const int ns = s_nslot[gq];              // the slots the list held (the others were empty: exact zeros before)
-                    for (int k = lane; k < ns; k += 64) v += s_part[gq * wpp + k];
+                    if (Kraw & 64) {
+                        const int C = s_mcum[Kraw & 63];
+                        const double* Gm = s_mom + (gq * 2) * rnd2(CM);
+                        const double* Wm = Gm + rnd2(CM);
+                        for (int al = lane; al < C; al += 64) v = fma(Gm[al] * Wm[al], c_monow[al], v);
+                    } else {
+                        const int ns = s_nslot[gq];              // the slots the list held (the others were empty: exact zeros before)
+                        for (int k = lane; k < ns; k += 64) v += s_part[gq * wpp + k];
+                    }
+                    v = wave_sum(v);
                 }
-                v = wave_sum(v);
                 if constexpr (TILED) {
                     const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
                     if (lane == 0) s_Sp[a * D - (a * (a - 1)) / 2 + (b - a)] = v * s_rdet[gq];
@@ -1584,15 +1834,25 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
             }
             const double v = S + s_Sig[idx] + (cij + cji);   // (cij + cji) commutes: Sigma stays exactly symmetric
             s_SigNext[idx] = v;
-            p.Sig_out[((size_t)c * (H + 1) + (t + 1)) * D * D + idx] = v;
+            if (member == 0) p.Sig_out[((size_t)c * (H + 1) + (t + 1)) * D * D + idx] = v;
         }
         for (int i = tid; i < D; i += NT) {
             const double v = s_mu[i] + s_M[i];
             s_mu[i] = v;
-            p.mu_out[((size_t)c * (H + 1) + (t + 1)) * D + i] = v;
+            if (member == 0) p.mu_out[((size_t)c * (H + 1) + (t + 1)) * D + i] = v;
         }
         cur ^= 1;
         __syncthreads();
+        if constexpr (CL) {
+            if (*s_fail) {
+                // a member never arrived (bounded wait): poison the rest of the trajectory instead of spinning on
+                if (member == 0) {
+                    for (int i = tid; i < (H - t) * D; i += NT) p.mu_out[((size_t)c * (H + 1) + (t + 1)) * D + i] = __builtin_nan("");
+                    for (int i = tid; i < (H - t) * D * D; i += NT) p.Sig_out[((size_t)c * (H + 1) + (t + 1)) * D * D + i] = __builtin_nan("");
+                }
+                return;
+            }
+        }
         GPMPC_TRACE(6);
     }
 #if defined(GPMPC_PROF_ON)
@@ -1600,9 +1860,14 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     if (blockIdx.x == 0 && threadIdx.x == 64) printf("PROF P1 pair problems done after %lld cycles (summed over steps)\n", prof_x[0]);
     if (blockIdx.x == 0 && threadIdx.x == NT - 1) printf("PROF P1 last thread done after %lld\n", prof_x[1]);
     if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) printf("PROF P3 wave %d left the queue after %lld\n", (int)(threadIdx.x >> 6), prof_x[2]);
+    if (CL && threadIdx.x == 0 && (blockIdx.x & 7) == 0)
+        printf("PROF member %2d xcc %d same_xcd %d\n", member, (int)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)), (int)same_xcd);
+    if (CL && threadIdx.x == 0 && (blockIdx.x & 7) == 0)
+        printf("PROF member %2d wall (10 ns ticks): P1 %lld | P2 %lld | items(wave 0) %lld | gather+wait %lld | P4 %lld | P5 %lld\n", member,
+               prof_wall[2], prof_wall[3], prof_wall[8], prof_wall[4], prof_wall[5], prof_wall[6]);
     if (threadIdx.x == 0 && blockIdx.x == 0)
-        printf("PROF cycles: init %lld | P1 %lld | P2 %lld | P3 %lld | P4 %lld | P5 %lld\n", prof_acc[1], prof_acc[2],
-               prof_acc[3], prof_acc[4], prof_acc[5], prof_acc[6]);
+        printf("PROF cycles: init %lld | P1 %lld | P2 %lld | P3 %lld (wave 0's items %lld) | P4 %lld | P5 %lld\n", prof_acc[1], prof_acc[2],
+               prof_acc[3], prof_acc[4] + prof_acc[8], prof_acc[8], prof_acc[5], prof_acc[6]);
 #endif
 }
 

@@ -109,6 +109,11 @@ class HipEngine:
         return int(self.lib.gpmpc_last_rollout_path(self._h))
 
     @property
+    def last_cluster(self):
+        """Workgroups per candidate of the last fused-horizon launch (1 = the plain kernel; > 1 = the few-candidate cooperative form)."""
+        return int(self.lib.gpmpc_last_cluster(self._h))
+
+    @property
     def last_grad_path(self):
         """Moment passes of the last `rollout_grad` (bit mask): 1 separable off-diagonal pairs, 2 tile moments of the diagonal
         pairs, 4 streaming element-wise pass, 8 the 8 < D <= 16 pass, 16 tile moments formed inside the batch-major forward."""

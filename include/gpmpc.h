@@ -95,6 +95,12 @@ int gpmpc_last_prepare_mode(gpmpc_t* h);
  * "tile_chunk" sets the candidates per tile workgroup. */
 int gpmpc_last_rollout_path(gpmpc_t* h);
 
+/* Workgroups per candidate of the last fused-horizon launch.  1 = one workgroup per candidate; > 1 = the few-candidate
+ * cooperative form: the reference evaluates ONE action sequence per objective call (restarts_optim 1-2,
+ * gp_mpc_controller.py:125-141), so while candidates x cluster fit the chip a cluster of workgroups shares each candidate's
+ * horizon step (bit-identical trajectories).  Option "cluster": 0 auto, 1 never, 2..32 fixed. */
+int gpmpc_last_cluster(gpmpc_t* h);
+
 /* Which moment passes the last gpmpc_rollout_grad launched (bit mask): 1 = off-diagonal output pairs in separable form on
  * the matrix cores, 2 = diagonal pairs batch-major over all (candidate, step) items, 4 = the streaming element-wise pass
  * (per-point arrays beyond the LDS), 8 = the 8 < D <= 16 pass, 16 (with 2) = the diagonal pairs' moments were formed by the

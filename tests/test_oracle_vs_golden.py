@@ -261,3 +261,48 @@ def test_training_loss_closed_form_gradient_matches_autograd():
         assert abs(loss - lt.item()) < 1e-10 * abs(loss)
         assert rel_err(g_ls, ls.grad.numpy()) < 1e-8
         assert abs(g_os - osc.grad.item()) < 1e-8 * abs(g_os) and abs(g_nz - nz.grad.item()) < 1e-8 * abs(g_nz)
+
+
+def test_training_loss_matches_independent_third_party_log_densities():
+    """An independent pin for the loss the reference delegates to gpytorch (gp_model.py:262-275).  gpytorch's
+    ExactMarginalLogLikelihood wraps `MultivariateNormal(mean, K + noise I).log_prob(y) / num_data`; gpytorch itself is
+    absent from this image, but two third-party implementations of that log-density are not: torch.distributions (the
+    class gpytorch's MultivariateNormal extends) and scipy.stats.  Both must give oracle/gp_training.py's loss.
+    (Parity stays 'unpinned' by the rule -- no reference RUN produced these numbers -- but the restatement is no longer
+    checked against itself only.)"""
+    import torch
+    from scipy.stats import multivariate_normal
+    from oracle import gp_training, synth
+    for N, seed in ((40, 9), (120, 3)):
+        w = synth.make_workload(N, 3, 1, 3, 2, seed=seed)
+        K = orc.rbf_ard_gram(w.X, w.lengthscales, w.outputscales)
+        for a in range(3):
+            loss = gp_training.neg_mll_and_grad(w.X, w.Y[:, a], w.lengthscales[a], w.outputscales[a], w.noises[a])[0]
+            cov = K[a] + w.noises[a] * np.eye(N)
+            mvn = torch.distributions.MultivariateNormal(torch.zeros(N, dtype=torch.float64), covariance_matrix=torch.as_tensor(cov))
+            lp_torch = float(mvn.log_prob(torch.as_tensor(w.Y[:, a]))) / N
+            lp_scipy = float(multivariate_normal.logpdf(w.Y[:, a], mean=np.zeros(N), cov=cov)) / N
+            assert abs(loss + lp_torch) < 1e-10 * abs(loss), (loss, lp_torch)
+            assert abs(loss + lp_scipy) < 1e-9 * abs(loss), (loss, lp_scipy)       # scipy factorises by eigendecomposition
+
+
+def test_gram_matrix_matches_the_expanded_distance_form():
+    """K(X, X) (gp_model.py:391,425 -- the one gpytorch call on the hot path) evaluated a second, differently ordered way:
+    gpytorch's RBFKernel scales the inputs by 1/lengthscale, centres them, forms ||x||^2 + ||x'||^2 - 2 x.x' by a matrix
+    product, zeroes the diagonal, clamps at 0 and applies exp(-d/2); ScaleKernel multiplies by the outputscale.  The
+    oracle's direct-difference form must agree with that to fp64 rounding of the expanded form (~1e-14 absolute on d)."""
+    from oracle import synth
+    w = synth.make_workload(150, 4, 2, 3, 2, seed=5)
+    K = orc.rbf_ard_gram(w.X, w.lengthscales, w.outputscales)
+    for a in range(4):
+        x = w.X / w.lengthscales[a]
+        x = x - x.mean(axis=0)
+        n2 = (x * x).sum(axis=1)
+        d = n2[:, None] + n2[None, :] - 2.0 * (x @ x.T)
+        np.fill_diagonal(d, 0.0)
+        Ke = w.outputscales[a] * np.exp(-0.5 * np.maximum(d, 0.0))
+        assert np.max(np.abs(Ke - K[a])) < 1e-13 * w.outputscales[a] * 50
+        # and what that difference becomes after the factorisation (cond ~ 1e6): far inside the 1e-5 north-star bound
+        iK1, b1 = orc.factorize(w.X, w.Y[:, a:a + 1], w.lengthscales[a:a + 1], w.outputscales[a:a + 1], w.noises[a:a + 1])
+        iK2, b2 = orc.factorize(w.X, w.Y[:, a:a + 1], w.lengthscales[a:a + 1], w.outputscales[a:a + 1], w.noises[a:a + 1], K=Ke[None])
+        assert rel_err(b2, b1) < 1e-7 and rel_err(iK2, iK1) < 1e-7
