@@ -50,6 +50,7 @@ SIGNATURES = {
     "gpmpc_set_cost": (C.c_int, [_P, _P, _P, _P, _D, _I, _P, _P, _I, _I]),
     "gpmpc_rollout": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P]),
     "gpmpc_rollout_grad": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _P, _P, _P, _P, _P, _P]),
+    "gpmpc_objective_grad_host": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _D, C.POINTER(C.POINTER(_D)), _P]),
     "gpmpc_rollout_timed": (C.c_int, [_P, _P, _P, _P, _I, _I, _I, _I, _D, _P, _I, C.POINTER(C.c_float), _P]),
     "gpmpc_cem_search": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _D, _I, _I, C.c_ulonglong, _P, _I, _P, _P, _P, _P, _P]),
     "gpmpc_cem_local": (C.c_int, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _D, _I, _I, C.c_ulonglong, _P, _I, _P, _P, _P, _P, _P, _P]),
@@ -59,7 +60,7 @@ SIGNATURES = {
 }
 
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 
 def load(path=LIB_PATH):

@@ -145,17 +145,15 @@ class GpMpcController(BaseControllerObject):
         self.transition_model.set_cost(self.config.reward)
         if self.analytic_gradient:
             try:
-                out = self.transition_model.objective_and_gradient_batch(base[None], obs_mu, obs_var, self.iter_ctrl,
-                                                                         trajectories=True)
+                host = self.transition_model.objective_and_gradient_host(base, obs_mu, obs_var, self.iter_ctrl)
             except GpmpcError as e:
                 if e.code != GPMPC_ERR_LIMIT:
                     raise
                 self.analytic_gradient = False         # shape outside the gradient kernels: difference the rollout
             else:
                 self.num_rollouts += 1
-                host = self.transition_model.engine.host_views(out)          # one device-to-host copy for everything
-                grad = self.actions_mapper.chain_grad_model_to_mpc(host["grad"][0].numpy())
-                self._cache_trajectory(host, 0)
+                grad = self.actions_mapper.chain_grad_model_to_mpc(host["grad"][0])
+                self._cache_trajectory({k: torch.from_numpy(v) for k, v in host.items()}, 0)
                 return float(host["J"][0]), grad
         J, g_model, out = self._objective_and_gradient_by_differences(base[None], obs_mu, obs_var, trajectories=True)
         grad = self.actions_mapper.chain_grad_model_to_mpc(g_model[0])

@@ -295,6 +295,15 @@ class GpStateTransitionModel(AbstractStateTransitionModel):
         return self.engine.rollout_grad(actions, _t(obs_mu).numpy(), _t(obs_var).numpy(), self.config.include_time_model,
                                         float(current_time_idx), trajectories)
 
+    def objective_and_gradient_host(self, actions, obs_mu, obs_var, current_time_idx=0):
+        """ONE sequence (H, A) -> dict of HOST (numpy) arrays J (1,), grad (1,H,A), mu, Sig, cost_mu, cost_var: the shape of call
+        scipy's L-BFGS-B makes (gp_mpc_controller.py:133-141, 229-285), served by gpmpc_objective_grad_host with one
+        synchronisation and no torch tensors in between."""
+        if self._cost_key is None:
+            raise RuntimeError("call set_cost(reward_config) before predicting")
+        return self.engine.objective_grad_host(np.asarray(actions, dtype=np.float64), _t(obs_mu).numpy(), _t(obs_var).numpy(),
+                                               self.config.include_time_model, float(current_time_idx))
+
     def predict_trajectory(self, actions, obs_mu, obs_var, len_horizon, current_time_idx):
         """Same signature / return shapes as the reference (:60-110): ((H+1,D), (H+1,D,D)) CPU tensors."""
         out = self.predict_trajectory_batch(_t(actions)[None], obs_mu, obs_var, len_horizon, current_time_idx,

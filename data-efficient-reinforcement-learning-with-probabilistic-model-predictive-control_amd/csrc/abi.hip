@@ -53,7 +53,7 @@ static void free_buf(Buf& b) {
 
 extern "C" {
 
-int gpmpc_abi_version(void) { return 11; }
+int gpmpc_abi_version(void) { return 12; }
 
 int gpmpc_create(gpmpc_t** out, int device_id) {
     if (!out) return GPMPC_ERR_ARG;
@@ -81,8 +81,9 @@ int gpmpc_destroy(gpmpc_t* g) {
     (void)hipSetDevice(h->device);
     Buf* all[] = {&h->Xt, &h->beta, &h->iK, &h->Tm, &h->ils2, &h->var, &h->logvar, &h->gram,
                   &h->linv, &h->zvec, &h->cost, &h->best, &h->xrange, &h->mono_w, &h->traj, &h->Xc, &h->Yc,
-                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws, &h->cemws, &h->tilews, &h->sepw, &h->tgradws, &h->xch};
+                  &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws, &h->cemws, &h->tilews, &h->sepw, &h->tgradws, &h->xch, &h->hio};
     for (Buf* b : all) free_buf(*b);
+    if (h->hio_host) (void)hipHostFree(h->hio_host);
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);
     if (h->septab) (void)hipFree(h->septab);
@@ -279,6 +280,72 @@ int gpmpc_rollout_grad(gpmpc_t* g, const double* actions, const double* mu0, con
     GPMPC_HIP_CHECK(H_(g), hipSetDevice(g->h.device));
     a.mu_out = mu_out; a.Sig_out = Sig_out; a.J_out = J_out; a.cm_out = cm_out; a.cv_out = cv_out;
     return launch_rollout_grad(H_(g), a, grad_out, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One evaluation for a host-side optimiser: the action sequence travels to the device as a kernel argument (no DMA engine
+// start-up for 200 bytes), the results come back through a pinned, device-mapped host buffer written by a copy kernel, one
+// stream synchronisation.
+namespace {
+constexpr int kUploadMax = 480;                        // doubles in the argument block (< 4 KiB)
+struct UploadArgs { double v[kUploadMax]; };
+__global__ __launch_bounds__(64) void upload_kernel(double* dst, int n, const UploadArgs a) {
+    for (int i = threadIdx.x; i < n; i += 64) dst[i] = a.v[i];
+}
+__global__ __launch_bounds__(256) void export_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
+}
+}  // namespace
+
+int gpmpc_objective_grad_host(gpmpc_t* g, const double* actions_host, const double* mu0, const double* S0, int H, int A,
+                              int include_time, double time0, const double** result_host, void* stream) {
+    Range roctx_range("gpmpc_objective_grad_host");
+    if (!g) return GPMPC_ERR_ARG;
+    if (!actions_host || !result_host) return bad(g, "null argument");
+    Handle* h = H_(g);
+    hipStream_t s = (hipStream_t)stream;
+    RolloutArgs a;
+    int rc = fill_args(g, a, actions_host, mu0, S0, 1, H, A, include_time, time0);
+    if (rc) return rc;
+    if (A < 1) return bad(g, "gradient needs A >= 1");
+    GPMPC_HIP_CHECK(h, hipSetDevice(h->device));
+    const int D = h->D, n_act = H * A;
+    const size_t n_out = 1 + (size_t)n_act + (size_t)(H + 1) * (D + D * D + 2);
+    rc = grow(h, h->hio, (size_t)n_act + n_out);
+    if (rc) return rc;
+    if (h->hio_host_cap < n_out) {
+        if (h->hio_host) GPMPC_HIP_CHECK(h, hipHostFree(h->hio_host));
+        h->hio_host = nullptr; h->hio_host_dev = nullptr; h->hio_host_cap = 0;
+        GPMPC_HIP_CHECK(h, hipHostMalloc(reinterpret_cast<void**>(&h->hio_host), n_out * sizeof(double), hipHostMallocMapped));
+        GPMPC_HIP_CHECK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->hio_host_dev), h->hio_host, 0));
+        h->hio_host_cap = n_out;
+    }
+    double* act_dev = h->hio.p;
+    double* out_dev = act_dev + n_act;
+    if (n_act <= kUploadMax) {
+        UploadArgs u;
+        memcpy(u.v, actions_host, n_act * sizeof(double));
+        hipLaunchKernelGGL(upload_kernel, dim3(1), dim3(64), 0, s, act_dev, n_act, u);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+    } else {
+        GPMPC_HIP_CHECK(h, hipMemcpyAsync(act_dev, actions_host, n_act * sizeof(double), hipMemcpyHostToDevice, s));
+    }
+    a.actions = act_dev;
+    double* q = out_dev;
+    a.J_out = q; q += 1;
+    double* grad = q; q += n_act;
+    a.mu_out = q; q += (size_t)(H + 1) * D;
+    a.Sig_out = q; q += (size_t)(H + 1) * D * D;
+    a.cm_out = q; q += H + 1;
+    a.cv_out = q;
+    rc = launch_rollout_grad(h, a, grad, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(export_kernel, dim3((unsigned)((n_out + 255) / 256 < 8 ? (n_out + 255) / 256 : 8)), dim3(256), 0, s, out_dev,
+                       h->hio_host_dev, (int)n_out);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
+    *result_host = h->hio_host;
+    return GPMPC_OK;
 }
 
 int gpmpc_cem_search(gpmpc_t* g, const double* mu0, const double* S0, int B, int H, int A, int include_time, double time0,

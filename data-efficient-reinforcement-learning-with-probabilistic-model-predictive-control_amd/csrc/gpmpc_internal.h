@@ -129,6 +129,10 @@ struct Handle {
     int* mismatch = nullptr;     // device flag of the prefix comparison
     int inc_updates = 0;         // border updates since the last full factorisation
     bool have_state = false;     // Xc / Yc / hyp describe the cached factors
+    Buf hio;      // gpmpc_objective_grad_host: actions | J | grad | mu | Sig | cost_mu | cost_var of one candidate (device side)
+    double* hio_host = nullptr;      // ... and its pinned, device-mapped host mirror (results)
+    double* hio_host_dev = nullptr;
+    size_t hio_host_cap = 0;
     Buf xch;      // exchange granules of the cooperative few-candidate kernel (zeroed when (re)allocated, tags never repeat)
     unsigned xch_epoch = 0;      // launches that used `xch` since it was last zeroed
     int opt_cluster = 0;         // workgroups per candidate of the few-candidate path: 0 auto, 1 never, n >= 2 fixed

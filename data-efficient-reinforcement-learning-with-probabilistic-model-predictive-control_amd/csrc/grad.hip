@@ -85,7 +85,9 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     // (2.86 vs 2.10 ms), so one column unless asked (option "grad_cols_per_lane")
     const int cols = (h->opt_grad_cols == 2) ? 2 : 1;
     const int NCU = (N + cols - 1) / cols;
-    const int sweep_nt = DP <= 4 ? 64 : 256;
+    // D <= 4: the sweep is one wavefront's, its prologue (cost adjoints and state-independent algebra of all H steps) every
+    // wavefront's of the launch -- 8 of them (512 threads: 256 VGPRs, the 1024-thread form spills at D = 4) while each candidate has a CU to itself, 4 up to four per CU, else the one
+    const int sweep_nt = DP <= 4 ? (B <= h->num_cu ? 512 : (B <= 4 * h->num_cu ? 256 : 64)) : 256;
     int CH = 0, RC = 0, NR = 0, wpp = 0, G = 0, gz = 1;
     size_t mom_lds = 0;
     int pairs_left = P;              // pairs the LDS-resident pass works on (known after the separable / tile passes were dispatched)
@@ -330,9 +332,9 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     }
     if (rc) return rc;
     switch (DP) {
-        case 2:  rc = launch_sweep<2, 64>(h, g, (size_t)SL.total * 8, s); break;
-        case 3:  rc = launch_sweep<3, 64>(h, g, (size_t)SL.total * 8, s); break;
-        case 4:  rc = launch_sweep<4, 64>(h, g, (size_t)SL.total * 8, s); break;
+        case 2:  rc = sweep_nt == 512 ? launch_sweep<2, 512>(h, g, (size_t)SL.total * 8, s) : (sweep_nt == 256 ? launch_sweep<2, 256>(h, g, (size_t)SL.total * 8, s) : launch_sweep<2, 64>(h, g, (size_t)SL.total * 8, s)); break;
+        case 3:  rc = sweep_nt == 512 ? launch_sweep<3, 512>(h, g, (size_t)SL.total * 8, s) : (sweep_nt == 256 ? launch_sweep<3, 256>(h, g, (size_t)SL.total * 8, s) : launch_sweep<3, 64>(h, g, (size_t)SL.total * 8, s)); break;
+        case 4:  rc = sweep_nt == 512 ? launch_sweep<4, 512>(h, g, (size_t)SL.total * 8, s) : (sweep_nt == 256 ? launch_sweep<4, 256>(h, g, (size_t)SL.total * 8, s) : launch_sweep<4, 64>(h, g, (size_t)SL.total * 8, s)); break;
         case 6:  rc = launch_sweep<6, 256>(h, g, (size_t)SL.total * 8, s); break;
         default: rc = launch_sweep<8, 256>(h, g, (size_t)SL.total * 8, s); break;
     }

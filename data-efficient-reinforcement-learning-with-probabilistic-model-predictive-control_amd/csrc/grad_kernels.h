@@ -716,18 +716,33 @@ __device__ inline void cost_adjoint_wave(int lane, int D, int A, bool terminal, 
     }
 }
 
-// One workgroup per candidate (one wavefront for D <= 4: every hand-off is then a wave-level LDS sync).
+// One workgroup per candidate.  D <= 4: the reverse sweep itself runs on ONE wavefront (every hand-off is then a wave-level LDS
+// sync), but the prologue -- the cost adjoints of the H + 1 time steps and the state-independent small algebra of every step,
+// all independent of each other -- is spread over all NT / 64 wavefronts of the launch (round 6: on one wavefront it was half of the
+// kernel at config 2, 58 of 123 us at B = 1); the other wavefronts leave before the sweep.
 // DX = exact state dimension at compile time (0: runtime p.D <= DP): the index arithmetic of this latency-bound kernel
 // (divisions by D and D*D, pair decoding) then folds into constants.
 template <int DP, int NT, int DX>
 __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NT / kWave;
-    constexpr int NPF = kSweepPrefetch<DP, NT>;
+    constexpr int NL = (DP <= 4) ? 64 : NT;          // threads of the reverse sweep proper
+    constexpr int NPF = kSweepPrefetch<DP, NL>;
     // LDS-only hand-off: the fences name the local address space, so a sync does not wait for the global loads of the
     // next step that are in flight
-    auto sync = [] {
+    auto sync_all = [] {                             // prologue: all wavefronts of the launch
         if constexpr (NT == 64) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+        } else {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+        }
+    };
+    auto sync = [] {
+        if constexpr (NL == 64) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
@@ -784,7 +799,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
     for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
     for (int i = tid; i < D; i += NT) c_var[i] = p.var[i];
     for (int i = tid; i < n + n * n + DD + 2 * D; i += NT) c_cost[i] = p.cost[i];
-    sync();
+    sync_all();
     // cost adjoints of every time step (independent of the sweep): one wavefront per step
     for (int t = wave; t <= H; t += NW) {
         const bool terminal = (t == H);
@@ -794,13 +809,13 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
                           gmu + t * D, gSig + t * DD, terminal ? ctmp + wave * (2 * n * n + 3 * n) : gu + t * A);
         wave_lds_sync();
     }
-    sync();
+    sync_all();
     for (int i = tid; i < D; i += NT) mubar[i] = gmu[H * D + i];
     for (int i = tid; i < DD; i += NT) {
         const int r = i / D, q = i - r * D;
         Sigbar[i] = 0.5 * (gSig[H * DD + i] + gSig[H * DD + q * D + r]);
     }
-    sync();
+    sync_all();
 
     // ---- state-independent small algebra of every step, all steps in parallel (lanes over (step, problem)) -----------
     const int oCC = D * DD, oRI = oCC + D, oZ = oRI + P * DD, oRD = oZ + P * DD, oY = oRD + P, oV = oY + DD, oM = oV + DD;
@@ -840,7 +855,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
                     base[oRD + prob - D] = 1.0 / sqrt(det);
                 }
             }
-            sync();
+            sync_all();
             for (int idx = tid; idx < H * P * DD; idx += NT) {
                 const int t = idx / (P * DD), i = idx - t * (P * DD);
                 const int q = i / DD, r = (i - q * DD) / D, cc = i - q * DD - r * D;
@@ -860,17 +875,18 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
                 base[oV + k * D + a] = base[oCC + a] * v;
                 if (k == 0) base[oM + a] = base[oCC + a] * ms[0];
             }
-            sync();
+            sync_all();
         }
     }
-    // NPF values per lane cover P*NSP and D*NM (host checks the bound); E, D*D <= NT
+    // NPF values per lane cover P*NSP and D*NM (host checks the bound); E, D*D <= NL
+    if constexpr (NL < NT) { if (tid >= NL) return; }          // the sweep is one wavefront's
     double pf_mom[NPF], pf_ms[NPF], pf_m = 0.0, pf_Sig = 0.0;
     auto fetch = [&](int t) {
         const double* mom = p.mom + ((size_t)c * H + t) * P * NSP;
         const double* ms = p.msum + ((size_t)c * H + t) * D * NM;
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
-            const int i = tid + k * NT;
+            const int i = tid + k * NL;
             pf_mom[k] = (i < P * NSP) ? mom[i] : 0.0;
             pf_ms[k] = (i < D * NM) ? ms[i] : 0.0;
         }
@@ -887,7 +903,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         {
 #pragma unroll
             for (int k = 0; k < NPF; ++k) {
-                const int i = tid + k * NT;
+                const int i = tid + k * NL;
                 if (i < P * NSP) s_mom[i] = pf_mom[k];
                 if (i < D * NM) s_ms[i] = pf_ms[k];
             }
@@ -898,7 +914,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
                 double* base = s_pre + t * NQ;
                 s_Ai = base; s_cc = base + oCC; s_Ri = base + oRI; s_Z = base + oZ; s_rdet = base + oRD;
                 s_y = base + oY; s_V = base + oV; s_M = base + oM;
-                for (int i = tid; i < DD; i += NT) {
+                for (int i = tid; i < DD; i += NL) {
                     const int r = i / D, q = i - r * D;
                     s_Sb[i] = 0.5 * (Sigbar[i] + Sigbar[q * D + r]);
                 }
@@ -908,7 +924,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         GPMPC_STRACE(0);
         if (!pre) {
         // ---- small solves: A_a^-1, c_a;  R_ab^-1, Z_ab, 1/sqrt det R_ab --------------------------------
-        constexpr int PSTEP = (DP <= 4) ? NT : kSweepAug;        // LDS solves: kSweepAug threads, one augmented block each
+        constexpr int PSTEP = (DP <= 4) ? NL : kSweepAug;        // LDS solves: kSweepAug threads, one augmented block each
         for (int prob = tid; prob < D + P && tid < PSTEP; prob += PSTEP) {
             int a = prob, b = prob;
             if (prob >= D) pair_of(prob - D, a, b);
@@ -955,32 +971,32 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
                 s_rdet[prob - D] = 1.0 / sqrt(det);
             }
         }
-        for (int i = tid; i < DD; i += NT) {
+        for (int i = tid; i < DD; i += NL) {
             const int r = i / D, q = i - r * D;
             s_Sb[i] = 0.5 * (Sigbar[i] + Sigbar[q * D + r]);
         }
         sync();
         GPMPC_STRACE(1);
         // ---- Z = R^-1 Sigma;  y = A^-1 s1, V, M --------------------------------------------------------
-        for (int i = tid; i < P * DD; i += NT) {
+        for (int i = tid; i < P * DD; i += NL) {
             const int q = i / DD, r = (i - q * DD) / D, cc = i - q * DD - r * D;
             double v = 0.0;
             for (int k = 0; k < D; ++k) v = fma(s_Ri[q * DD + r * D + k], s_Sig[k * D + cc], v);
             s_Z[i] = v;
         }
-        for (int i = tid; i < DD; i += NT) {
+        for (int i = tid; i < DD; i += NL) {
             const int a = i / D, k = i - a * D;
             double v = 0.0;
             for (int j = 0; j < D; ++j) v = fma(s_Ai[a * DD + k * D + j], s_ms[a * NM + 1 + j], v);
             s_y[a * D + k] = v;
             s_V[k * D + a] = s_cc[a] * v;
         }
-        for (int a = tid; a < D; a += NT) s_M[a] = s_cc[a] * s_ms[a * NM];
+        for (int a = tid; a < D; a += NL) s_M[a] = s_cc[a] * s_ms[a * NM];
         sync();
         }
         GPMPC_STRACE(2);
         // ---- Sigma' = Sigma + S + Sigma V + (Sigma V)^T,  mu' = mu + M,  S -= M M^T ------------------
-        for (int i = tid; i < DD; i += NT) {
+        for (int i = tid; i < DD; i += NL) {
             const int r = i / D, q = i - r * D;
             double acc = s_Sb[i], vb = 0.0;
             for (int k = 0; k < D; ++k) {
@@ -990,13 +1006,13 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             Sacc[i] = acc;
             s_Vb[i] = vb;
         }
-        for (int a = tid; a < D; a += NT) {
+        for (int a = tid; a < D; a += NL) {
             double v = mubar[a];
             for (int b = 0; b < D; ++b) v = fma(-2.0 * s_Sb[a * D + b], s_M[b], v);
             s_Mb[a] = v;
         }
         // pairs: RZ = R^-T Z_bar,  Z_bar = 1/2 W_bar P2
-        for (int i = tid; i < P * DD; i += NT) {
+        for (int i = tid; i < P * DD; i += NL) {
             const int q = i / DD, r = (i - q * DD) / D, cc = i - q * DD - r * D;
             int a, b;
             pair_of(q, a, b);
@@ -1008,13 +1024,13 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         }
         sync();
         GPMPC_STRACE(3);
-        for (int i = tid; i < DD; i += NT) {
+        for (int i = tid; i < DD; i += NL) {
             const int a = i / D, k = i - a * D;
             double v = 0.0;
             for (int j = 0; j < D; ++j) v = fma(s_Ai[a * DD + k * D + j], s_Vb[j * D + a], v);
             s_s1b[a * D + k] = s_cc[a] * v;                                      // s1_bar = c A^-1 v_bar
         }
-        for (int a = tid; a < D; a += NT) {
+        for (int a = tid; a < D; a += NL) {
             double v = s_Mb[a] * s_ms[a * NM];
             for (int k = 0; k < D; ++k) v = fma(s_Vb[k * D + a], s_y[a * D + k], v);
             s_cb[a] = v;                                                         // c_bar
@@ -1022,7 +1038,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         }
         // pairs: K_q = RZ + (coef R^-T - RZ Z^T) diag(dab);  m_q
         if constexpr (DP <= 4) {
-            for (int i = tid; i < P * DD; i += NT) {                 // one thread per element, own buffer
+            for (int i = tid; i < P * DD; i += NL) {                 // one thread per element, own buffer
                 const int q = i / DD, r = (i - q * DD) / D, cc = i - q * DD - r * D;
                 int a, b;
                 pair_of(q, a, b);
@@ -1033,7 +1049,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
                 s_Kq[i] = s_RZ[i] + (coef * s_Ri[q * DD + cc * D + r] - rzzt) * (c_ils2[a * E + cc] + c_ils2[b * E + cc]);
             }
         } else {
-            for (int i = tid; i < P * D; i += NT) {                  // one thread per row, in place over RZ (LDS budget)
+            for (int i = tid; i < P * D; i += NL) {                  // one thread per row, in place over RZ (LDS budget)
                 const int q = i / D, r = i - q * D;
                 int a, b;
                 pair_of(q, a, b);
@@ -1054,7 +1070,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
                 }
             }
         }
-        for (int i = tid; i < P * E; i += NT) {
+        for (int i = tid; i < P * E; i += NL) {
             const int q = i / E, e = i - q * E;
             int a, b;
             pair_of(q, a, b);
@@ -1073,7 +1089,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         sync();
         GPMPC_STRACE(4);
         // ---- mean part: G1, G2, Ge from the stored moments (q_bar_i = -1/2 lb_i (s0_bar + s1_bar . nu_i)) ----
-        for (int i = tid; i < D * NG; i += NT) {
+        for (int i = tid; i < D * NG; i += NL) {
             const int a = i / NG, k = i - a * NG;
             const double* ms = s_ms + a * NM;
             const double* Q2 = ms + 1 + D;
@@ -1098,13 +1114,13 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         }
         sync();
         GPMPC_STRACE(5);
-        for (int i = tid; i < D * DD; i += NT) {
+        for (int i = tid; i < D * DD; i += NL) {
             const int a = i / DD, k = (i - a * DD) / D, l = i - a * DD - k * D;
             const double* G2 = s_Gs + a * NG + D;
             s_Aib[i] = 0.5 * s_cc[a] * (s_Vb[k * D + a] * s_ms[a * NM + 1 + l] + s_Vb[l * D + a] * s_ms[a * NM + 1 + k])
                      + 0.5 * (G2[k * D + l] + G2[l * D + k]);
         }
-        for (int i = tid; i < D * E; i += NT) {
+        for (int i = tid; i < D * E; i += NL) {
             const int a = i / E, e = i - a * E;
             const double* G1 = s_Gs + a * NG;
             double v;
@@ -1120,7 +1136,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         sync();
         GPMPC_STRACE(6);
         // A_bar = -A^-1 Ai_bar A^-1 - 1/2 c_bar c A^-1
-        for (int i = tid; i < D * DD; i += NT) {
+        for (int i = tid; i < D * DD; i += NL) {
             const int a = i / DD, r = (i - a * DD) / D, cc = i - a * DD - r * D;
             const double* Ai = s_Ai + a * DD;
             double v = 0.0;
@@ -1134,13 +1150,13 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         sync();
         GPMPC_STRACE(7);
         // ---- assemble (fixed order) -------------------------------------------------------------------
-        for (int i = tid; i < DD; i += NT) {
+        for (int i = tid; i < DD; i += NL) {
             double v = Sacc[i];
             for (int a = 0; a < D; ++a) v += s_Ab[a * DD + i];
             for (int q = 0; q < P; ++q) v += s_Kq[q * DD + i];
             Sacc[i] = v;
         }
-        for (int e = tid; e < E; e += NT) {
+        for (int e = tid; e < E; e += NL) {
             double v = (e < D) ? mubar[e] : 0.0;
             for (int a = 0; a < D; ++a) v += s_mba[a * E + e];
             for (int q = 0; q < P; ++q) v += s_mq[q * E + e];
@@ -1148,12 +1164,12 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         }
         sync();
         GPMPC_STRACE(8);
-        for (int i = tid; i < DD; i += NT) {
+        for (int i = tid; i < DD; i += NL) {
             const int r = i / D, q = i - r * D;
             Sigbar[i] = 0.5 * (Sacc[i] + Sacc[q * D + r]) + 0.5 * (gSig[t * DD + i] + gSig[t * DD + q * D + r]);
         }
-        for (int i = tid; i < D; i += NT) mubar[i] = mbar[i] + gmu[t * D + i];
-        for (int i = tid; i < A; i += NT) p.grad[((size_t)c * H + t) * A + i] = mbar[D + i] + gu[t * A + i];
+        for (int i = tid; i < D; i += NL) mubar[i] = mbar[i] + gmu[t * D + i];
+        for (int i = tid; i < A; i += NL) p.grad[((size_t)c * H + t) * A + i] = mbar[D + i] + gu[t * A + i];
         sync();
         GPMPC_STRACE(9);
     }

@@ -217,6 +217,26 @@ class HipEngine:
                                                 out["cost_var"].data_ptr() if trajectories else None, self._stream()))
         return out
 
+    def objective_grad_host(self, actions, mu0, S0, include_time=False, time0=0.0):
+        """ONE action sequence (H, A) on the host -> objective, gradient, trajectory and stage costs on the host
+        (gpmpc_objective_grad_host: the sequence travels as a kernel argument, the results through a pinned host buffer,
+        one synchronisation) -- what a host-side optimiser that evaluates one sequence per call needs (the reference's
+        scipy L-BFGS-B loop, gp_mpc_controller.py:133-141).  Returns numpy arrays (copies: the buffer is reused)."""
+        actions = _host(actions)
+        H, A = actions.shape
+        D = self.D
+        mu0 = _host(mu0, (D,))
+        S0 = _host(S0, (D, D))
+        res = C.POINTER(C.c_double)()
+        self._check(self.lib.gpmpc_objective_grad_host(self._h, _hp(actions), _hp(mu0), _hp(S0), H, A, int(bool(include_time)),
+                                                       float(time0), C.byref(res), self._stream()))
+        n = 1 + H * A + (H + 1) * (D + D * D + 2)
+        flat = np.ctypeslib.as_array(res, shape=(n,)).copy()
+        o = np.cumsum([0, 1, H * A, (H + 1) * D, (H + 1) * D * D, H + 1, H + 1])
+        return {"J": flat[o[0]:o[1]], "grad": flat[o[1]:o[2]].reshape(1, H, A), "mu": flat[o[2]:o[3]].reshape(1, H + 1, D),
+                "Sig": flat[o[3]:o[4]].reshape(1, H + 1, D, D), "cost_mu": flat[o[4]:o[5]].reshape(1, H + 1),
+                "cost_var": flat[o[5]:o[6]].reshape(1, H + 1)}
+
     @staticmethod
     def host_views(out):
         """All tensors of a `rollout_grad` result on the host with a single device-to-host copy."""

@@ -215,6 +215,18 @@ int gpmpc_rollout_grad(gpmpc_t* h, const double* actions_dev, const double* mu0_
                        double* mu_out_dev, double* Sig_out_dev, double* cost_mu_out_dev, double* cost_var_out_dev,
                        void* stream);
 
+/*
+ * gpmpc_objective_grad_host  <->  ONE call of compute_mean_lcb_trajectory (gp_mpc_controller.py:229-285) as scipy's L-BFGS-B
+ * makes it (:133-141: one action sequence per evaluation, host arrays in, (float, host gradient) out): gpmpc_rollout_grad for
+ * B = 1 with host buffers on both sides and ONE synchronisation of `stream`.
+ *   actions_host (H, A) model-space actions
+ *   *result_host: pinned host buffer owned by the handle, valid until the next call:
+ *       J (1) | grad (H, A) | mu (H+1, D) | Sig (H+1, D, D) | cost_mu (H+1) | cost_var (H+1)
+ * (the trajectory and the stage costs are what the reference caches on the controller for IterationInformation, :279-283).
+ */
+int gpmpc_objective_grad_host(gpmpc_t* h, const double* actions_host, const double* mu0_host, const double* S0_host,
+                              int H, int A, int include_time, double time0, const double** result_host, void* stream);
+
 /* Asynchronous form of gpmpc_argmin for the multi-GPU path: same rule, no host synchronisation; writes
  * the record out_dev[0] = best J, out_dev[1] = (double) global index (-1.0 if nothing selectable) and, when
  * actions_dev (B, HA) is given, out_dev[2 .. 2+HA) = the winning action sequence, on `stream` -- ready to

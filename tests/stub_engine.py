@@ -128,6 +128,11 @@ class OracleEngine:
             off += out[k].numel()
         return out
 
+    def objective_grad_host(self, actions, mu0, S0, include_time=False, time0=0.0):
+        """HipEngine.objective_grad_host: one sequence (H, A), numpy in / numpy out."""
+        out = self.rollout_grad(np.asarray(actions, dtype=np.float64)[None], mu0, S0, include_time, time0, trajectories=True)
+        return {k: out[k].numpy().copy() for k in ("J", "grad", "mu", "Sig", "cost_mu", "cost_var")}
+
     @staticmethod
     def host_views(out):
         return {k: out["packed"][off:off + n].view(sh) for k, sh, off, n in out["layout"]}

@@ -158,11 +158,13 @@ def _full_size(engine, name, sub, path, sig_tol):
     lo, hi = B // 2 - 8, B // 2 + 56
     w.actions = w.actions[lo:hi].copy()
     engine.set_option("pair_tiles", 1 if path == TILES else 2)
+    engine.set_option("cluster", 1)          # "same path": 64 candidates alone would take the few-candidate cooperative form (its own chunk length)
     try:
         part = engine.rollout(w.actions, w.mu0, w.S0)
         assert engine.last_rollout_path == path
     finally:
         engine.set_option("pair_tiles", 0)
+        engine.set_option("cluster", 0)
     assert np.array_equal(part["Sig"].cpu().numpy(), Sig[lo:hi]) and np.array_equal(part["J"].cpu().numpy(), J[lo:hi])
 
 

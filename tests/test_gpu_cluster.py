@@ -1,0 +1,159 @@
+"""Tier 2 (GPU): the few-candidate cooperative form of the fused-horizon kernel (rollout_kernel<..., CL>, option "cluster").
+
+The reference evaluates ONE action sequence per objective call (restarts_optim 1-2, gp_mpc_controller.py:125-141, 229-285);
+with few candidates a cluster of workgroups shares each candidate's horizon step.  Checked here:
+  * bit for bit the one-workgroup-per-candidate kernel at equal row-chunk length, over shapes, batch sizes, cluster sizes and
+    workgroup widths (every value is formed by the same instruction sequence and summed in the same order);
+  * the reference goldens through the cooperative path at its own (shorter) chunk length, same tolerances as the plain path;
+  * results independent of the batch composition and of the cluster size among few-candidate launches;
+  * the dispatch rule, the objective + gradient on top of it, the host-in / host-out entry of the sequential optimiser.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load, workload_of, factors_of, rel_err, record
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def engine():
+    import gp_mpc_amd
+    eng = gp_mpc_amd.HipEngine(0)
+    yield eng
+    eng.close()
+
+
+def _model(engine, w):
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    engine.set_cost(w.target, w.W, w.W_T, w.kappa)
+
+
+def _same(a, b):
+    return all(torch.equal(a[k], b[k]) for k in ("mu", "Sig", "J", "cost_mu", "cost_var"))
+
+
+@pytest.mark.parametrize("N,D,A,H,tm", [(200, 3, 1, 25, False), (500, 2, 1, 12, False), (150, 3, 2, 6, True), (90, 1, 1, 5, False),
+                                        (260, 2, 3, 5, False)])
+def test_bitwise_equal_to_the_one_workgroup_kernel(engine, N, D, A, H, tm):
+    w = synth.make_workload(N, D, A, H, 12, include_time=tm, seed=N + H)
+    _model(engine, w)
+    acts = torch.as_tensor(w.actions, device="cuda:0")
+    checked = 0
+    for rpc in (16, 32):
+        engine.set_option("rows_per_chunk", rpc)
+        for B in (1, 3, 9, 12):
+            engine.set_option("cluster", 1)
+            engine.set_option("threads", 0)
+            ref = engine.rollout(acts[:B], w.mu0, w.S0, w.include_time, w.time0)
+            assert engine.last_cluster == 1 and engine.last_rollout_path == 0
+            for cs, nt in ((2, 0), (5, 1024), (8, 512), (16, 0), (32, 256)):
+                engine.set_option("cluster", cs)
+                engine.set_option("threads", nt)
+                out = engine.rollout(acts[:B], w.mu0, w.S0, w.include_time, w.time0)
+                assert engine.last_cluster > 1, (rpc, B, cs)
+                assert _same(out, ref), (rpc, B, cs, nt, float((out["Sig"] - ref["Sig"]).abs().max()))
+                checked += 1
+    assert checked == 40
+
+
+@pytest.mark.parametrize("name", ["traj_c2", "traj_c3", "traj_clip", "traj_constraints", "traj_bigvar"])
+def test_reference_goldens_through_the_cooperative_path(engine, name):
+    """The cooperative form at ITS chunk length (16 / 32 rows) against the reference's trajectories: the tolerances of the plain
+    path (tests/test_gpu_parity.py), including `|HIP - exact| <= |reference - exact|` where the tolerance is the north-star bound."""
+    from test_gpu_parity import _check_traj, _set_cost
+    g = load(name)
+    w = workload_of(g)
+    engine.prepare(w.X, w.Y, w.lengthscales, w.outputscales, w.noises)
+    _set_cost(engine, w, g)
+    engine.set_option("cluster", 4)
+    out = engine.rollout(w.actions, w.mu0, w.S0, w.include_time, w.time0)
+    assert engine.last_cluster == 4
+    _check_traj(out, g, name, "cooperative_path")
+
+
+def test_dispatch_rule(engine):
+    """Few candidates of a memory with enough pairwise items take the cooperative form; small memories and large batches do not."""
+    for N, H, B, expect in ((200, 25, 1, True), (200, 25, 16, True), (200, 25, 300, False), (50, 15, 1, False), (500, 10, 2, True)):
+        w = synth.make_workload(N, 3 if N != 500 else 2, 1, H, B, seed=1)
+        _model(engine, w)
+        engine.rollout(w.actions, w.mu0, w.S0)
+        assert (engine.last_cluster > 1) == expect, (N, B, engine.last_cluster)
+    engine.set_option("cluster", 1)
+    w = synth.make_workload(200, 3, 1, 25, 1, seed=1)
+    _model(engine, w)
+    engine.rollout(w.actions, w.mu0, w.S0)
+    assert engine.last_cluster == 1
+    with pytest.raises(Exception):
+        engine.set_option("cluster", 99)
+
+
+def test_few_candidate_results_do_not_depend_on_batch_or_cluster_size(engine):
+    """Lockstep restarts and the sequential optimiser both live in the few-candidate regime: one candidate alone, inside a batch
+    of 5, of 16 and of 40 (cluster sizes 32 / 32 / 16 / 6 here) must give the same bits -- the chunk length depends on N only."""
+    w = synth.make_workload(200, 3, 1, 25, 40, seed=4)
+    _model(engine, w)
+    acts = torch.as_tensor(w.actions, device="cuda:0")
+    alone = engine.rollout(acts[7:8], w.mu0, w.S0)
+    sizes = {engine.last_cluster}
+    for lo, hi in ((5, 10), (0, 16), (0, 40)):
+        out = engine.rollout(acts[lo:hi], w.mu0, w.S0)
+        sizes.add(engine.last_cluster)
+        assert engine.last_cluster > 1
+        assert torch.equal(out["Sig"][7 - lo], alone["Sig"][0]) and torch.equal(out["J"][7 - lo], alone["J"][0])
+    assert len(sizes) >= 2
+    # against the plain kernel (its own chunk length): the method's noise floor, not bits
+    engine.set_option("cluster", 1)
+    plain = engine.rollout(acts[7:8], w.mu0, w.S0)
+    e = rel_err(alone["Sig"].cpu().numpy(), plain["Sig"].cpu().numpy())
+    record("cooperative_vs_plain[c2]", Sig=e)
+    assert 0.0 < e < 1e-6
+
+
+def test_gradient_on_the_cooperative_forward_and_the_host_entry(engine):
+    from oracle import adjoint
+    g = load("lcb_grad_norm")
+    w = workload_of(g)
+    f = factors_of(w)
+    engine.set_factors(w.X, f.iK, f.beta, w.lengthscales, w.outputscales)
+    engine.set_cost(w.target, w.W, w.W_T, w.kappa)
+    engine.set_option("cluster", 4)
+    out = engine.rollout_grad(g["actions_model"][:1], w.mu0, w.S0, w.include_time, w.time0, trajectories=True)
+    assert engine.last_cluster == 4
+    assert rel_err(out["J"].cpu().numpy(), g["J"][:1]) < 1e-9
+    assert rel_err(out["grad"].cpu().numpy().reshape(-1), g["grad"][0]) < 1e-7        # the reference's autograd (gp_mpc_controller.py:277)
+    host = engine.objective_grad_host(g["actions_model"][0], w.mu0, w.S0, w.include_time, w.time0)
+    for k in ("J", "grad", "mu", "Sig", "cost_mu", "cost_var"):
+        assert np.array_equal(host[k], out[k].cpu().numpy()), k
+    # a config-2-sized memory, B = 1, default dispatch: against the numpy adjoint
+    w = synth.make_workload(200, 3, 1, 25, 1, seed=3)
+    _model(engine, w)
+    engine.set_option("cluster", 0)
+    host = engine.objective_grad_host(w.actions[0], w.mu0, w.S0)
+    assert engine.last_cluster > 1
+    J0, g0, *_ = adjoint.lcb_and_gradient(factors_of(w), w.actions[0], w.mu0, w.S0, w.target, w.W, w.W_T, w.kappa)
+    assert abs(float(host["J"][0]) - J0) < 1e-8 * abs(J0) and rel_err(host["grad"].reshape(-1), g0.reshape(-1)) < 1e-7
+
+
+def test_many_launches_back_to_back(engine):
+    """Exchange buffers and tags over many launches of changing shape (tags never repeat while the buffer lives)."""
+    ws = [synth.make_workload(200, 3, 1, 9, 3, seed=2), synth.make_workload(300, 2, 2, 7, 9, seed=5)]
+    refs = []
+    for w in ws:
+        _model(engine, w)
+        engine.set_option("cluster", 1)
+        engine.set_option("rows_per_chunk", 16)
+        refs.append(engine.rollout(w.actions, w.mu0, w.S0))
+    engine.set_option("cluster", 0)
+    for i in range(60):
+        w, ref = ws[i % 2], refs[i % 2]
+        if i % 2 == 0 or i < 4:
+            _model(engine, w)
+        else:
+            _model(engine, w)
+        B = 1 + i % w.actions.shape[0]
+        out = engine.rollout(w.actions[:B], w.mu0, w.S0)
+        assert engine.last_cluster > 1
+        assert torch.equal(out["Sig"], ref["Sig"][:B]) and torch.equal(out["J"], ref["J"][:B]), i
