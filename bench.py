@@ -76,6 +76,99 @@ def algorithmic_bytes_per_rollout(N, D, E, H):
     return H * 8 * (D * N * N + N * E + 2 * D * N)
 
 
+def _taylor_thresholds():
+    """Largest c with c^(K+1)/(K+1)! e^(2c) <= 2^-54, K = 0..14 (csrc/rollout_kernel.h kTaylorMaxArg; derived, not copied:
+    tests/test_taylor_recentring.py checks the kernel's table against the same rule)."""
+    from math import factorial
+    out = []
+    for K in range(15):
+        lo, hi = 0.0, 5.0
+        for _ in range(200):
+            mid = 0.5 * (lo + hi)
+            lo, hi = (mid, hi) if mid ** (K + 1) / factorial(K + 1) * np.exp(2 * mid) <= 2.0 ** -54 else (lo, mid)
+        out.append(lo)
+    return out
+
+
+def formulation_work(X, lengthscales, mu, Sig, A, E, rollout_path):
+    """Flops and exponentials of the formulation the kernels EXECUTE (not the reference's), per rollout, from the
+    stored trajectories mu (S, H+1, D), Sig (S, H+1, D, D) of S candidates and the kernels' own per-(pair, step) rule
+    (csrc/rollout_kernel.h P1: bound cmax of |g.w| from the data range, Taylor degree K, separable form of an off-diagonal pair
+    when the cost model says so, D <= 4).  Counted per (candidate, step):
+      per-point pass   D mean items (2 D^2 + 2 D + 3 (E-D) + 3 flops, 1 exp) and (P + P_offdiag) pair-side items
+                       (4 D^2 + 5 D + 3 (E-D) + 3 flops, 1 exp) per memory point;
+      diagonal pair    N (N+1) / 2 elements (only i <= j is visited) x (2 D + 2 K + 3) [Taylor] | (2 D + 13) [tabulated e^c,
+                       matrix-core pair pass, |g.w| <= 8] | (2 D + 4 flops, 1 exp) [direct];
+      off-diagonal     N^2 elements of the same cost, or -- separable -- 2 sides x N points x 2 flops x C(D + K, D) monomials
+                       + 3 C(D + K, D);
+      mean sums        2 D (D + 1) N.
+    An estimate of USEFUL work (no padding, no masked lanes, no index arithmetic): executed fp64 flops from the SQ counters sit
+    above it, and flops / kernel time / peak <= 1 by construction where `roofline.frac` (the reference formulation's count) is not."""
+    from math import comb
+    X = np.asarray(X)
+    N, D = X.shape[0], mu.shape[2]
+    H = mu.shape[1] - 1
+    ils = 1.0 / np.asarray(lengthscales)[:, :D] ** 2                     # (D, D) state part
+    xmin, xmax = X.min(0)[:D], X.max(0)[:D]
+    thr = _taylor_thresholds()
+    P, P_off = D * (D + 1) // 2, D * (D - 1) // 2
+    NX = E - D
+    f_point = N * (D * (2 * D * D + 2 * D + 3 * NX + 3) + (P + P_off) * (4 * D * D + 5 * D + 3 * NX + 3))
+    x_point = N * (D + P + P_off)
+    f_mean = 2 * D * (D + 1) * N
+    sep_kmax = 0
+    if D <= 4:
+        for k in range(1, 15):
+            if comb(D + k, D) <= 256:
+                sep_kmax = k
+    flops = exps = 0.0
+    forms = {"taylor": 0, "tabulated": 0, "direct": 0, "separable": 0}
+    ksum = kcnt = 0
+    S = mu.shape[0]
+    for c in range(S):
+        for t in range(H):
+            m, Sg = mu[c, t], Sig[c, t]
+            rg = np.maximum(np.abs(xmin - m), np.abs(xmax - m))
+            flops += f_point + f_mean
+            exps += x_point
+            for a in range(D):
+                for b in range(a, D):
+                    R = Sg * (ils[a] + ils[b])[None, :] + np.eye(D)
+                    Z = np.linalg.solve(R, Sg)
+                    cmax = float(np.sum(np.abs(Z) * np.outer(rg * ils[a], rg * ils[b])))
+                    n_el = N * (N + 1) // 2 if a == b else N * N
+                    if cmax <= thr[14]:
+                        K = 1 + sum(cmax > thr[k] for k in range(1, 14))
+                        ksum += K
+                        kcnt += 1
+                        sep = False
+                        if a != b and D <= 4 and K <= sep_kmax and (D != 3 or K <= 6) and rollout_path != 1:
+                            if D == 3:
+                                C_ = comb(D + max(K, 3), D)
+                                cost_sep = 2 * (((N + 63) // 64) * (2 * C_ + 40) + (C_ // 8 + 4) * 70)
+                            else:
+                                cost_sep = 2 * ((comb(D + K, D) + 7) // 8) * (((N + 63) // 64) * (6 + 8 * K) + 80)
+                            sep = cost_sep < N * N * (D + K + 3) // 64
+                        if sep:
+                            Cm = comb(D + (max(K, 3) if D == 3 else K), D)
+                            flops += 2 * N * 2 * Cm + 3 * Cm
+                            forms["separable"] += 1
+                        else:
+                            flops += n_el * (2 * D + 2 * K + 3)
+                            forms["taylor"] += 1
+                    elif rollout_path == 1 and D > 4 and cmax <= 8.0:
+                        flops += n_el * (2 * D + 13)
+                        forms["tabulated"] += 1
+                    else:
+                        flops += n_el * (2 * D + 4)
+                        exps += n_el
+                        forms["direct"] += 1
+    tot = max(1, sum(forms.values()))
+    return {"flops_per_rollout": flops / S, "exps_per_rollout": exps / S, "candidates_sampled": S,
+            "mean_taylor_degree": None if not kcnt else ksum / kcnt,
+            "pair_steps_by_form": {k: v / tot for k, v in forms.items()}}
+
+
 def counter_figures(workload, N, Bg, kernel_ms, build_id):
     """Counter-derived figures of a launch shape, collected with rocprofv3 --pmc in separate passes
     (tools/gpu_counters.sh -> profiles/pmc_traffic.json, profiles/pmc_counters.json): traffic, the counters themselves, a note when
@@ -343,15 +436,25 @@ def main():
         path_batch = eng.last_rollout_path
         rev = eng.rollout(torch.flip(actions, dims=[0]).contiguous(), w.mu0, w.S0, w.include_time, w.time0)
         same_rev = bool(all(torch.equal(torch.flip(rev[k], dims=[0]), fwd[k]) for k in ("mu", "Sig", "J")))
+        # alone, one workgroup per candidate (the batch's own kernel form) ...
+        eng.set_option("cluster", 1)
         alone = eng.rollout(actions[Bg - 1:Bg].contiguous(), w.mu0, w.S0, w.include_time, w.time0)
+        path_alone = eng.last_rollout_path
         same_alone = bool(all(torch.equal(alone[k][0], fwd[k][Bg - 1]) for k in ("mu", "Sig", "J")))
+        # ... and as the dispatch launches a single candidate: the few-candidate cooperative form where the shape has one (its own
+        # row-chunk length, i.e. another summation order: equal to the method's rounding noise, not bit for bit)
+        eng.set_option("cluster", engine_options.get("cluster", 0))
+        coop = eng.rollout(actions[Bg - 1:Bg].contiguous(), w.mu0, w.S0, w.include_time, w.time0)
         batch_indep = {"batch": Bg, "bitwise_equal_reversed_batch": same_rev,
                        "last_candidate_alone": {"bitwise_equal": same_alone, "rollout_path_batch": path_batch,
-                                                "rollout_path_alone": eng.last_rollout_path,
+                                                "rollout_path_alone": path_alone,
                                                 "max_rel_cov_diff": float((alone["Sig"][0] - fwd["Sig"][Bg - 1]).abs().max()
-                                                                          / fwd["Sig"][Bg - 1].abs().max())}}
-        del fwd, rev, alone
-        assert same_rev, f"a candidate's trajectory depends on its position in the batch: {batch_indep}"
+                                                                          / fwd["Sig"][Bg - 1].abs().max()),
+                                                "default_dispatch": {"workgroups_per_candidate": eng.last_cluster,
+                                                                     "max_rel_cov_diff": float((coop["Sig"][0] - fwd["Sig"][Bg - 1]).abs().max()
+                                                                                               / fwd["Sig"][Bg - 1].abs().max())}}}
+        del fwd, rev, alone, coop
+        # (a failure is reported in the line and fails the run AFTER the line is out: the other ranks are not left in a collective)
 
     # the same step with the winner read BEFORE the next launch is enqueued (depth 0): what a closed-loop user pays
     closed_loop_ms = None
@@ -421,6 +524,16 @@ def main():
             launch(0)[0].result()
     kernel_ms, _ = eng.rollout_timed(actions, w.mu0, w.S0, max(reps, 3 if est_step_ms < 1000 else 1), w.include_time, w.time0)
     rollout_path = eng.last_rollout_path
+    cluster = eng.last_cluster
+    # one evaluation of the sequential optimiser (host in, host out, one synchronisation): the reference's regime, reported on
+    # few-candidate lines
+    host_eval_ms = None
+    if Bg <= 16 and grad_ms is not None:
+        eng.objective_grad_host(w.actions[lo], w.mu0, w.S0, w.include_time, w.time0)
+        th = time.perf_counter()
+        for _ in range(20):
+            eng.objective_grad_host(w.actions[lo], w.mu0, w.S0, w.include_time, w.time0)
+        host_eval_ms = (time.perf_counter() - th) / 20 * 1e3
     build_id = eng.build_id
     # per-rank view for a multi-GPU line: every rank's slice and kernel time (a future SCALE line is diagnosable from it)
     per_rank = None
@@ -439,6 +552,14 @@ def main():
         achieved_tflops = flops_launch / (kernel_ms * 1e-3) / 1e12
         traffic, counters, counters_note, valu_busy, executed = counter_figures(args.workload, N, Bg, kernel_ms, build_id)
         fma_peak, fma_src = measured_fma_loop_peak()
+        # the work of the formulation the kernels execute, from the stored trajectories of (up to) 8 candidates
+        n_s = min(Bg, 8 if D <= 4 else 1)
+        form = formulation_work(w.X, w.lengthscales, out["mu"][:n_s].cpu().numpy(), out["Sig"][:n_s].cpu().numpy(), A, E, rollout_path)
+        form_tflops = (form["flops_per_rollout"] + form["exps_per_rollout"]) * Bg / (kernel_ms * 1e-3) / 1e12
+        form.update({"tflops": form_tflops, "frac_formulation": form_tflops / PEAK_F64_VECTOR_TFLOPS,
+                     "note": "flops (+ 1 per exponential) of the evaluation forms the kernels chose per (pair, step) -- Taylor degree, "
+                             "triangle-only diagonal pairs, separable off-diagonal pairs -- x candidates / kernel time / nominal peak: "
+                             "useful work only, <= 1 by construction (bench.formulation_work)"})
         result = {
             "metric": "MPC trajectory rollouts/sec",
             "value": B_total * args.steps / elapsed,
@@ -447,6 +568,7 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_first_window": windows[0][0] / args.steps * 1e3,      # BENCH_r01-r04 reported a single window: this is that figure
             # every timed window of --steps steps of this run (ms per step, max over ranks, in run order); `value` and
             # `ms_per_step` are the median window
             "windows": {"n": n_windows, "ms_per_step": [wd[0] / args.steps * 1e3 for wd in windows],
@@ -465,6 +587,7 @@ def main():
                            "rccl": "RCCL gather of (J, idx, winner) only, on the compute stream",
                            "rccl_side": "RCCL gather of (J, idx, winner) only, over xGMI on a side stream behind an event"}[args.exchange],
                        "exchange": args.exchange, "exchange_note": exchange_note, "winner_read_steps_late": depth,
+                       "workgroups_per_candidate": cluster, "lib_path": gp_mpc_amd._lib.LIB_PATH,
                        # host time of reading one step's winner (event wait + exchange when it is host-side), rank 0, ms
                        "winner_read_host_ms": {"median": float(np.median(read_host_s) * 1e3), "max": float(np.max(read_host_s) * 1e3)},
                        **({"engine_options": engine_options} if engine_options else {})},
@@ -472,6 +595,7 @@ def main():
                          "unit": "TFLOP/s", "frac": achieved_tflops / PEAK_F64_VECTOR_TFLOPS, "traffic": traffic,
                          "peak_measured_fma_loop": fma_peak, "peak_measured_source": fma_src,
                          "frac_of_measured_fma_loop": None if not fma_peak else achieved_tflops / fma_peak,
+                         "formulation": form,
                          "valu_busy_frac": valu_busy,
                          "executed": executed,
                          "counters_note": counters_note,
@@ -511,7 +635,10 @@ def main():
             "gradient": None if grad_ms is None else {
                 "ms_per_launch": grad_ms, "objective_gradients_per_s": Bg / (grad_ms * 1e-3),
                 "rollouts_the_same_gradients_cost_by_differences": Bg * (4 * H * A + 1),
-                "note": "J and dJ/du (H x A) for every candidate of the batch: rollout + pair_moments + adjoint_sweep kernels"},
+                "host_in_host_out_ms_per_evaluation": host_eval_ms,
+                "note": "J and dJ/du (H x A) for every candidate of the batch: rollout + pair_moments + adjoint_sweep kernels; "
+                        "host_in_host_out_ms_per_evaluation (few-candidate lines) = gpmpc_objective_grad_host for ONE sequence, the "
+                        "call scipy's L-BFGS-B makes per evaluation (gp_mpc_controller.py:133-141), one synchronisation"},
             "best_index": int(best_i), "best_J": float(best_J),
             "per_rank": per_rank,
         }
@@ -636,6 +763,8 @@ def main():
     os.close(stdout_fd)
     if line is not None:
         print(line, flush=True)
+    if batch_indep is not None and not batch_indep["bitwise_equal_reversed_batch"]:
+        raise SystemExit(f"a candidate's trajectory depends on its position in the batch: {batch_indep}")
 
 
 if __name__ == "__main__":

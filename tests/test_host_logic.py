@@ -661,3 +661,27 @@ int main(int argc, char** argv) {
         chosen[(N, NW, nd, no)] = want
     assert chosen[(50, 16, 3, 0)] <= 20           # config 1: several items per pair instead of one
     assert 36 <= chosen[(200, 16, 3, 0)] <= 48    # config 2 with the off-diagonal pairs on the matrix cores: 30 items for 2 rounds of 16 wavefronts
+
+
+def test_formulation_work_is_bounded_by_the_reference_count_and_by_the_executed_flops():
+    """bench.formulation_work (the `roofline.formulation` block): the useful work of the evaluation forms the kernels choose per
+    (pair, step) -- Taylor degree from the kernels' own bound, triangle-only diagonal pairs, separable off-diagonal pairs.  It must
+    sit below the reference formulation's count (what `roofline.frac` prices) and below the fp64 flops the SIMDs
+    actually issued for the same launch (SQ counters of the round-5 config-2 line), so that its fraction of the peak is <= 1
+    by construction where `frac` (1.17 / 2.04 on configs 3 / 4) is not."""
+    import json
+    import bench
+    from oracle import synth, gpmpc_oracle as orc
+    for name in ("c1", "c2"):
+        n, d, a, h, b, tm = synth.SHAPES[name]
+        w = synth.make_workload(n, d, a, h, 2, include_time=tm, seed=0)
+        ref = orc.evaluate_candidates(orc.Factors(w.X, w.Y, w.lengthscales, w.outputscales, w.noises), w)
+        fw = bench.formulation_work(w.X, w.lengthscales, ref["mu"], ref["Sig"], a, d + a + (1 if tm else 0), 0)
+        total = fw["flops_per_rollout"] + fw["exps_per_rollout"]
+        assert 0.0 < total < bench.algorithmic_flops_per_rollout(n, d, a, d + a + (1 if tm else 0), h)
+        assert abs(sum(fw["pair_steps_by_form"].values()) - 1.0) < 1e-12 and 1.0 <= fw["mean_taylor_degree"] <= 14.0
+        if name == "c2":
+            stored = json.loads(open(os.path.join(ROOT, "profiles", "r05y_c2_bench.json")).read().strip().splitlines()[-1])
+            executed = stored["roofline"]["executed"]["fp64_flops_per_launch"]
+            assert total * stored["config"]["B_per_gpu"] < executed            # useful work <= issued work
+            assert fw["pair_steps_by_form"]["separable"] == 0.5               # the three off-diagonal pairs of D = 3, every step
