@@ -318,8 +318,18 @@ class GpMpcController(BaseControllerObject):
         # rank whose slice is empty (B < world) launches nothing and contributes an (inf, -1) record.
         lo, hi = sharding.shard_bounds(B, world, rank)
         eng = self.transition_model.engine
-        out = self.evaluate_candidates(cands[lo:hi], state_mu, state_var, trajectories=True) if hi > lo else None
+        failure = None
+        try:
+            out = self.evaluate_candidates(cands[lo:hi], state_mu, state_var, trajectories=True) if hi > lo else None
+        except Exception as e:                   # noqa: BLE001 -- world > 1: handed on after the collective, see below
+            if world == 1:
+                raise
+            # this rank must still enter the step's all_gather (its peers would wait in it until the watchdog fires): it
+            # contributes an (inf, -1) record whose error flag every rank reads after the exchange
+            failure, out = e, None
         local = torch.as_tensor(cands[lo:hi].reshape(hi - lo, H, A), device=eng.device)
+        if failure is not None:
+            local = local[:0]
         if world == 1:
             J, best, win = sharding.select_best_on_device(eng, out["J"], local, lo, B, group=sharding.LOCAL)
             self._cache_trajectory(out, B - 1)       # the reference caches the LAST evaluated trajectory, not the winner's (:279-283)
@@ -328,19 +338,29 @@ class GpMpcController(BaseControllerObject):
             # global candidate appends that trajectory to its record, so the step's whole exchange is ONE all_gather.
             D = self.transition_model.dim_state
             last_owner = sharding.owner_of(B - 1, B, world)
-            if rank == last_owner:
+            if rank == last_owner and out is not None:
                 extra = torch.cat([out[k][-1].reshape(-1) for k in ("mu", "Sig", "cost_mu", "cost_var")] + [out["J"][-1:]])
             else:
                 extra = torch.zeros((H + 1) * (D + D * D + 2) + 1, dtype=F64, device=eng.device)
             # two trailing doubles: checksums of the state and of the drawn candidates (same on every rank, or the union of
             # the slices is not the single-GPU population)
-            sums = torch.tensor([self._state_checksum(state_mu, state_var), float(np.dot(cands.ravel(), np.cos(np.arange(cands.size))))],
-                                dtype=F64, device=eng.device)
+            # three trailing doubles: an error flag, and checksums of the state and of the drawn candidates (same on every rank, or
+            # the union of the slices is not the single-GPU population)
+            sums = torch.tensor([0.0 if failure is None else 1.0, self._state_checksum(state_mu, state_var),
+                                 float(np.dot(cands.ravel(), np.cos(np.arange(cands.size))))], dtype=F64, device=eng.device)
             J, best, win, extras = sharding.select_best_on_device(eng, None if out is None else out["J"], local, lo, B,
-                                                                  extra=torch.cat([extra, sums]), group=self.process_group)
+                                                                  extra=torch.cat([extra, sums]), group=self.process_group,
+                                                                  raise_if_none=False)
+            if failure is not None:
+                raise failure
+            failed = [r for r in range(world) if float(extras[r, -3]) != 0.0]
+            if failed:
+                raise RuntimeError(f"random shooting: the slice of rank(s) {failed} failed; no winner this step")
             self._assert_ranks_agree(extras[:, -2], "the state")
             self._assert_ranks_agree(extras[:, -1], "the drawn candidates")
-            self._cache_packed_trajectory(extras[last_owner][:-2], H, D)
+            if win is None:
+                raise FloatingPointError("no selectable candidate (all objectives NaN)")
+            self._cache_packed_trajectory(extras[last_owner][:-3], H, D)
         self.best_candidate_index, self.best_candidate_J = best, J
         self.actions_mpc_previous_iter = win.numpy().reshape(-1).copy()
         return self.actions_mapper.transform_action_mpc_to_action_model(self.actions_mpc_previous_iter)
@@ -411,7 +431,15 @@ class GpMpcController(BaseControllerObject):
             head = np.concatenate([[float(seed >> 31), float(seed & 0x7fffffff), 1.0 if first is not None else 0.0],
                                    np.zeros(n) if first is None else np.asarray(first, dtype=np.float64).ravel(),
                                    np.asarray(state_mu, dtype=np.float64).ravel(), np.asarray(state_var, dtype=np.float64).ravel()])
+            mine = self._state_checksum(state_mu, state_var)
             head = sharding.broadcast_from_first(head, tm.engine.device, self.process_group)
+            # the ranks must sit at the SAME state (the other searches verify it inside their exchange): compared with rank 0's
+            # here, and the verdict is taken by all ranks together (one rank raising alone would leave the others in the search's
+            # collectives)
+            theirs = self._state_checksum(head[3 + n:3 + n + np.asarray(state_mu).size], head[3 + n + np.asarray(state_mu).size:])
+            if sharding.any_rank(mine != theirs, tm.engine.device, self.process_group):
+                raise RuntimeError("candidate sharding: the ranks disagree on the state; every rank must see the same observation "
+                                   "(or switch ControllerConfig.shard_over_ranks off)")
             seed = (int(head[0]) << 31) | int(head[1])
             first = head[3:3 + n].copy() if head[2] != 0.0 else None
             nmu = np.asarray(state_mu).size
@@ -487,16 +515,19 @@ class GpMpcController(BaseControllerObject):
 
         def flush():                                   # called with the lock held, by the last thread to arrive
             idx = sorted(pending)
+            J, G = np.full(len(idx), np.nan), np.zeros((len(idx), H * A))
             try:
                 J, G = self.objective_and_gradient_batch(np.stack([pending[i] for i in idx]), state_mu, state_var)
-            except Exception as e:                     # hand the failure to every waiting restart (interrupts pass through)
-                state["error"] = e
-                J, G = np.full(len(idx), np.nan), np.zeros((len(idx), H * A))
-            state["launches"] += 1
-            for k, i in enumerate(idx):
-                results[i] = (float(J[k]), G[k].copy())
-            pending.clear()
-            cond.notify_all()
+            except BaseException as e:                 # every waiting restart is served -- nobody may wait forever ...
+                state["error"] = e if isinstance(e, Exception) else RuntimeError(repr(e))
+                if not isinstance(e, Exception):       # ... and KeyboardInterrupt / SystemExit go on in the flushing thread
+                    raise
+            finally:
+                state["launches"] += 1
+                for k, i in enumerate(idx):
+                    results[i] = (float(J[k]), G[k].copy())
+                pending.clear()
+                cond.notify_all()
 
         def make_fun(i):
             def fun(x):
@@ -504,8 +535,14 @@ class GpMpcController(BaseControllerObject):
                     pending[i] = np.array(x, dtype=np.float64)
                     if len(pending) == state["running"]:
                         flush()
+                    waited = 0.0
                     while i not in results:
-                        cond.wait()
+                        # a rendezvous that never completes (a sibling died outside `worker`'s bookkeeping) must not hang the step
+                        if not cond.wait(timeout=5.0):
+                            waited += 5.0
+                            if waited >= 600.0:
+                                pending.pop(i, None)
+                                raise TimeoutError(f"lockstep evaluation of restart {i} not served within 600 s")
                     out = results.pop(i)
                 if state["error"] is not None:
                     raise RuntimeError("batched evaluation failed") from state["error"]

@@ -38,6 +38,17 @@ def broadcast_from_first(array, device, group=None):
     return t.cpu().numpy().reshape(a.shape)
 
 
+def any_rank(flag, device, group=None):
+    """True on every rank if `flag` is true on ANY rank of `group` (one all_reduce(MAX) of one double): how a condition only one
+    rank can see -- its slice failed, its state differs from what rank 0 broadcast -- becomes a decision all ranks take together,
+    so that nobody raises alone and leaves the others waiting in the next collective."""
+    if not _active(group):
+        return bool(flag)
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return bool(t.item() != 0.0)
+
+
 def shard_bounds(num_candidates, world_size, rank):
     """Contiguous balanced slice [lo, hi) of range(num_candidates) owned by `rank`."""
     base, extra = divmod(int(num_candidates), int(world_size))
@@ -275,7 +286,7 @@ def select_best_async(engine, J, actions_local, lo, num_candidates, group=None, 
     return PendingBest(host_buffer, ev, world, H, A, rec)
 
 
-def select_best_on_device(engine, J, actions_local, lo, num_candidates, group=None, extra=None):
+def select_best_on_device(engine, J, actions_local, lo, num_candidates, group=None, extra=None, raise_if_none=True):
     """Device-resident variant of sharded_argmin for the HIP engine: local keep-the-best on the GPU
     (gpmpc_argmin_async), the record [J, global index, winning (H*A) sequence] packed on the device, ONE
     RCCL all_gather of 16 + 8*H*A bytes per rank, one device-to-host copy, the cross-rank rule applied on
@@ -291,7 +302,12 @@ def select_best_on_device(engine, J, actions_local, lo, num_candidates, group=No
         rec = torch.cat([rec, extra.to(rec.device, torch.float64).reshape(-1)])
     world, flat = _gather_records(rec, group)
     host = flat.cpu().view(world, rec.numel())
-    bJ, bi, win = _winner_of(host, world, H, A)
+    try:
+        bJ, bi, win = _winner_of(host, world, H, A)
+    except FloatingPointError:
+        if raise_if_none:
+            raise
+        bJ, bi, win = math.inf, -1, None           # the caller inspects `extra` (error flags) before it decides what to raise
     if extra is None:
         return bJ, bi, win
     return bJ, bi, win, host[:, 2 + H * A:].clone()
@@ -317,7 +333,7 @@ def sharded_cem_search(engine, mu0, S0, B_total, H, A, iterations, n_elite, seed
                                  first_candidate=first_candidate, max_change=max_change, action_prev=action_prev, noise=noise)
     lo, hi = shard_bounds(B_total, world, rank)
     state = torch.zeros(3 * n + 1, dtype=torch.float64, device=engine.device)
-    gathered = torch.empty((world * n_elite, n + 2), dtype=torch.float64, device=engine.device) if world > 1 else None
+    gathered = torch.zeros((world * n_elite, n + 2), dtype=torch.float64, device=engine.device) if world > 1 else None
     elites = None
     failure = None
     for it in range(int(iterations)):
@@ -353,9 +369,12 @@ def sharded_cem_search(engine, mu0, S0, B_total, H, A, iterations, n_elite, seed
         # rank that failed keeps contributing marked records until the end)
         flag = (gathered[:, 1] == _CEM_FAILED).any().to(torch.float64).view(1)
         host = torch.cat([state, flag]).cpu().numpy()
+        # a failure of the LAST iteration's merge is followed by no further gather that could carry the marker: one
+        # all_reduce of the local failure flags, so that every rank raises (or none does)
+        failed_somewhere = any_rank(failure is not None, engine.device, group)
         if failure is not None:
             raise failure
-        if host[-1] != 0.0:
+        if host[-1] != 0.0 or failed_somewhere:
             raise RuntimeError("sharded cross-entropy search: another rank's slice failed; no winner this step")
         host = host[:-1]
     else:

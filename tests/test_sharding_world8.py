@@ -107,6 +107,34 @@ def test_cross_entropy_search_failure_on_one_rank_raises_everywhere():
         assert got[r][0] == "raised" and "another rank" in got[r][2], (r, got[r])
 
 
+def cem_merge_fail_rank(rank, world, B, n_elite, fail_rank):
+    """The LAST iteration's merge fails on one rank: no later gather could carry a marker."""
+    from gp_mpc_amd import sharding
+    w, eng = _cem_setup()
+    rng = np.random.default_rng(12)
+    iters = 2
+    noise = np.concatenate([rng.uniform(size=(1, B, 3)), rng.standard_normal((iters - 1, B, 3))])
+    if rank == fail_rank:
+        real = eng.cem_merge
+
+        def failing(elites, n_elite_, n, it, state):
+            if it == iters - 1:
+                raise RuntimeError("injected failure of this rank's last merge")
+            return real(elites, n_elite_, n, it, state)
+        eng.cem_merge = failing
+    x, J = sharding.sharded_cem_search(eng, w.mu0, w.S0, B, 3, 1, iters, n_elite, seed=0, noise=noise, group=None)
+    return x, J
+
+
+def test_cross_entropy_search_failure_of_the_last_merge_raises_everywhere():
+    """a cem_merge failure in the LAST iteration is followed by no gather; the ranks agree on it through one
+    all_reduce of their failure flags, so nobody returns a winner while another rank raises."""
+    got = _spawn(cem_merge_fail_rank, 3, 42900, 9, 2, 2, timeout=120)
+    assert got[2][0] == "raised" and "injected" in got[2][2], got[2]
+    for r in (0, 1):
+        assert got[r][0] == "raised" and "another rank" in got[r][2], (r, got[r])
+
+
 def test_cross_entropy_search_beyond_the_merge_limit_runs_unsharded():
     """world x n_elite > 4096 records do not fit the merge kernel's LDS sort: every rank runs the whole population (same draws),
     no collective, instead of failing with GPMPC_ERR_LIMIT only when sharded."""
@@ -213,6 +241,46 @@ def test_lbfgs_failure_on_one_rank_raises_everywhere():
     assert got[1][0] == "raised" and ("injected" in got[1][2] or "batched evaluation failed" in got[1][2]), got[1]
     for r in (0, 2):
         assert got[r][0] == "raised" and "rank(s) [1]" in got[r][2], (r, got[r])
+
+
+def shoot_fail_rank(rank, world, restarts, fail_rank):
+    w, eng, c, mu0 = _controller("shoot", restarts)
+    if rank == fail_rank:
+        def broken(*a, **k):
+            raise RuntimeError("injected failure of this rank's launch")
+        eng.rollout = broken
+    np.random.seed(8)
+    return _steps(c, mu0, eng, n=1)
+
+
+@pytest.mark.parametrize("restarts,fail_rank", [(7, 1), (2, 0)])
+def test_random_shooting_failure_on_one_rank_raises_everywhere(restarts, fail_rank):
+    """a slice evaluation that raises on one rank (launch error, GPMPC_ERR_LIMIT) used to happen BEFORE the
+    step's all_gather -- the peers then waited in it until the watchdog fired.  The failing rank now contributes an (inf, -1)
+    record with an error flag and every rank raises after the exchange (also when the failing rank owned the only candidates
+    of interest: B = 2 over 3 ranks, rank 0 failing)."""
+    got = _spawn(shoot_fail_rank, 3, 45900, restarts, fail_rank, timeout=120)
+    assert got[fail_rank][0] == "raised" and "injected" in got[fail_rank][2], got[fail_rank]
+    for r in range(3):
+        if r != fail_rank:
+            assert got[r][0] == "raised" and f"rank(s) [{fail_rank}]" in got[r][2], (r, got[r])
+
+
+def cem_device_state_rank(rank, world, shift_rank):
+    w, eng, c, mu0 = _controller("shoot", 4)
+    c.config.controller.optimize = True
+    c.config.controller.candidate_optimizer = "cem_device"
+    c.config.controller.cem_candidates, c.config.controller.cem_iterations, c.config.controller.cem_elite_fraction = 6, 2, 0.34
+    np.random.seed(8)
+    return _steps(c, mu0 + (0.01 if rank == shift_rank else 0.0), eng, n=1)
+
+
+def test_device_cross_entropy_search_detects_ranks_at_different_states():
+    """the sharded device CEM adopted rank 0's state silently; a rank called with another observation now makes
+    every rank raise (one all_reduce of the mismatch flags right after the broadcast)."""
+    got = _spawn(cem_device_state_rank, 2, 46900, 1, timeout=120)
+    for r in range(2):
+        assert got[r][0] == "raised" and "disagree on the state" in got[r][2], (r, got[r])
 
 
 @pytest.mark.parametrize("kind", ["shoot", "lbfgs"])
