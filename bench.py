@@ -252,6 +252,10 @@ def main():
     ap.add_argument("--no-batch-check", action="store_true",
                     help="skip the alone-vs-in-batch bitwise check of the last candidate (config 5: one more 28 s launch)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: gloo ranks on the CPU with tests/stub_engine.DryRunEngine (objective = a cheap function of the "
+                         "actions).  Exercises the launch contract, the slice arithmetic, the exchange and the assembly of a "
+                         "multi-GPU line (per_rank block) before the first real N-GPU run; its numbers mean nothing")
     ap.add_argument("--option", action="append", default=[], metavar="NAME=VALUE",
                     help="engine option for an A/B run (gpmpc_set_option; recorded in config.engine_options)")
     args = ap.parse_args()
@@ -271,12 +275,21 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dry = args.dry_run
+    if dry:
+        device = torch.device("cpu")
+        torch.cuda.synchronize = lambda *a, **k: None          # the only torch.cuda calls of this file
+        args.exchange, args.no_gradient, args.no_batch_check, args.no_cpu_baseline = "rccl", True, True, True
+    else:
+        torch.cuda.set_device(local_rank)
+        device = torch.device("cuda", local_rank)
     if world > 1 or args.force_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if dry:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import gp_mpc_amd
     from gp_mpc_amd import sharding
@@ -302,7 +315,12 @@ def main():
     lo, hi = sharding.shard_bounds(B_total, world, rank)
     Bg = hi - lo                                   # this rank's candidates (rank 0 holds the largest slice)
 
-    eng = gp_mpc_amd.HipEngine(local_rank)
+    if dry:
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from stub_engine import DryRunEngine
+        eng = DryRunEngine(D)
+    else:
+        eng = gp_mpc_amd.HipEngine(local_rank)
     engine_options = {}
     for kv in args.option:
         name, value = kv.split("=")
@@ -359,13 +377,29 @@ def main():
 
     # Untimed pre-conditioning: the GPU needs a few tens of milliseconds of sustained load to reach its steady clocks
     # (the first launches after the tiny prepare kernels run ~10 % slow); a running controller is in that state.
+    # Every launch of a multi-rank run holds a collective (the exchange of the winner records): the NUMBER of pre-conditioning
+    # launches is therefore rank 0's (broadcast) -- a time-bounded loop per rank would leave the ranks in different collectives
+    # (found by the gloo dry run of tests/test_bench_dry_run.py in round 6; no multi-GPU run had reached this line before).
+    multi_rank = dist.is_initialized() and world > 1
     tc = time.perf_counter()
-    n_pre = 0
-    while time.perf_counter() - tc < 0.25:
+    pend, out = launch(0)
+    pend.result()
+    n_pre = int(min(5000, max(1, 0.25 / max(time.perf_counter() - tc, 1e-5))))
+    if multi_rank:
+        npt = torch.tensor([float(n_pre)], dtype=torch.float64, device=device)
+        dist.broadcast(npt, src=0)
+        n_pre = int(npt.item())
+    tc = time.perf_counter()
+    for _ in range(n_pre):
         pend, out = launch(0)
         pend.result()
-        n_pre += 1
     est_step_ms = (time.perf_counter() - tc) / n_pre * 1e3          # sizes the HIP-event repetition count below
+    if multi_rank:
+        # every later decision taken from this estimate (number of windows, closed-loop leg, pre-conditioning before the HIP-event
+        # leg) involves launches with collectives: all ranks use rank 0's figure
+        est_t = torch.tensor([est_step_ms], dtype=torch.float64, device=device)
+        dist.broadcast(est_t, src=0)
+        est_step_ms = float(est_t.item())
     for k in range(args.warmup):
         pend, out = launch(k)
         pend.result()
@@ -519,8 +553,7 @@ def main():
         # steady clocks again: the prepare and gradient legs above leave the GPU idle between their host-side steps, and the first
         # launches after that run several per cent slow (round 5: 0.398 ms by these events against 0.356 ms in the rocprofv3 trace
         # of the same run and a 0.376 ms step) -- the same untimed pre-conditioning as before the timed windows
-        tw = time.perf_counter()
-        while time.perf_counter() - tw < 0.25:
+        for _ in range(n_pre):                     # (a rank-agreed count, as above)
             launch(0)[0].result()
     kernel_ms, _ = eng.rollout_timed(actions, w.mu0, w.S0, max(reps, 3 if est_step_ms < 1000 else 1), w.include_time, w.time0)
     rollout_path = eng.last_rollout_path
@@ -762,6 +795,10 @@ def main():
     os.dup2(stdout_fd, 1)
     os.close(stdout_fd)
     if line is not None:
+        if dry:
+            d_ = json.loads(line)
+            d_["data"] = "DRY RUN (CPU stand-in engine, gloo): contract and slice arithmetic only, the numbers mean nothing"
+            line = json.dumps(d_)
         print(line, flush=True)
     if batch_indep is not None and not batch_indep["bitwise_equal_reversed_batch"]:
         raise SystemExit(f"a candidate's trajectory depends on its position in the batch: {batch_indep}")

@@ -136,3 +136,53 @@ class OracleEngine:
     @staticmethod
     def host_views(out):
         return {k: out["packed"][off:off + n].view(sh) for k, sh, off, n in out["layout"]}
+
+
+class DryRunEngine:
+    """`bench.py --dry-run`: the engine methods bench.py touches, with an objective that costs nothing (a fixed function of the
+    action sequence) -- a multi-rank run of the bench on the CPU then exercises everything AROUND the launches at the full
+    config-5 slice sizes (8192 candidates over 8 ranks), which the CPU oracle could not evaluate in hours."""
+    last_rollout_path = 1
+    last_cluster = 1
+    last_prepare_mode = 1
+    build_id = "dry-run"
+
+    def __init__(self, D):
+        self.device = torch.device("cpu")
+        self.D = D
+        self.launches = 0
+
+    def set_option(self, name, value):
+        pass
+
+    def set_cost(self, *a, **k):
+        pass
+
+    def prepare(self, X, Y, *a):
+        self.N = X.shape[0]
+
+    def rollout(self, actions, mu0, S0, include_time=False, time0=0.0, trajectories=True, stage_costs=True, out=None):
+        actions = torch.as_tensor(actions, dtype=torch.float64)
+        B, H, A = actions.shape
+        self.launches += 1
+        if out is None:
+            out = {"mu": torch.zeros((B, H + 1, self.D), dtype=torch.float64), "Sig": torch.zeros((B, H + 1, self.D, self.D), dtype=torch.float64),
+                   "cost_mu": torch.zeros((B, H + 1), dtype=torch.float64), "cost_var": torch.zeros((B, H + 1), dtype=torch.float64),
+                   "J": torch.zeros(B, dtype=torch.float64)}
+            out["mu"][:] = torch.as_tensor(np.asarray(mu0))
+            out["Sig"][:] = torch.as_tensor(np.asarray(S0))
+        w = torch.cos(torch.arange(1, H * A + 1, dtype=torch.float64))
+        out["J"].copy_(((actions.reshape(B, -1) - 0.5) ** 2 @ w.abs()) + 0.01 * (actions.reshape(B, -1) @ w))
+        return out
+
+    def rollout_timed(self, actions, mu0, S0, reps, include_time=False, time0=0.0):
+        import time
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            out = self.rollout(actions, mu0, S0)
+        return (time.perf_counter() - t0) / reps * 1e3, out["J"]
+
+    argmin_async = OracleEngine.argmin_async
+
+    def close(self):
+        pass
