@@ -106,8 +106,6 @@ int gpmpc_set_option(gpmpc_t* g, const char* name, long long value) {
     else if (!strcmp(name, "force_path")) h->opt_force_path = (int)value;
     else if (!strcmp(name, "force_separable")) h->opt_force_sep = (int)value;
     else if (!strcmp(name, "cols_per_lane")) h->opt_cols_per_lane = (int)value;
-    else if (!strcmp(name, "exact_dim")) h->opt_exact_dim = (int)value;
-    else if (!strcmp(name, "grad_cols_per_lane")) h->opt_grad_cols = (int)value;
     else if (!strcmp(name, "grad_share_cu")) h->opt_grad_share = (int)value;
     else if (!strcmp(name, "grad_chunk_rows")) {
         const int v = (int)value;

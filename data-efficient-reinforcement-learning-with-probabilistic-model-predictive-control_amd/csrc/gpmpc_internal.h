@@ -159,7 +159,6 @@ struct Handle {
     int opt_force_path = 0;
     int opt_force_sep = 0;
     int opt_grad_stream = 0;         // 1: always the streaming moment pass of the gradient (tests); otherwise only when N needs it
-    int opt_grad_cols = 0;           // 2: two columns per lane in the gradient's moment pass (A/B)
     int opt_grad_share = 0;          // moment pass of the gradient, D <= 3: two 512-thread workgroups per CU -- 0 auto (grad.hip), 1 where the LDS fits twice, 2 never
     int opt_grad_chunk = 0;          // rows per work item of the LDS-resident moment pass: 0 = chosen by the schedule model (grad.hip), else fixed (multiple of 4, <= 64)
     int chunk_key[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the model's last answer: (N, D, E, columns per lane, waves, LDS KiB, small-batch items, pairs left) -> chunk_rows
@@ -167,7 +166,6 @@ struct Handle {
     int opt_grad_tiles = 1;          // diagonal pairs of the gradient's moment pass batch-major (pair_tile_grad_kernel.h): 0 never, 1 auto, 2 always
     int opt_grad_sep = 1;            // off-diagonal pairs of the gradient's moment pass in separable form on the matrix cores:
                                      // 0 never (element-wise), 1 from N = 128 on when B x H fills the chip (measured crossover, grad.hip), 2 always (tests, A/B)
-    int opt_exact_dim = 0;           // 2: forbid the compile-time-D kernel instantiation (A/B)
     int opt_cols_per_lane = 0;       // 0 auto, 1 / 2: columns per lane in the pairwise pass of the rollout kernel
     int opt_incremental = 1;         // reuse / border-update the cached factors when the memory only grew
     int opt_refresh_every = 32;      // full refactorisation after this many border updates (bounds drift)

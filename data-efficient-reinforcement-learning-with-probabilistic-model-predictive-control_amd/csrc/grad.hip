@@ -19,8 +19,6 @@ int launch_moments(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s
         GPMPC_HIP_CHECK(h, hipGetLastError());
         return GPMPC_OK;
     };
-    // two columns per lane: twice the accumulators, 8 waves per (candidate, step)
-    if (g.cols == 2) return go(pair_moments_kernel<DP, NXP, kMomThreads, 2>, kMomThreads);
     if constexpr (DP <= 3) {
         // two 512-thread workgroups per CU (see pair_moments_kernel), or
         // 16 waves per (candidate, step): the accumulators fit the 128-VGPR budget of a 1024-thread workgroup
@@ -81,9 +79,9 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     memset(&g, 0, sizeof g);
     // tiling of the pairwise pass: row chunks of CH rows (64 to start with; the LDS-resident pass re-plans with the schedule model's
     // answer once it is known which pairs it is left with), as many output pairs per group as the LDS holds
-    // two columns per lane need > 128 VGPRs, i.e. 8 waves instead of 16 per workgroup: measured slower at config 2
-    // (2.86 vs 2.10 ms), so one column unless asked (option "grad_cols_per_lane")
-    const int cols = (h->opt_grad_cols == 2) ? 2 : 1;
+    // one column per lane (two need > 128 VGPRs, i.e. 8 waves instead of 16 per workgroup: measured slower at config 2,
+    // 2.86 vs 2.10 ms, round 3 -- that instantiation is no longer built)
+    const int cols = 1;
     const int NCU = (N + cols - 1) / cols;
     // D <= 4: the sweep is one wavefront's, its prologue (cost adjoints and state-independent algebra of all H steps) every
     // wavefront's of the launch -- 8 of them (512 threads: 256 VGPRs, the 1024-thread form spills at D = 4) while each candidate has a CU to itself, 4 up to four per CU, else the one

@@ -228,7 +228,7 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     a.CM = CM;
     a.force_path = h->opt_force_path;
     a.force_sep = h->opt_force_sep;
-    a.exact_dim = h->opt_exact_dim;
+    a.exact_dim = 0;
 
     // LDS budget of a workgroup of the fused-horizon kernel: all of it, or (option "lds_limit_kb", sharing rule below) a share
     // that lets two workgroups of 8 wavefronts live on one CU
