@@ -123,6 +123,7 @@ int gpmpc_set_option(gpmpc_t* g, const char* name, long long value) {
     else if (!strcmp(name, "prepare_invcols")) h->opt_prepare_invcols = (int)value;
     else if (!strcmp(name, "prepare_inv_batch")) h->opt_prepare_inv_batch = (int)value;
     else if (!strcmp(name, "fused_prepare")) h->opt_fused_prepare = (int)value;
+    else if (!strcmp(name, "gram_shared")) h->opt_gram_shared = (int)value;
     else if (!strcmp(name, "outer_block")) h->opt_outer_block = (int)value;
     else if (!strcmp(name, "tile128")) h->opt_tile128 = (int)value;
     else if (!strcmp(name, "block128")) h->opt_block128 = (int)value;

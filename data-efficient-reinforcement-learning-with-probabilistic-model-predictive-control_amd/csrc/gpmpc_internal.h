@@ -191,6 +191,7 @@ struct Handle {
     int opt_prepare_invcols = 1;     // 32-wide panel path, N <= 352 (measured crossover; option 2: up to 544): L^-1 in one launch after the factorisation (0: row blocks beside / after the panels)
     int opt_prepare_fuse = 1;        // 32-wide panel path: trailing update fused with the next diagonal block's factorisation (0: separate launches, A/B)
     int opt_prepare_overlap = 1;     // 32-wide panel path: the inverse's launches on a side stream beside the factorisation's (0: one stream, A/B)
+    int opt_gram_shared = 1;         // large N: K of all GPs by one workgroup per tile, squared differences shared (0: per-GP kernel, A/B)
     int opt_fused_prepare = 1;       // N <= 256: the whole factorisation in one launch (prepare_small.hip); 0: panel path (A/B, tests)
     int last_prepare_mode = 0;       // 0 full, 1 border update(s), 2 unchanged (cache hit)
     int lds_limit = 160 * 1024;

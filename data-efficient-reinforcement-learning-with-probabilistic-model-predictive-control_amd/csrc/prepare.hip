@@ -14,6 +14,7 @@
 // D[row=(l>>4)+4r][col=l&15]).
 #include "gpmpc_internal.h"
 #include "prepare_tiled.h"
+#include "rollout_kernel.h"        // fast_exp / kExp2Tab
 
 namespace gpmpc_hip {
 
@@ -181,6 +182,69 @@ __global__ __launch_bounds__(256) void gram_kernel(const double* __restrict__ Xt
             const int r = wave * 16 + rr;
             const int jj = j0 + r, ii = i0 + lane;
             if (jj < N && ii < N) Ka[(size_t)jj * N + ii] = tile[lane][r];
+        }
+    }
+}
+
+// The same matrices for large memories (lower triangle only, N >= outer_min_n), all D GPs by ONE workgroup per 64 x 64 tile:
+// the squared differences (x_ie - x_je)^2 of an element are formed once and contracted with every GP's 1 / l_ae^2 (LDS
+// broadcasts), instead of being recomputed per GP -- per stored element E FMAs + a table-based exp (fast_exp, ~1 ulp) where
+// gram_kernel spends 2 EP VALU + libm's exp (139 vector instructions per element at config 5: it ran at 1.05 TB/s of stores,
+// VALU-bound).  Lane = column j (coalesced 512-byte row segments per GP), a thread visits its 16 rows two at a
+// time (one set of LDS reads of 1 / l^2 serves both).  Tiles with tj > ti are not launched at all (grid over the lower block
+// triangle through a linear tile index).
+template <int EP>
+__global__ __launch_bounds__(256) void gram_lower_kernel(const double* __restrict__ Xt, const double* __restrict__ ils2,
+                                                         const double* __restrict__ var, const double* __restrict__ noise,
+                                                         int N, int E, int D, double* __restrict__ K) {
+    __shared__ double xi[64][EP + 1];           // rows of the tile (unscaled)
+    __shared__ __attribute__((aligned(16))) double s_il[kMaxD][EP];
+    __shared__ double s_var[kMaxD], s_nz[kMaxD], s_tab[64];
+    // linear index over the lower block triangle: t = ti (ti + 1) / 2 + tj, tj <= ti
+    const int t = blockIdx.x;
+    int ti = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+    while ((ti + 1) * (ti + 2) / 2 <= t) ++ti;
+    while (ti * (ti + 1) / 2 > t) --ti;
+    const int tj = t - ti * (ti + 1) / 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = ti * 64, j0 = tj * 64;
+    for (int idx = threadIdx.x; idx < 64 * EP; idx += 256) {
+        const int r = idx / EP, e = idx - r * EP;
+        xi[r][e] = (e < E && i0 + r < N) ? Xt[(size_t)e * N + i0 + r] : 0.0;
+    }
+    for (int idx = threadIdx.x; idx < D * EP; idx += 256) {
+        const int a = idx / EP, e = idx - a * EP;
+        s_il[a][e] = (e < E) ? ils2[a * E + e] : 0.0;
+    }
+    if ((int)threadIdx.x < D) { s_var[threadIdx.x] = var[threadIdx.x]; s_nz[threadIdx.x] = noise[threadIdx.x]; }
+    if (threadIdx.x >= 64 && threadIdx.x < 128) s_tab[threadIdx.x - 64] = kExp2Tab[threadIdx.x - 64];
+    const int j = j0 + lane;
+    double xj[EP];
+#pragma unroll
+    for (int e = 0; e < EP; ++e) xj[e] = (e < E && j < N) ? Xt[(size_t)e * N + j] : 0.0;
+    __syncthreads();
+    for (int rr = 0; rr < 16; rr += 2) {
+        const int r0 = wave * 16 + rr, r1 = r0 + 1;
+        double d0[EP], d1[EP];
+#pragma unroll
+        for (int e = 0; e < EP; ++e) {
+            const double a0 = xi[r0][e] - xj[e], a1 = xi[r1][e] - xj[e];
+            d0[e] = a0 * a0;
+            d1[e] = a1 * a1;
+        }
+        const int ia = i0 + r0, ib = i0 + r1;
+        for (int a = 0; a < D; ++a) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int e = 0; e < EP; ++e) { const double w = s_il[a][e]; s0 = fma(w, d0[e], s0); s1 = fma(w, d1[e], s1); }
+            double v0 = s_var[a] * fast_exp(-0.5 * s0, s_tab), v1 = s_var[a] * fast_exp(-0.5 * s1, s_tab);
+            if (ia == j) v0 += s_nz[a];
+            if (ib == j) v1 += s_nz[a];
+            double* Ka = K + (size_t)a * N * N;
+            if (j < N) {
+                if (ia < N) Ka[(size_t)ia * N + j] = v0;
+                if (ib < N) Ka[(size_t)ib * N + j] = v1;
+            }
         }
     }
 }
@@ -1314,7 +1378,22 @@ int run_prepare(Handle* h, const double* X, const double* Y, const double* ls, c
     if (!factored) {
         const dim3 grid((N + 63) / 64, (N + 63) / 64, D);
         const int lower = (N >= h->opt_outer_min_n && h->opt_outer_block != 0) ? 1 : 0;
-        if (E <= 4) hipLaunchKernelGGL(gram_kernel<4>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p, lower);
+        const int nt_l = (N + 63) / 64;
+        // all GPs per tile, squared differences shared (gram_lower_kernel), once its one-workgroup-per-tile grid fills the chip
+        // (measured, profiles/r06_gram_ab.txt: N = 4096, D = 16: 985 -> 264 us = 4.1 TB/s of stores; N = 1000, D = 4 (136 tiles):
+        // 15.0 -> 17.4 us, hence the tile-count rule); "gram_shared" 0: the per-GP kernel always, 2: the shared one whenever lower (A/B)
+        if (lower && (h->opt_gram_shared == 2 || (h->opt_gram_shared == 1 && nt_l * (nt_l + 1) / 2 >= 2 * h->num_cu))) {
+            const int nt = nt_l;
+            const dim3 gl(nt * (nt + 1) / 2);
+            auto go = [&](auto kern) { hipLaunchKernelGGL(kern, gl, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, D, h->gram.p); };
+            if (E <= 4) go(gram_lower_kernel<4>);
+            else if (E <= 8) go(gram_lower_kernel<8>);
+            else if (E <= 12) go(gram_lower_kernel<12>);
+            else if (E <= 16) go(gram_lower_kernel<16>);
+            else if (E <= 20) go(gram_lower_kernel<20>);
+            else go(gram_lower_kernel<24>);
+        }
+        else if (E <= 4) hipLaunchKernelGGL(gram_kernel<4>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p, lower);
         else if (E <= 8) hipLaunchKernelGGL(gram_kernel<8>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p, lower);
         else if (E <= 16) hipLaunchKernelGGL(gram_kernel<16>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p, lower);
         else hipLaunchKernelGGL(gram_kernel<24>, grid, dim3(256), 0, s, h->Xt.p, h->ils2.p, h->var.p, noise, N, E, h->gram.p, lower);
