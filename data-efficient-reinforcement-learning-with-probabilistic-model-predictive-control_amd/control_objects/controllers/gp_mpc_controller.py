@@ -153,7 +153,7 @@ class GpMpcController(BaseControllerObject):
             else:
                 self.num_rollouts += 1
                 grad = self.actions_mapper.chain_grad_model_to_mpc(host["grad"][0])
-                self._cache_trajectory({k: torch.from_numpy(v) for k, v in host.items()}, 0)
+                self._lazy_host = host                          # the caches of :279-283, made on first read
                 return float(host["J"][0]), grad
         J, g_model, out = self._objective_and_gradient_by_differences(base[None], obs_mu, obs_var, trajectories=True)
         grad = self.actions_mapper.chain_grad_model_to_mpc(g_model[0])
@@ -250,6 +250,31 @@ class GpMpcController(BaseControllerObject):
             self.info_iters.setdefault(key, []).append(val)
 
     # ---------------------------------------------------------------------------- internals
+    # The logging caches of the reference (:279-283) are written by EVERY objective evaluation but read once per control step
+    # (get_action, :88-106): the sequential optimiser's evaluations keep the host arrays of their last call and the five
+    # tensors are made when somebody looks.
+    def _materialise_caches(self):
+        host = self.__dict__.pop("_lazy_host", None)
+        if host is not None:
+            self._cache_trajectory({k: torch.from_numpy(v) for k, v in host.items()}, 0)
+
+    def _lazy_cache_property(name):                    # noqa: N805 -- class-body helper
+        def get(self):
+            self._materialise_caches()
+            return self.__dict__[name]
+
+        def put(self, value):
+            self.__dict__.pop("_lazy_host", None) if name == "states_mu_pred" else None
+            self.__dict__[name] = value
+        return property(get, put)
+
+    states_mu_pred = _lazy_cache_property("states_mu_pred")
+    states_var_pred = _lazy_cache_property("states_var_pred")
+    rewards_trajectory = _lazy_cache_property("rewards_trajectory")
+    rewards_traj_var = _lazy_cache_property("rewards_traj_var")
+    cost_traj_mean_lcb = _lazy_cache_property("cost_traj_mean_lcb")
+    del _lazy_cache_property
+
     def _cache_trajectory(self, out, idx):
         self.states_mu_pred = out["mu"][idx].cpu()
         self.states_var_pred = out["Sig"][idx].cpu()

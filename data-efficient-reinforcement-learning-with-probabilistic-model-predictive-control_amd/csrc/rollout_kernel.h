@@ -1696,7 +1696,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                         } else {
                             // rows per trip = depth of the T prefetch (see item_taylor2): 4 from DP = 4 up.  One
                             // instantiation per degree: a second one (choice by N) cost config 2 2.7 % through the larger kernel.
-                            constexpr int TU = DP >= 4 ? 4 : 2;
+                            constexpr int TU = DP >= 4 ? 4 : 2;       // (the cooperative form measured the same with 2, 4, 8: its items are bound by their set-up)
                             if (K <= 2) item_taylor2<DP, 2, TU>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
                             else if (K == 3) item_taylor2<DP, 3, TU>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
                             else if (K == 4) item_taylor2<DP, 4, TU>(rec, nrows, w, w1, diag, Tp, N, acc0, acc1);
