@@ -118,6 +118,7 @@ int gpmpc_set_option(gpmpc_t* g, const char* name, long long value) {
     else if (!strcmp(name, "grad_tiles")) h->opt_grad_tiles = (int)value;
     else if (!strcmp(name, "grad_fuse")) h->opt_grad_fuse = (int)value;
     else if (!strcmp(name, "grad_mean")) h->opt_grad_mean = (int)value;
+    else if (!strcmp(name, "grad_merge")) h->opt_grad_merge = (int)value;
     else if (!strcmp(name, "prepare_overlap")) h->opt_prepare_overlap = (int)value;
     else if (!strcmp(name, "prepare_fuse")) h->opt_prepare_fuse = (int)value;
     else if (!strcmp(name, "prepare_invcols")) h->opt_prepare_invcols = (int)value;

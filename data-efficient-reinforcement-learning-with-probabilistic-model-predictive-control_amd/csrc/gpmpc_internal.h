@@ -78,6 +78,7 @@ struct RolloutArgs {
     int xch_n;                   // values per exchange
     unsigned xch_tag0;           // tags of this launch: xch_tag0 + step + 1 (unique over the life of the buffer)
     unsigned long long* xch;
+    int defer_cost;              // 1: launch_rollout leaves the stage costs / objective to its caller (the few-candidate gradient launch folds them into its moment launch)
     int cl_dbg;                  // timing experiments of the exchange (-DGPMPC_CL_DEBUG builds only)
     // initial state distribution
     double mu0[kMaxD];
@@ -183,6 +184,7 @@ struct Handle {
                                      // of 2.14 + 0.49 ms) but the fp64 pipe is already at the ~76 % of its nominal rate an FMA loop reaches
     int last_rollout_path = 0;       // what the last rollout launch used: 0 fused-horizon kernel, 1 streaming kernel, 2 batch-major tiles
     int last_fused_tiles = 0;        // 1: the last batch-major forward also formed the gradient's tile moments (RolloutArgs::grad_mom)
+    int opt_grad_merge = 1;          // few candidates: element-wise moments + mean moments + stage costs in ONE launch (0: three launches, A/B)
     int opt_grad_mean = 1;           // moment pass (D <= 4): the mean part by mean_moments_kernel (lanes over points); 0: inside the pass (A/B, tests)
     int opt_grad_fuse = 1;           // gradient: form the diagonal pairs' tile moments inside the batch-major forward (0: separate pass, A/B)
     int last_grad_path = 0;          // moment passes of the last gpmpc_rollout_grad: bit 0 separable off-diagonal pairs, bit 1 tile moments of
@@ -220,6 +222,7 @@ inline int allow_full_lds(Handle* h, const void* kernel) {
 // rollout.hip
 int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s);
 int launch_argmin(Handle* h, const double* J, int B, long long first, hipStream_t s);
+int launch_traj_cost(Handle* h, const RolloutArgs& a, double* cm, double* cv, double* J, hipStream_t s);     // stage costs + objective of the stored trajectory
 // pair_tile.hip: the batch-major pass of horizon step t (a.mu_out / a.Sig_out hold the state), a.tile_part / a.ntiles set on return
 bool tile_path_supported(Handle* h, const RolloutArgs& a);
 int tile_workspace(Handle* h, RolloutArgs& a);

@@ -29,6 +29,44 @@ int launch_moments(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s
     }
 }
 
+// Few candidates (B x H x 2 <= CUs: the reference's one-sequence-per-evaluation regime): the element-wise moment pass, the mean
+// moments and the stage costs / objective of the stored trajectory are independent of each other and each fills a fraction of
+// the chip -- ONE grid runs them side by side (z < gz: pair groups, z = gz: mean moments, z = gz + 1 and x = 0: the candidate's
+// costs) instead of three launches in a row (config-2 shape, B = 1: 23 + 7.5 + 12 us and two launch gaps -> ~24 us).
+struct CostSlice {
+    const double* cost; double kappa; int clip, use_constraints; double* cm; double* cv; double* J;
+};
+template <int DP, int NXP, int NT>
+__global__ __launch_bounds__(NT) void few_candidate_moments_kernel(const GradArgs p, const CostSlice cs) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    if ((int)blockIdx.z < p.gz) { pair_moments_body<DP, NXP, NT, 1>(p, smem); return; }
+    if ((int)blockIdx.z == p.gz) {
+        if ((int)threadIdx.x >= 64 * DP) return;
+        mean_moments_body<DP, NXP>(p, smem);
+        return;
+    }
+    if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+    traj_cost_body(blockIdx.y, threadIdx.x, p.mu, p.Sig, p.actions, cs.cost, p.D, p.A, p.H, cs.kappa, cs.clip, cs.use_constraints,
+                   cs.cm, cs.cv, cs.J);
+}
+
+template <int DP, int NXP>
+int launch_few_candidate_moments(Handle* h, const GradArgs& g, const CostSlice& cs, size_t lds_bytes, hipStream_t s) {
+    constexpr int NT = DP <= 3 ? 1024 : kMomThreads;
+    auto kern = few_candidate_moments_kernel<DP, NXP, NT>;
+    int rc = allow_full_lds(h, reinterpret_cast<const void*>(kern));
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3(g.H, g.B, g.gz + 2), dim3(NT), lds_bytes, s, g, cs);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    return GPMPC_OK;
+}
+
+template <int DP>
+int launch_few_candidate_moments_dp(Handle* h, const GradArgs& g, const CostSlice& cs, size_t lds_bytes, hipStream_t s) {
+    if (g.NXP == 1) return launch_few_candidate_moments<DP, 1>(h, g, cs, lds_bytes, s);
+    return g.NXP == 2 ? launch_few_candidate_moments<DP, 2>(h, g, cs, lds_bytes, s) : launch_few_candidate_moments<DP, 6>(h, g, cs, lds_bytes, s);
+}
+
 template <int DP, int NT>
 int launch_sweep(Handle* h, const GradArgs& g, size_t lds_bytes, hipStream_t s) {
     auto kern = (g.D == DP) ? adjoint_sweep_kernel<DP, NT, DP> : adjoint_sweep_kernel<DP, NT, 0>;
@@ -157,8 +195,15 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
         GPMPC_HIP_CHECK(h, hipMemsetAsync(sep_flags, 0, (size_t)B * H * P * sizeof(int), s));
         a.grad_mom = g.mom; a.grad_done = sep_flags; a.grad_NSP = NSP; a.grad_NXP = NXP;
     }
+    // few candidates: the stage costs / objective ride in the moment launch below (few_candidate_moments_kernel)
+    const bool few = DP <= 4 && !stream && h->opt_grad_mean != 0 && h->opt_grad_merge != 0 && (long long)B * H * 2 <= h->num_cu &&
+                     mom_lds >= 64 * sizeof(double);
+    double* want_cm = a.cm_out; double* want_J = a.J_out;
+    a.defer_cost = few ? 1 : 0;
     rc = launch_rollout(h, a, s);            // forward: trajectory, costs, J (+ the fused tile moments)
+    a.defer_cost = 0;
     if (rc) return rc;
+    bool cost_pending = few;
     const bool fused = h->last_fused_tiles != 0;
 
     g.Xt = a.Xt; g.beta = a.beta; g.Tm = a.Tm; g.ils2 = a.ils2; g.var = a.var; g.logvar = a.logvar; g.cost = a.cost;
@@ -243,7 +288,14 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
         if (rc) return rc;
         h->last_grad_path |= 2;
     }
-    if (DP <= 4 && h->opt_grad_mean != 0) {
+    const bool merged = cost_pending && g.sepdone == nullptr && !want_tiles && gz >= 1;
+    if (cost_pending && !merged) {
+        // (the separable / tile passes took pairs after all: the costs as their own launch)
+        rc = launch_traj_cost(h, a, want_cm, a.cv_out, want_J, s);
+        if (rc) return rc;
+        cost_pending = false;
+    }
+    if (DP <= 4 && h->opt_grad_mean != 0 && !merged) {
         // the mean part on its own, lanes over points (mean_moments_kernel): 22 -> ~1 ms of a config-4 launch (streaming pass); in the
         // LDS-resident pass it was a quarter of the kernel's time per (candidate, step) at config 2 (profiles/r04j_moment_phases.txt)
         auto launch = [&](auto kern) -> int {
@@ -320,6 +372,16 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
         }
         if (!plan(want)) plan(CH0);
         publish_plan();
+    if (merged) {
+        g.mean_done = 1;
+        h->last_grad_path |= 32 | 64;
+        const CostSlice cs{a.cost, a.kappa, a.clip, a.use_constraints, want_cm, a.cv_out, want_J};
+        switch (DP) {
+            case 2:  rc = launch_few_candidate_moments_dp<2>(h, g, cs, mom_lds, s); break;
+            case 3:  rc = launch_few_candidate_moments_dp<3>(h, g, cs, mom_lds, s); break;
+            default: rc = launch_few_candidate_moments_dp<4>(h, g, cs, mom_lds, s); break;
+        }
+    } else
     switch (DP) {
         case 2:  rc = launch_moments_dp<2>(h, g, mom_lds, s); break;
         case 3:  rc = launch_moments_dp<3>(h, g, mom_lds, s); break;

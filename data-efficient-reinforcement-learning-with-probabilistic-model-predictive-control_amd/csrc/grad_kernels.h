@@ -118,8 +118,7 @@ __host__ __device__ inline MomLayout make_mom_layout(int N, int D, int E, int G,
 // NT = 512 with one column per lane at D <= 3: the same 128-VGPR code as the 1024-thread workgroup, TWO workgroups per CU (when
 // their LDS fits twice) -- one's per-step set-up and reductions overlap the other's item loop.
 template <int DP, int NXP, int NT, int NC>
-__global__ __launch_bounds__(NT, (NT == 512 && NC == 1 && DP <= 3) ? 4 : 1) void pair_moments_kernel(const GradArgs p) {
-    extern __shared__ __attribute__((aligned(16))) double smem[];
+__device__ __forceinline__ void pair_moments_body(const GradArgs& p, double* smem) {
     constexpr int NW = NT / kWave;
     constexpr int RS = grad_row_stride(DP, NXP);     // row record: ka'_i, beta_ai, g_i (DP), u_i (DP), nu_ie / l_ae^2 (NXP), pad
     constexpr int NH = DP * (DP + 1) / 2;
@@ -617,12 +616,19 @@ __global__ __launch_bounds__(NT, (NT == 512 && NC == 1 && DP <= 3) ? 4 : 1) void
 #endif
 }
 
+template <int DP, int NXP, int NT, int NC>
+__global__ __launch_bounds__(NT, (NT == 512 && NC == 1 && DP <= 3) ? 4 : 1) void pair_moments_kernel(const GradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    pair_moments_body<DP, NXP, NT, NC>(p, smem);
+}
+
 // ------------------------------------------------------------------------------------------
 constexpr int kSweepAug = 16;     // LDS augmented blocks of the sweep (D > 4)
 // registers per lane that hold the next step's moments: max(P * NSP, D * NM) / NT for the largest shapes of a padded D
 // (NX <= 6): DP 2: 3*14 | 2*24 -> 1 (64 lanes);  3: 6*19 | 3*54 -> 3;  4: 10*25 | 4*94 -> 6;  6: 21*40 | 6*223 -> 6 (256 lanes);  8: 36*57 | 8*423 -> 14
+// (four sweep wavefronts at DP <= 4: 256 lanes -> 1, 1, 2)
 template <int DP, int NT>
-constexpr int kSweepPrefetch = (DP == 2) ? 1 : (DP == 3) ? 3 : (DP == 4) ? 6 : (DP == 6) ? 6 : 14;
+constexpr int kSweepPrefetch = (DP <= 4 && NT >= 256) ? (DP == 4 ? 2 : 1) : (DP == 2) ? 1 : (DP == 3) ? 3 : (DP == 4) ? 6 : (DP == 6) ? 6 : 14;
 
 struct SweepLayout {
     int c_ils2, c_var, cost, gmu, gSig, gu, ctmp, mubar, Sigbar, Sacc, mbar, m, Sig, ms, mom, Ai, cc, M, y, V, Sb, Vb, Mb, cb, s0b,
@@ -726,7 +732,12 @@ template <int DP, int NT, int DX>
 __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     constexpr int NW = NT / kWave;
-    constexpr int NL = (DP <= 4) ? 64 : NT;          // threads of the reverse sweep proper
+    // threads of the reverse sweep proper.  D <= 4: four wavefronts when the launch has them -- the independent loops of a phase (e.g.
+    // the mean part's s1_bar, the pairs' K_q and m_q) then run side by side on their own wavefronts instead of one after the other
+    // on one (round 6; same arithmetic per element, results bit-identical) -- else the one
+    constexpr int NL = (DP <= 4) ? (NT >= 256 ? 256 : 64) : NT;
+    // first thread of the wavefront a loop is given to (0 when the sweep has a single wavefront)
+    [[maybe_unused]] constexpr int W1 = (DP <= 4 && NL > 64) ? 64 : 0, W2 = (DP <= 4 && NL > 64) ? 128 : 0, W3 = (DP <= 4 && NL > 64) ? 192 : 0;
     constexpr int NPF = kSweepPrefetch<DP, NL>;
     // LDS-only hand-off: the fences name the local address space, so a sync does not wait for the global loads of the
     // next step that are in flight
@@ -879,7 +890,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         }
     }
     // NPF values per lane cover P*NSP and D*NM (host checks the bound); E, D*D <= NL
-    if constexpr (NL < NT) { if (tid >= NL) return; }          // the sweep is one wavefront's
+    if constexpr (NL < NT) { if (tid >= NL) return; }          // the sweep proper runs on NL threads
     double pf_mom[NPF], pf_ms[NPF], pf_m = 0.0, pf_Sig = 0.0;
     auto fetch = [&](int t) {
         const double* mom = p.mom + ((size_t)c * H + t) * P * NSP;
@@ -1006,13 +1017,13 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             Sacc[i] = acc;
             s_Vb[i] = vb;
         }
-        for (int a = tid; a < D; a += NL) {
+        for (int a = tid - W1; a < D; a += NL) { if (a < 0) continue;
             double v = mubar[a];
             for (int b = 0; b < D; ++b) v = fma(-2.0 * s_Sb[a * D + b], s_M[b], v);
             s_Mb[a] = v;
         }
         // pairs: RZ = R^-T Z_bar,  Z_bar = 1/2 W_bar P2
-        for (int i = tid; i < P * DD; i += NL) {
+        for (int i = tid - W2; i < P * DD; i += NL) { if (i < 0) continue;
             const int q = i / DD, r = (i - q * DD) / D, cc = i - q * DD - r * D;
             int a, b;
             pair_of(q, a, b);
@@ -1030,7 +1041,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             for (int j = 0; j < D; ++j) v = fma(s_Ai[a * DD + k * D + j], s_Vb[j * D + a], v);
             s_s1b[a * D + k] = s_cc[a] * v;                                      // s1_bar = c A^-1 v_bar
         }
-        for (int a = tid; a < D; a += NL) {
+        for (int a = tid - W1; a < D; a += NL) { if (a < 0) continue;
             double v = s_Mb[a] * s_ms[a * NM];
             for (int k = 0; k < D; ++k) v = fma(s_Vb[k * D + a], s_y[a * D + k], v);
             s_cb[a] = v;                                                         // c_bar
@@ -1038,7 +1049,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         }
         // pairs: K_q = RZ + (coef R^-T - RZ Z^T) diag(dab);  m_q
         if constexpr (DP <= 4) {
-            for (int i = tid; i < P * DD; i += NL) {                 // one thread per element, own buffer
+            for (int i = tid - W2; i < P * DD; i += NL) { if (i < 0) continue;   // one thread per element, own buffer
                 const int q = i / DD, r = (i - q * DD) / D, cc = i - q * DD - r * D;
                 int a, b;
                 pair_of(q, a, b);
@@ -1070,7 +1081,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
                 }
             }
         }
-        for (int i = tid; i < P * E; i += NL) {
+        for (int i = tid - W3; i < P * E; i += NL) { if (i < 0) continue;
             const int q = i / E, e = i - q * E;
             int a, b;
             pair_of(q, a, b);
@@ -1120,7 +1131,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             s_Aib[i] = 0.5 * s_cc[a] * (s_Vb[k * D + a] * s_ms[a * NM + 1 + l] + s_Vb[l * D + a] * s_ms[a * NM + 1 + k])
                      + 0.5 * (G2[k * D + l] + G2[l * D + k]);
         }
-        for (int i = tid; i < D * E; i += NL) {
+        for (int i = tid - W1; i < D * E; i += NL) { if (i < 0) continue;
             const int a = i / E, e = i - a * E;
             const double* G1 = s_Gs + a * NG;
             double v;
@@ -1156,7 +1167,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             for (int q = 0; q < P; ++q) v += s_Kq[q * DD + i];
             Sacc[i] = v;
         }
-        for (int e = tid; e < E; e += NL) {
+        for (int e = tid - W1; e < E; e += NL) { if (e < 0) continue;
             double v = (e < D) ? mubar[e] : 0.0;
             for (int a = 0; a < D; ++a) v += s_mba[a * E + e];
             for (int q = 0; q < P; ++q) v += s_mq[q * E + e];
@@ -1168,8 +1179,8 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             const int r = i / D, q = i - r * D;
             Sigbar[i] = 0.5 * (Sacc[i] + Sacc[q * D + r]) + 0.5 * (gSig[t * DD + i] + gSig[t * DD + q * D + r]);
         }
-        for (int i = tid; i < D; i += NL) mubar[i] = mbar[i] + gmu[t * D + i];
-        for (int i = tid; i < A; i += NL) p.grad[((size_t)c * H + t) * A + i] = mbar[D + i] + gu[t * A + i];
+        for (int i = tid - W1; i < D; i += NL) if (i >= 0) mubar[i] = mbar[i] + gmu[t * D + i];
+        for (int i = tid - W2; i < A; i += NL) if (i >= 0) p.grad[((size_t)c * H + t) * A + i] = mbar[D + i] + gu[t * A + i];
         sync();
         GPMPC_STRACE(9);
     }

@@ -393,8 +393,7 @@ __global__ __launch_bounds__(kGsThreads) void pair_moments_stream_kernel(const G
 // registers over the lane's N / 64 points, and ONE round of wave reductions (16 values per 57 instructions: wave_reduce16) ends
 // the item.  Grid (H, B), D wavefronts per workgroup.
 template <int DP, int NXP>
-__global__ __launch_bounds__(64 * DP) void mean_moments_kernel(const GradArgs p) {
-    __shared__ double s_tab[64];
+__device__ __forceinline__ void mean_moments_body(const GradArgs& p, double* s_tab) {
     constexpr int T2 = DP * (DP + 1) / 2;
     constexpr int NC = 1 + DP + T2 + DP * T2 + NXP + DP * NXP;       // components in the compile-time (DP, NXP) layout
     constexpr int NG = (NC + 15) / 16;
@@ -498,5 +497,12 @@ __global__ __launch_bounds__(64 * DP) void mean_moments_kernel(const GradArgs p)
         }
     }
 }
+
+template <int DP, int NXP>
+__global__ __launch_bounds__(64 * DP) void mean_moments_kernel(const GradArgs p) {
+    __shared__ double s_tab[64];
+    mean_moments_body<DP, NXP>(p, s_tab);
+}
+
 
 }  // namespace gpmpc_hip

@@ -21,62 +21,7 @@ __global__ __launch_bounds__(64) void traj_cost_kernel(const double* __restrict_
                                                        int D, int A, int H, double kappa, int clip, int use_constraints,
                                                        double* __restrict__ cm_out, double* __restrict__ cv_out,
                                                        double* __restrict__ J_out) {
-    const int c = blockIdx.x, lane = threadIdx.x;
-    const int DA = D + A;
-    const double* target = cost;
-    const double* W = cost + DA;
-    const double* WT = W + DA * DA;
-    const double* smin = WT + D * D;
-    const double* smax = smin + D;
-    double jsum = 0.0;
-    for (int t = lane; t <= H; t += 64) {
-        const bool terminal = (t == H);
-        const int n = terminal ? D : DA;
-        const double* Wm = terminal ? WT : W;
-        const double* m = mu + ((size_t)c * (H + 1) + t) * D;
-        const double* S = Sig + ((size_t)c * (H + 1) + t) * D * D;
-        const double* a = actions + ((size_t)c * H + (terminal ? 0 : t)) * A;
-        auto err = [&](int i) { return (i < D ? m[i] : a[i - D]) - target[i]; };
-        double cm = 0.0, cv = 0.0;
-        // tr(Sigma W) and e^T W e
-        for (int i = 0; i < D; ++i)
-            for (int j = 0; j < D; ++j) cm = fma(S[i * D + j], Wm[j * n + i], cm);
-        for (int i = 0; i < n; ++i) {
-            const double ei = err(i);
-            for (int j = 0; j < n; ++j) cm = fma(ei * Wm[i * n + j], err(j), cm);
-        }
-        // tr(2 TS TS) with TS = W Sigma (state block), 4 (W^T e)^T Sigma (W e)
-        for (int i = 0; i < D; ++i)
-            for (int j = 0; j < D; ++j) {
-                double tij = 0.0, tji = 0.0;
-                for (int k = 0; k < D; ++k) {
-                    tij = fma(Wm[i * n + k], S[k * D + j], tij);
-                    tji = fma(Wm[j * n + k], S[k * D + i], tji);
-                }
-                cv = fma(2.0 * tij, tji, cv);
-                double v1 = 0.0, v2 = 0.0;
-                for (int k = 0; k < n; ++k) {
-                    v1 = fma(err(k), Wm[k * n + i], v1);
-                    v2 = fma(Wm[j * n + k], err(k), v2);
-                }
-                cv = fma(4.0 * v1 * S[i * D + j], v2, cv);
-            }
-        if (use_constraints && !terminal) {
-            for (int d = 0; d < D; ++d) {
-                const double sg = S[d * D + d];              // the reference passes the VARIANCE as sigma (:63-64)
-                cm += 0.5 * (1.0 + erf((smin[d] - m[d]) / (sg * 1.4142135623730951)))
-                    + (1.0 - 0.5 * (1.0 + erf((smax[d] - m[d]) / (sg * 1.4142135623730951))));
-            }
-        }
-        double ucb = -cm + kappa * sqrt(cv);
-        if (clip) ucb = fmin(ucb, 0.0);
-        jsum -= ucb;
-        if (cm_out) cm_out[(size_t)c * (H + 1) + t] = cm;
-        if (cv_out) cv_out[(size_t)c * (H + 1) + t] = cv;
-    }
-    // fixed-order sum over lanes (lane l holds steps l, l + 64, ...)
-    for (int off = 32; off >= 1; off >>= 1) jsum += __shfl_xor(jsum, off, 64);
-    if (lane == 0 && J_out) J_out[c] = jsum / (double)(H + 1);
+    traj_cost_body(blockIdx.x, threadIdx.x, mu, Sig, actions, cost, D, A, H, kappa, clip, use_constraints, cm_out, cv_out, J_out);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -119,6 +64,13 @@ __global__ __launch_bounds__(1024) void argmin_kernel(const double* J, int B, lo
         const long long w = s_best;
         for (int k = tid; k < HA; k += 1024) out[2 + k] = actions[w * HA + k];
     }
+}
+
+int launch_traj_cost(Handle* h, const RolloutArgs& a, double* cm, double* cv, double* J, hipStream_t s) {
+    hipLaunchKernelGGL(traj_cost_kernel, dim3(a.B), dim3(64), 0, s, a.mu_out, a.Sig_out, a.actions, a.cost, a.D, a.A, a.H, a.kappa,
+                       a.clip, a.use_constraints, cm, cv, J);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    return GPMPC_OK;
 }
 
 int launch_argmin_to(Handle* h, const double* J, int B, long long first, const double* actions, int HA, double* out_dev,
@@ -433,7 +385,7 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         rc = launch_kernel();
     }
     if (rc) return rc;
-    if (user_cm || user_cv || user_J) {
+    if ((user_cm || user_cv || user_J) && !a.defer_cost) {
         hipLaunchKernelGGL(traj_cost_kernel, dim3(a.B), dim3(64), 0, s, a.mu_out, a.Sig_out, a.actions, a.cost, D, A, a.H,
                            a.kappa, a.clip, a.use_constraints, user_cm, user_cv, user_J);
         GPMPC_HIP_CHECK(h, hipGetLastError());

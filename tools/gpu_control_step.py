@@ -12,20 +12,7 @@ from oracle import synth
 eng = gp_mpc_amd.HipEngine(0)
 w = synth.make_workload(200, 3, 1, 25, 2, seed=0)
 mu0, S0 = torch.as_tensor(w.mu0), torch.as_tensor(w.S0)
-for restarts, opt in ((1, None), (4, None), (4, "lbfgs"), (16, "lbfgs")):
-    c = make_controller(w, optimize=True, restarts=restarts, engine=eng)
-    c.config.controller.candidate_optimizer = opt
-    np.random.seed(1)
-    c._get_optimal_actions(mu0, S0)                 # warm-up (allocations, first launches)
-    n0 = c.num_rollouts
-    np.random.seed(2)
-    t0 = time.perf_counter()
-    c._get_optimal_actions(mu0, S0)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    nev = c.num_rollouts - n0
-    print(f"restarts={restarts} optimizer={opt or 'scipy sequential'}: {dt*1e3:.1f} ms per control-step optimisation, {nev} evaluations, "
-          f"{dt/nev*1e3:.3f} ms per evaluation" + (f", {c.lbfgs_evaluations} launches" if opt else ""), flush=True)
+# (the single-call figures first: after the 16 solver threads of the lockstep runs below the interpreter times them several times too long)
 acts = torch.as_tensor(w.actions[:1], device="cuda:0")
 eng.rollout_grad(acts, w.mu0, w.S0)
 torch.cuda.synchronize()
@@ -42,4 +29,18 @@ t0 = time.perf_counter()
 for _ in range(20):
     c.compute_mean_lcb_trajectory(x, mu0, S0)
 print(f"controller.compute_mean_lcb_trajectory: {(time.perf_counter()-t0)/20*1e3:.3f} ms", flush=True)
+for restarts, opt in ((1, None), (4, None), (4, "lbfgs"), (16, "lbfgs")):
+    c = make_controller(w, optimize=True, restarts=restarts, engine=eng)
+    c.config.controller.candidate_optimizer = opt
+    np.random.seed(1)
+    c._get_optimal_actions(mu0, S0)                 # warm-up (allocations, first launches)
+    n0 = c.num_rollouts
+    np.random.seed(2)
+    t0 = time.perf_counter()
+    c._get_optimal_actions(mu0, S0)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nev = c.num_rollouts - n0
+    print(f"restarts={restarts} optimizer={opt or 'scipy sequential'}: {dt*1e3:.1f} ms per control-step optimisation, {nev} evaluations, "
+          f"{dt/nev*1e3:.3f} ms per evaluation" + (f", {c.lbfgs_evaluations} launches" if opt else ""), flush=True)
 eng.close()
