@@ -632,7 +632,7 @@ constexpr int kSweepPrefetch = (DP <= 4 && NT >= 256) ? (DP == 4 ? 2 : 1) : (DP 
 
 struct SweepLayout {
     int c_ils2, c_var, cost, gmu, gSig, gu, ctmp, mubar, Sigbar, Sacc, mbar, m, Sig, ms, mom, Ai, cc, M, y, V, Sb, Vb, Mb, cb, s0b,
-        s1b, Gs, Aib, Ab, mba, Ri, Z, rdet, RZ, Kq, mq, aug, pre, total;
+        s1b, Gs, Aib, Ab, mba, Ri, Z, rdet, RZ, Kq, mq, aug, pre, tmu, tSig, tact, tcv, total;
 };
 
 __host__ __device__ inline int sweep_pre_words(int D) {        // per step: Ai, c, Ri, Z, rdet, y, V, M
@@ -655,6 +655,9 @@ __host__ __device__ inline SweepLayout make_sweep_layout(int D, int A, int E, in
     take(L.Ri, P * DD); take(L.Z, P * DD); take(L.rdet, P); take(L.RZ, P * DD); take(L.Kq, D <= 4 ? P * DD : 0); take(L.mq, P * E);
     take(L.aug, naug * D * 2 * D);
     take(L.pre, pre_steps * sweep_pre_words(D));      // state-independent small algebra of every step, computed up front
+    // the candidate's stored trajectory, actions and cost variances, staged once: the prologue's cost adjoints read them in
+    // dependent inner loops (from global memory they were ~30 k of its ~60 k cycles at config 2)
+    take(L.tmu, (H + 1) * D); take(L.tSig, (H + 1) * DD); take(L.tact, H * A); take(L.tcv, H + 1);
     L.total = o;
     return L;
 }
@@ -764,7 +767,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         }
     };
 #if defined(GPMPC_PROF_ON)
-    long long sprof[12] = {0};
+    long long sprof[16] = {0};
     long long sprof_last = __builtin_readcyclecounter();
 #define GPMPC_STRACE(id) do { if (threadIdx.x == 0 && blockIdx.x == 0) { long long now_ = __builtin_readcyclecounter(); \
     sprof[id] += now_ - sprof_last; sprof_last = now_; } } while (0)
@@ -810,17 +813,24 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
     for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
     for (int i = tid; i < D; i += NT) c_var[i] = p.var[i];
     for (int i = tid; i < n + n * n + DD + 2 * D; i += NT) c_cost[i] = p.cost[i];
+    double* s_tmu = smem + L.tmu; double* s_tSig = smem + L.tSig; double* s_tact = smem + L.tact; double* s_tcv = smem + L.tcv;
+    for (int i = tid; i < (H + 1) * D; i += NT) s_tmu[i] = traj_mu[i];
+    for (int i = tid; i < (H + 1) * DD; i += NT) s_tSig[i] = traj_Sig[i];
+    for (int i = tid; i < H * A; i += NT) s_tact[i] = act[i];
+    for (int i = tid; i <= H; i += NT) s_tcv[i] = cvv[i];
     sync_all();
+    GPMPC_STRACE(10);
     // cost adjoints of every time step (independent of the sweep): one wavefront per step
     for (int t = wave; t <= H; t += NW) {
         const bool terminal = (t == H);
-        const double wv = -p.kappa / (2.0 * sqrt(cvv[t])) * inv_n;
-        cost_adjoint_wave(lane, D, A, terminal, traj_mu + t * D, traj_Sig + t * DD, act + (terminal ? 0 : t) * A, target,
+        const double wv = -p.kappa / (2.0 * sqrt(s_tcv[t])) * inv_n;
+        cost_adjoint_wave(lane, D, A, terminal, s_tmu + t * D, s_tSig + t * DD, s_tact + (terminal ? 0 : t) * A, target,
                           terminal ? WT : Wst, smin, smax, p.use_constraints != 0, inv_n, wv, ctmp + wave * (2 * n * n + 3 * n),
                           gmu + t * D, gSig + t * DD, terminal ? ctmp + wave * (2 * n * n + 3 * n) : gu + t * A);
         wave_lds_sync();
     }
     sync_all();
+    GPMPC_STRACE(11);
     for (int i = tid; i < D; i += NT) mubar[i] = gmu[H * D + i];
     for (int i = tid; i < DD; i += NT) {
         const int r = i / D, q = i - r * D;
@@ -834,7 +844,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         if (pre) {
             for (int idx = tid; idx < H * (D + P); idx += NT) {
                 const int t = idx / (D + P), prob = idx - t * (D + P);
-                const double* Sg = traj_Sig + t * DD;
+                const double* Sg = s_tSig + t * DD;
                 double* base = s_pre + t * NQ;
                 int a = prob, b = prob;
                 if (prob >= D) pair_of(prob - D, a, b);
@@ -872,7 +882,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
                 const int q = i / DD, r = (i - q * DD) / D, cc = i - q * DD - r * D;
                 const double* base = s_pre + t * NQ;
                 double v = 0.0;
-                for (int k = 0; k < D; ++k) v = fma(base[oRI + q * DD + r * D + k], traj_Sig[t * DD + k * D + cc], v);
+                for (int k = 0; k < D; ++k) v = fma(base[oRI + q * DD + r * D + k], s_tSig[t * DD + k * D + cc], v);
                 s_pre[t * NQ + oZ + i] = v;
             }
             for (int idx = tid; idx < H * DD; idx += NT) {
@@ -889,6 +899,7 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
             sync_all();
         }
     }
+    GPMPC_STRACE(12);
     // NPF values per lane cover P*NSP and D*NM (host checks the bound); E, D*D <= NL
     if constexpr (NL < NT) { if (tid >= NL) return; }          // the sweep proper runs on NL threads
     double pf_mom[NPF], pf_ms[NPF], pf_m = 0.0, pf_Sig = 0.0;
@@ -1185,6 +1196,8 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         GPMPC_STRACE(9);
     }
 #if defined(GPMPC_PROF_ON)
+    if (threadIdx.x == 0 && blockIdx.x == 0)
+        printf("PROF sweep prologue cycles: constants + trajectory %lld | cost adjoints %lld | state-independent algebra %lld\n", sprof[10], sprof[11], sprof[12]);
     if (threadIdx.x == 0 && blockIdx.x == 0)
         printf("PROF sweep cycles: load %lld | solves %lld | Z,y,V %lld | Sacc,Vb,RZ %lld | s1b,K,mq %lld | G %lld | Aib,mba %lld | Ab %lld | assemble %lld | finish %lld\n",
                sprof[0], sprof[1], sprof[2], sprof[3], sprof[4], sprof[5], sprof[6], sprof[7], sprof[8], sprof[9]);
