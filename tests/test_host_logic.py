@@ -443,7 +443,8 @@ def test_committed_bench_line_has_the_contract_fields():
     d5 = json.loads(open(os.path.join(ROOT, "profiles", "r02b_c5_bench_B256.json")).read().strip().splitlines()[-1])
     assert d5["scaling"] == "strong" and d5["cpu_baseline"].get("extrapolated") is True and d5["config"]["N"] == 4096
     # the round-5 lines: median of five timed windows, and the reversed-batch bitwise check at the bench's own batch size
-    for name, nwin in (("r05y_c2_bench.json", 5), ("r05y_c2_bench_v2.json", 5), ("r05y_c5_bench_B256.json", 1)):
+    for name, nwin in (("r05y_c2_bench.json", 5), ("r05y_c2_bench_v2.json", 5), ("r05y_c5_bench_B256.json", 1),
+                       ("r06z_c2_bench.json", 5), ("r06z_c3_bench.json", 5), ("r06z_c4_bench.json", 1), ("r06z_c5_bench_B256.json", 1)):
         e = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
         for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                   "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "windows"):
@@ -453,6 +454,15 @@ def test_committed_bench_line_has_the_contract_fields():
         assert abs(e["value"] - e["config"]["B_total"] / (e["ms_per_step"] * 1e-3)) / e["value"] < 1e-9
         assert e["parity"]["batch_independence"]["bitwise_equal_reversed_batch"] is True
         assert e["roofline"]["counters_note"] is None and 0.0 < e["roofline"]["valu_busy_frac"] < 1.0
+        if name.startswith("r06z"):
+            # round 6: the bounded fraction beside the contract's `frac` (which exceeds 1 on configs 3 / 4), the library path, the first window
+            assert 0.0 < e["roofline"]["formulation"]["frac_formulation"] < 1.0
+            assert e["config"]["lib_path"].endswith("libgpmpc_hip.so") and e["ms_per_step_first_window"] == w["ms_per_step"][0]
+    # few-candidate latency lines (the reference's regime): one candidate per GPU, the cooperative form where the shape has one
+    for name, coop in (("r06z_c2_B1_bench.json", True), ("r06z_c3_B1_bench.json", True), ("r06z_c1_B1_bench.json", False)):
+        e = json.loads(open(os.path.join(ROOT, "profiles", name)).read().strip().splitlines()[-1])
+        assert e["config"]["B_per_gpu"] == 1 and (e["config"]["workgroups_per_candidate"] > 1) == coop
+        assert 0.0 < e["gradient"]["host_in_host_out_ms_per_evaluation"] < 1.0
 
 
 def test_counter_derived_fields_of_the_stored_lines(tmp_path):
@@ -465,7 +475,7 @@ def test_counter_derived_fields_of_the_stored_lines(tmp_path):
     import subprocess
     import sys
     # (the lines of the LATEST evidence run: profiles/pmc_*.json hold one entry per workload key, stamped with that build)
-    for name in ("r05y_c5_bench_B256.json", "r05y_c2_bench.json", "r05y_c2_bench_v2.json", "r05y_c2_B4096_bench.json", "r05y_c4_bench.json"):
+    for name in ("r06z_c5_bench_B256.json", "r06z_c2_bench.json", "r06z_c3_bench.json", "r06z_c2_B4096_bench.json", "r06z_c4_bench.json"):
         src = os.path.join(ROOT, "profiles", name)
         stored = json.loads(open(src).read().strip().splitlines()[-1])
         cp = tmp_path / name
@@ -481,7 +491,10 @@ def test_counter_derived_fields_of_the_stored_lines(tmp_path):
         assert stored["value"] == got["value"] and stored["gradient"] == got["gradient"]
         if "counters_refreshed" in a:             # the stored line already went through the refresh: idempotent
             assert abs(a["valu_busy_frac"] - b["valu_busy_frac"]) < 1e-12 and a["executed"] == b["executed"]
-        if name.startswith("r05y_c5"):
+        # the work of the formulation the kernels execute: bounded by the peak on every shape, and by the issued fp64 flops
+        f = b["formulation"]
+        assert 0.0 < f["frac_formulation"] < 1.0 and f["frac_formulation"] <= b["executed"]["frac_of_peak"] * 1.0001
+        if name.startswith("r06z_c5"):
             c = b["counters"]
             n_mfma = 0.25 * c["SQ_INSTS_VALU_MFMA_MOPS_F64"]
             want = ((c["SQ_INSTS_VALU"] - n_mfma) * 4 + n_mfma * 64) / (1024 * b["kernel_ms"] * 1e-3 * 2.4e9)

@@ -13,6 +13,9 @@ eng = gp_mpc_amd.HipEngine(0)
 w = synth.make_workload(200, 3, 1, 25, 2, seed=0)
 mu0, S0 = torch.as_tensor(w.mu0), torch.as_tensor(w.S0)
 # (the single-call figures first: after the 16 solver threads of the lockstep runs below the interpreter times them several times too long)
+c = make_controller(w, optimize=True, restarts=1, engine=eng)
+c._prepare()
+c.transition_model.set_cost(c.config.reward)
 acts = torch.as_tensor(w.actions[:1], device="cuda:0")
 eng.rollout_grad(acts, w.mu0, w.S0)
 torch.cuda.synchronize()
@@ -21,8 +24,6 @@ for _ in range(20):
     eng.rollout_grad(acts, w.mu0, w.S0)
 torch.cuda.synchronize()
 print(f"engine.rollout_grad B=1 (device-resident actions): {(time.perf_counter()-t0)/20*1e3:.3f} ms", flush=True)
-c = make_controller(w, optimize=True, restarts=1, engine=eng)
-c._prepare()
 x = w.actions[0].reshape(-1)
 c.compute_mean_lcb_trajectory(x, mu0, S0)
 t0 = time.perf_counter()
