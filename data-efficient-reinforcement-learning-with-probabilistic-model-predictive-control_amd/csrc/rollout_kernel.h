@@ -868,9 +868,12 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     const int tid = threadIdx.x;
     // cooperative form: workgroup b is member (b / 8) % cluster of candidate (b % 8) + 8 (b / (8 cluster)) -- the members of a
     // candidate are 8 apart in dispatch order, i.e. on one XCD where the dispatcher places block b on XCD b % 8 (speed only)
+    // (cluster_debug 8, a test hook: members of a candidate on CONSECUTIVE blocks instead, i.e. spread over the XCDs -- the
+    //  placement-independent form of the exchange is then what runs, across L2s for real)
     const int CS = CL ? p.cluster : 1;
-    const int member = CL ? (int)(blockIdx.x >> 3) % CS : 0;
-    const int c = CL ? (int)(blockIdx.x & 7) + 8 * ((int)(blockIdx.x >> 3) / CS) : (int)blockIdx.x;
+    const bool spread = CL && (p.cl_dbg & 8);
+    const int member = CL ? (spread ? (int)blockIdx.x % CS : (int)(blockIdx.x >> 3) % CS) : 0;
+    const int c = CL ? (spread ? (int)blockIdx.x / CS : (int)(blockIdx.x & 7) + 8 * ((int)(blockIdx.x >> 3) / CS)) : (int)blockIdx.x;
     if constexpr (CL) { if (c >= p.B) return; }
     const int D = (DX > 0) ? DX : p.D;
     const int N = p.N, A = p.A, E = p.E, H = p.H, G = p.G, CM = p.CM;

@@ -74,6 +74,31 @@ def test_reference_goldens_through_the_cooperative_path(engine, name):
     _check_traj(out, g, name, "cooperative_path")
 
 
+def test_members_spread_over_the_xcds_take_the_placement_independent_exchange(engine):
+    """The exchange must not depend on where the dispatcher puts the members: option `cluster_debug` 8 lays the members of a candidate
+    on consecutive blocks (block b runs on XCD b % 8: the members then sit on different XCDs and the kernel's own check of
+    HW_REG_XCC_ID selects the write-through form, across L2s that are not coherent with each other), 4 forces that form on one XCD.
+    Same bits as the one-workgroup kernel in every case, over many steps and launches."""
+    w = synth.make_workload(200, 3, 1, 25, 9, seed=11)
+    _model(engine, w)
+    acts = torch.as_tensor(w.actions, device="cuda:0")
+    engine.set_option("rows_per_chunk", 16)
+    engine.set_option("cluster", 1)
+    ref = {B: engine.rollout(acts[:B], w.mu0, w.S0) for B in (1, 9)}
+    try:
+        for dbg in (8, 4, 12, 0):
+            engine.set_option("cluster_debug", dbg)
+            for cs in (3, 8, 16):
+                engine.set_option("cluster", cs)
+                for rep in range(6):
+                    for B in (1, 9):
+                        out = engine.rollout(acts[:B], w.mu0, w.S0)
+                        assert engine.last_cluster == cs
+                        assert _same(out, ref[B]), (dbg, cs, rep, B)
+    finally:
+        engine.set_option("cluster_debug", 0)
+
+
 def test_dispatch_rule(engine):
     """Few candidates of a memory with enough pairwise items take the cooperative form; small memories and large batches do not."""
     for N, H, B, expect in ((200, 25, 1, True), (200, 25, 16, True), (200, 25, 300, False), (50, 15, 1, False), (500, 10, 2, True)):
