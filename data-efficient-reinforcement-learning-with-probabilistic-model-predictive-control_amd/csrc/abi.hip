@@ -84,6 +84,7 @@ int gpmpc_destroy(gpmpc_t* g) {
                   &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws, &h->cemws, &h->tilews, &h->sepw, &h->tgradws, &h->xch, &h->hio};
     for (Buf* b : all) free_buf(*b);
     if (h->hio_host) (void)hipHostFree(h->hio_host);
+    if (h->xch_uc) (void)hipFree(h->xch_uc);
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);
     if (h->septab) (void)hipFree(h->septab);

@@ -16,6 +16,66 @@ constexpr int kMaxE = GPMPC_MAX_E;
 constexpr int kWave = 64;
 
 // ---------------------------------------------------------------------------------------
+// Static owners of a horizon step's work items among the CS members of a candidate (cooperative form of the fused-horizon kernel,
+// rollout_kernel.h), planned once per launch on the host and read by the kernel (owner tables, LDS slots of the pairs a member
+// holds records of) and by the host (sizing those slots):
+//   diagonal pairs (always element-wise): their D * wtri items in order, an equal contiguous share per member;
+//   off-diagonal pair of ordinal o: k = max(1, CS / P_off) consecutive members starting at o k (mod CS) share its wpp element-wise
+//   slots; the one of them with the fewest diagonal items owns the pair when it is separable (a separable pair is up to 14 more
+//   items, and a member with more items than wavefronts runs a second round) -- so a member holds records of at most ~2 diagonal
+//   and ~1 off-diagonal pairs whatever forms the step takes (all P pairs would not fit the LDS at D = 4 or large N);
+//   mean sums of output a: one member each, counted down from the last, past the owners of separable pairs (a member with a
+//   separable pair AND a mean sum runs three trips of the per-point pass where the others run two).
+struct ClusterMap {
+    int CS, D, P, P_off, wpp, wtri, koff;
+    unsigned char sepown[8];            // owner of off-diagonal pair o when it is separable (D <= 4: P_off <= 6)
+    unsigned char meanown[4];           // owner of the mean sums of output a
+    __host__ __device__ int diag_owner(int ord, int slot) const { return ((ord * wtri + slot) * CS) / (D * wtri); }
+    __host__ __device__ int off_owner(int ord, int slot) const { return ((slot * koff) / wpp + ord * koff) % CS; }
+    __host__ __device__ int sep_owner(int ord) const { return sepown[ord]; }
+    __host__ __device__ int mean_owner(int a) const { return meanown[a]; }
+    __host__ __device__ bool diag_needed(int ord, int m) const { return diag_owner(ord, 0) <= m && m <= diag_owner(ord, wtri - 1); }
+    __host__ __device__ bool off_needed(int ord, int m) const {            // owns an element-wise slot, or the separable pair
+        if (sep_owner(ord) == m) return true;
+        const int mp = ((m - (ord * koff) % CS) % CS + CS) % CS;
+        if (mp >= koff) return false;
+        const int s0 = (mp * wpp + koff - 1) / koff;
+        return s0 < wpp && (s0 * koff) / wpp == mp;
+    }
+    int diag_count(int m) const {                                          // element-wise items of the diagonal pairs member m owns
+        const int T = D * wtri;
+        return ((m + 1) * T + CS - 1) / CS - (m * T + CS - 1) / CS;
+    }
+    int slots_needed(int m) const {                                        // pairs member m holds per-point records of
+        int n = 0;
+        for (int a = 0; a < D; ++a) n += diag_needed(a, m) ? 1 : 0;
+        for (int o = 0; o < P_off; ++o) n += off_needed(o, m) ? 1 : 0;
+        return n;
+    }
+    void plan(int cs, int d, int wpp_, int wtri_) {                        // host
+        CS = cs; D = d; P = d * (d + 1) / 2; P_off = d * (d - 1) / 2; wpp = wpp_; wtri = wtri_ > 0 ? wtri_ : 1;
+        koff = P_off > 0 ? CS / P_off : 1;
+        if (koff < 1) koff = 1;
+        bool taken[64] = {false};
+        for (int o = 0; o < P_off && o < 8; ++o) {
+            int best = (o * koff) % CS;
+            for (int k = 1; k < koff; ++k) {
+                const int m = (o * koff + k) % CS;
+                if (diag_count(m) <= diag_count(best)) best = m;
+            }
+            sepown[o] = (unsigned char)best;
+            taken[best] = true;
+        }
+        for (int a = 0; a < D && a < 4; ++a) {
+            int pick = -1;
+            for (int m = CS - 1, k = 0; m >= 0 && pick < 0; --m)
+                if (!taken[m]) { if (k == a) pick = m; ++k; }
+            meanown[a] = (unsigned char)(pick >= 0 ? pick : (a * CS / D) % CS);
+        }
+    }
+};
+
+// ---------------------------------------------------------------------------------------
 // Kernel argument block of the rollout kernel (passed by value, < 4 KiB).
 struct RolloutArgs {
     // cached model (device)
@@ -75,9 +135,12 @@ struct RolloutArgs {
     // few-candidate cooperative form (rollout_kernel<..., CL = true>): `cluster` workgroups share one candidate's horizon step
     // and exchange their partial sums as tagged 8-byte granules through `xch` (per candidate: 2 buffers x xch_n values x 2 words)
     int cluster;                 // workgroups per candidate (1: the plain kernel)
+    ClusterMap cmap;             // owners of the step's work items among the members (host-planned)
+    int cl_slots;                // pairs whose per-point records a member keeps in LDS (ClusterMap::slots_needed, maximum over the members)
     int xch_n;                   // values per exchange
     unsigned xch_tag0;           // tags of this launch: xch_tag0 + step + 1 (unique over the life of the buffer)
     unsigned long long* xch;
+    unsigned long long* xch_uc;  // the same layout in uncached device memory (members on several XCDs; the placement prologue)
     int defer_cost;              // 1: launch_rollout leaves the stage costs / objective to its caller (the few-candidate gradient launch folds them into its moment launch)
     int cl_dbg;                  // timing experiments of the exchange (-DGPMPC_CL_DEBUG builds only)
     // initial state distribution
@@ -135,7 +198,10 @@ struct Handle {
     double* hio_host_dev = nullptr;
     size_t hio_host_cap = 0;
     Buf xch;      // exchange granules of the cooperative few-candidate kernel (zeroed when (re)allocated, tags never repeat)
-    unsigned xch_epoch = 0;      // launches that used `xch` since it was last zeroed
+    unsigned long long* xch_uc = nullptr;    // ... its uncached twin (hipExtMallocWithFlags)
+    size_t xch_uc_cap = 0;       // 8-byte words
+    unsigned xch_epoch = 1;      // launches that used the exchange buffers, from 1: tag 0 is what a zeroed buffer holds and must never be
+                                 // a tag anybody waits for (a fresh handle's first launch accepted the zeros as the members' XCD ids)
     int opt_cluster = 0;         // workgroups per candidate of the few-candidate path: 0 auto, 1 never, n >= 2 fixed
     int opt_cl_dbg = 0;
     int last_cluster = 1;        // what the last fused-horizon launch used

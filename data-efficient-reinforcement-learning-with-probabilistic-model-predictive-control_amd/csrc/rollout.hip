@@ -66,6 +66,21 @@ __global__ __launch_bounds__(1024) void argmin_kernel(const double* J, int B, lo
     }
 }
 
+// Zeroes an exchange buffer of the cooperative form with WRITE-THROUGH (agent-scope, sc1) stores: every later write to these
+// buffers from another XCD is write-through as well, and no dirty zero line may stay behind in some XCD's L2 to be written back
+// over it.
+__global__ __launch_bounds__(256) void xch_zero_kernel(unsigned long long* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        __hip_atomic_store(p + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+static int zero_exchange(Handle* h, unsigned long long* p, size_t words, hipStream_t s) {
+    const unsigned blocks = (unsigned)((words + 255) / 256 < 256 ? (words + 255) / 256 : 256);
+    hipLaunchKernelGGL(xch_zero_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, p, words);
+    GPMPC_HIP_CHECK(h, hipGetLastError());
+    return GPMPC_OK;
+}
+
 int launch_traj_cost(Handle* h, const RolloutArgs& a, double* cm, double* cv, double* J, hipStream_t s) {
     hipLaunchKernelGGL(traj_cost_kernel, dim3(a.B), dim3(64), 0, s, a.mu_out, a.Sig_out, a.actions, a.cost, a.D, a.A, a.H, a.kappa,
                        a.clip, a.use_constraints, cm, cv, J);
@@ -256,19 +271,14 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
             if (G != 0 && G < (Pg < 48 ? Pg : 48) && xl == 1) { G = 0; }
         }
     };
-    if (!gs) {
-        if (want_cluster) {
-            cl_chunks = true;
-            choose_layout(true);
-            if (G != P) want_cluster = false;              // the cooperative form keeps all pairs in one group
-        }
-        cl_chunks = want_cluster;
-        if (!want_cluster) choose_layout(false);
-        if (G == 0) { gs = true; tiled = false; want_cluster = false; }
-    }
-    if (want_cluster) {
-        // slots of a diagonal pair's triangle (the kernel's s_tri): the element-wise items that are always there
-        int tri = 0;
+    int cl_slots = 0;
+    if (!gs && want_cluster) {
+        // the cooperative form keeps all pairs in ONE group (one exchange per step) but a member holds per-point records only of the
+        // pairs it owns items of (ClusterMap): its chunk length depends on N alone, so chunks, slots and cluster size come first
+        cl_chunks = true;
+        chunking(P);
+        const int wpp_c = (RC * NCu + 63) / 64;
+        int tri = 0;             // slots of a diagonal pair's triangle (the kernel's s_tri): the element-wise items that are always there
         for (int r = 0; r < RC; ++r) { const int first = (r * CH) / 2; tri += first < NCu ? NCu - first : 0; }
         const int wtri = (tri + 63) / 64;
         // ~4 element-wise items per member; below ~24 items the exchange costs what the spread gains (N = 50: 0.122 against 0.127 ms,
@@ -277,12 +287,27 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         if (cs > 32) cs = 32;
         const int cap = h->num_cu / (8 * groups8);
         if (cs > cap) cs = cap;
-        if (cs >= 2) cluster = cs;
+        // (the pairs a member holds records of depend on how the cluster size divides the pairs: when the size of the rule does not
+        //  fit the LDS, the next smaller ones are tried -- down to half of it; a size asked for by option is taken or not at all)
+        for (const int cs_min = h->opt_cluster >= 2 ? cs : (cs + 1) / 2; cs >= 2 && cs >= cs_min && cluster == 1; --cs) {
+            ClusterMap& cmap = a.cmap;
+            cmap.plan(cs, D, wpp_c, wtri);
+            cl_slots = 0;
+            for (int m = 0; m < cs; ++m) { const int n = cmap.slots_needed(m); if (n > cl_slots) cl_slots = n; }
+            for (int xl = ((size_t)E * N * 8 <= 32 * 1024) ? 1 : 0; xl >= 0 && cluster == 1; --xl) {
+                const Layout L = make_layout(N, D, A, E, P, DP, wpp_c, CM, CH, a.H * A, xl != 0, true, cl_slots);
+                if ((size_t)L.lds_total * 8 <= lds_cap) { G = P; lds_bytes = (size_t)L.lds_total * 8; a.x_in_lds = xl; cluster = cs; }
+            }
+        }
         // members of 8 wavefronts (no register spills: 145 VGPRs) from 8 members on; few, wide members otherwise (measured: B = 64,
         // 4 members: 0.267 / 0.270 ms with 1024 / 512 threads; B = 128, 2 members: 0.323 / 0.354; 16 members: 0.240 / 0.216)
         if (cluster > 1 && h->opt_threads == 0) nt = cluster >= 8 ? 512 : 1024;
+        if (cluster == 1) cl_chunks = false;
     }
-    if (cluster == 1 && want_cluster) { cl_chunks = false; choose_layout(false); }          // the plain layout and chunking
+    if (!gs && cluster == 1) {
+        choose_layout(false);
+        if (G == 0) { gs = true; tiled = false; }
+    }
     if (gs) {
         // large-N variant (rollout_stream_kernel.h): column factors + a double-buffered 64-row stage in LDS
         // matrix-core pair pass (DP = 8 / 16): chunks of 64 / 128 / 256 rows = 4 / 8 / 16 row tiles per (chunk, 16-column
@@ -347,24 +372,46 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         }
     };
     a.cl_dbg = h->opt_cl_dbg;
+    a.cl_slots = cl_slots;
+    a.xch_uc = nullptr;
     a.cluster = cluster; a.xch = nullptr; a.xch_n = 0; a.xch_tag0 = 0;
     h->last_cluster = cluster;
     if (cluster > 1) {
         const unsigned wppv = (unsigned)((RC * NCu + 63) / 64);
         a.xch_n = G * (int)wppv + G + D * (D + 1) + 32;       // item slots | separable pairs | mean sums | the members' XCD ids
         const size_t words = (size_t)8 * groups8 * 4 * a.xch_n;
-        // tags never repeat while the buffer lives: 8192 per launch, the buffer is zeroed when it is (re)allocated and before the
-        // 32-bit tag would wrap
+        // tags never repeat while the HANDLE lives (8192 per launch), short of the 32-bit wrap; the buffer is zeroed when it is
+        // (re)allocated and at the wrap
+        // The epoch survives a re-allocation: the new buffer may sit where the old one did, and lines of the old one -- with the
+        // old launches' tags -- can still be in some XCD's L2 (a re-allocated buffer whose tags restarted at 1 let a member accept
+        // such a line: the members' states then differ, so do their item lists, and somebody waits for a value nobody publishes:
+        // seen as a bounded-wait timeout in round 6).  Only the 32-bit wrap restarts it, 2^19 launches later.
         const bool fresh = !h->xch.p || words > h->xch.cap;
         int rcx = grow(h, h->xch, words);
         if (rcx) return rcx;
-        if (fresh || h->xch_epoch >= (1u << 19) - 1) {
-            GPMPC_HIP_CHECK(h, hipMemsetAsync(h->xch.p, 0, h->xch.cap * sizeof(double), s));
-            h->xch_epoch = 0;
+        const bool wrap = h->xch_epoch >= (1u << 19) - 1;
+        if (fresh || wrap) { rcx = zero_exchange(h, reinterpret_cast<unsigned long long*>(h->xch.p), h->xch.cap, s); if (rcx) return rcx; }
+        if (words > h->xch_uc_cap) {
+            if (h->xch_uc) GPMPC_HIP_CHECK(h, hipFree(h->xch_uc));
+            h->xch_uc = nullptr; h->xch_uc_cap = 0;
+            void* q = nullptr;
+            if (hipExtMallocWithFlags(&q, words * sizeof(unsigned long long), hipDeviceMallocUncached) != hipSuccess) {
+                (void)hipGetLastError();
+                GPMPC_HIP_CHECK(h, hipExtMallocWithFlags(&q, words * sizeof(unsigned long long), hipDeviceMallocFinegrained));
+            }
+            h->xch_uc = reinterpret_cast<unsigned long long*>(q);
+            h->xch_uc_cap = words;
+            rcx = zero_exchange(h, h->xch_uc, words, s);
+            if (rcx) return rcx;
+        } else if (wrap) {
+            rcx = zero_exchange(h, h->xch_uc, h->xch_uc_cap, s);
+            if (rcx) return rcx;
         }
+        if (wrap) h->xch_epoch = 1;
         a.xch_tag0 = h->xch_epoch * 8192u;
         h->xch_epoch += 1;
         a.xch = reinterpret_cast<unsigned long long*>(h->xch.p);
+        a.xch_uc = h->xch_uc;
     }
     h->last_rollout_path = gs ? 1 : (tiled ? 2 : 0);
     // the batch-major state of a (possibly re-used) argument block is set on EVERY call, never inherited from an earlier one

@@ -120,7 +120,8 @@ __host__ __device__ inline int rnd2(int x) { return (x + 1) & ~1; }
 constexpr int kClusterScratch = 16 * 64 / 8;     // the cooperative form's per-wavefront problem lists (16 wavefronts x 64 bytes)
 
 __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G, int DP, int wpp, int CM, int CH, int HA,
-                                              bool x_in_lds, bool cluster = false) {
+                                              bool x_in_lds, bool cluster = false, int lds_pairs = 0) {
+    const int GL = (cluster && lds_pairs > 0) ? lds_pairs : G;      // pairs whose per-point records live in LDS (cooperative form: the member's own)
     Layout L;
     const int P = D * (D + 1) / 2;
     int o = 0;
@@ -148,8 +149,9 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     // failure flag + spare (ints) [2] | per-wavefront problem lists of the per-point pass
     // | static owner tables (bytes): item slots [G * wpp], separable pairs [G], pairs needed in element-wise form [G], mean sums [16]
     // | this member's items of the step (16-bit codes) [G * wpp + 16] + their number
+    // | LDS slot of each pair's records (ints) [G]
     L.cl = o;       o += cluster ? rnd2(G) + rnd2((G + 1) / 2) + 2 + kClusterScratch + rnd2((G * wpp + 2 * G + 16 + 7) / 8) +
-                                   rnd2((G * wpp + 16 + 4 + 3) / 4) : 0;
+                                   rnd2((G * wpp + 16 + 4 + 3) / 4) + rnd2((G + 1) / 2) : 0;
     L.c_ils2 = o;   o += rnd2(D * E);
     L.c_logvar = o; o += rnd2(D);
     L.c_var = o;    o += rnd2(D);
@@ -162,8 +164,8 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     int q = o;
     L.nu = q;   q += rnd2(D * N);
     L.lb = q;   q += rnd2(D * N);
-    L.rows = q; q += G * (N + CH) * ((DP + 3) & ~1);   // RowRecAligned<DP>::RS; + CH zero rows per pair (lanes of a wave share the trip count)
-    L.kb = q;   q += rnd2(G * N);
+    L.rows = q; q += GL * (N + CH) * ((DP + 3) & ~1);   // RowRecAligned<DP>::RS; + CH zero rows per pair (lanes of a wave share the trip count)
+    L.kb = q;   q += rnd2(GL * N);
     L.lds_total = q;
     L.pp_total = q - o;
     return L;
@@ -884,7 +886,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     const int wpp = (p.RC * NC + 63) / 64;  // work-item slots per output pair
     const int SD2 = rnd2(D * D);
 
-    const Layout L = make_layout(N, D, A, E, G, DP, wpp, CM, p.CH, H * A, p.x_in_lds != 0, CL);     // the host sized it with the same wpp
+    const Layout L = make_layout(N, D, A, E, G, DP, wpp, CM, p.CH, H * A, p.x_in_lds != 0, CL, CL ? p.cl_slots : 0);     // the host sized it with the same wpp
     const int NR = N + p.CH;                // rows per pair in the row-record array (data + zero padding)
     double* s_mu = smem + L.mu;
     double* s_Sig2 = smem + L.Sig;
@@ -932,6 +934,11 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     [[maybe_unused]] unsigned char* s_meanown = s_elneed + G;                   // owner of the mean sums of output a
     [[maybe_unused]] unsigned short* s_mine = reinterpret_cast<unsigned short*>(       // this member's items of the step, [0] = their number
         smem + L.cl + rnd2(G) + rnd2((G + 1) / 2) + 2 + kClusterScratch + rnd2((G * wpp + 2 * G + 16 + 7) / 8));
+    [[maybe_unused]] int* s_slot = reinterpret_cast<int*>(smem + L.cl + rnd2(G) + rnd2((G + 1) / 2) + 2 + kClusterScratch +
+                                                          rnd2((G * wpp + 2 * G + 16 + 7) / 8) + rnd2((G * wpp + 16 + 4 + 3) / 4));
+    const int GL = CL ? p.cl_slots : G;             // LDS slots of per-pair records
+
+    [[maybe_unused]] unsigned long long* xbuf_uc = CL ? p.xch_uc + (size_t)c * 4 * p.xch_n : nullptr;    // the same in UNCACHED memory: prologue, and the steps of members on several XCDs
     [[maybe_unused]] unsigned long long* xbuf = CL ? p.xch + (size_t)c * 4 * p.xch_n : nullptr;    // [buffer][value][2]
     [[maybe_unused]] const int x_sep = G * wpp, x_mean = G * wpp + G;                       // value index: item slots | separable pairs | mean sums
     [[maybe_unused]] const int x_xcc = x_mean + D * (D + 1);                                // ... | the members' XCD ids (prologue)
@@ -981,7 +988,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
         c_monow[i] = p.mono_w[i];
         c_monoe[i] = p.mono_exp[i * 4] | (p.mono_exp[i * 4 + 1] << 8) | (p.mono_exp[i * 4 + 2] << 16) | (p.mono_exp[i * 4 + 3] << 24);
     }
-    for (int i = tid; i < G * p.CH * RS; i += NT) {
+    for (int i = tid; i < GL * p.CH * RS; i += NT) {
         const int gq = i / (p.CH * RS), k = i - gq * (p.CH * RS);
         a_rows[((size_t)gq * NR + N) * RS + k] = 0.0;                      // zero padding rows
     }
@@ -1053,28 +1060,29 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     if constexpr (CL) {
         // the owners do not depend on the state: tabulated once per launch (the divisions by run-time values cost ~40 vector
         // instructions each -- per step and wavefront they were ~5 k cycles)
+        const ClusterMap& cmap = p.cmap;                 // planned on the host (run-time divisions and searches cost tens of us here)
         for (int i = tid; i < P * wpp; i += NT) {
             const int gq = i / wpp, slot = i - gq * wpp, ord = s_ord[gq];
             int o;
-            if (s_pa[gq] == s_pb[gq]) o = slot < wtri_c ? ((ord * wtri_c + slot) * CS) / (D * wtri_c) : 255;
-            else o = ((slot * CS) / wpp + ord) % CS;
+            if (s_pa[gq] == s_pb[gq]) o = slot < wtri_c ? cmap.diag_owner(ord, slot) : 255;
+            else o = cmap.off_owner(ord, slot);
             s_own[i] = (unsigned char)o;
         }
         for (int gq = tid; gq < P; gq += NT) {
             const int ord = s_ord[gq];
-            s_sepown[gq] = (unsigned char)(CS - 1 - ord % CS);
-            bool need;
-            if (s_pa[gq] == s_pb[gq]) {
-                const int den = D * wtri_c;
-                need = (ord * wtri_c * CS) / den <= member && member <= (((ord + 1) * wtri_c - 1) * CS) / den;
-            } else {
-                const int mp = (member - ord % CS + CS) % CS;
-                const int s0 = (mp * wpp + CS - 1) / CS;
-                need = s0 < wpp && (s0 * CS) / wpp == mp;
-            }
-            s_elneed[gq] = need ? 1 : 0;
+            const bool dg = s_pa[gq] == s_pb[gq];
+            s_sepown[gq] = (unsigned char)(dg ? 255 : cmap.sep_owner(ord));
+            s_elneed[gq] = (dg ? cmap.diag_needed(ord, member) : cmap.off_needed(ord, member)) ? 1 : 0;
         }
-        for (int a = tid; a < D; a += NT) s_meanown[a] = (unsigned char)(CS - 1 - ((P - D + a) % CS));
+        for (int a = tid; a < D; a += NT) s_meanown[a] = (unsigned char)cmap.mean_owner(a);
+        __syncthreads();
+        if (tid == 0) {
+            // LDS slots of the pairs this member holds records of (s_elneed covers both forms of an off-diagonal pair); more than
+            // the host provided cannot happen (same ClusterMap) -- checked all the same: the launch then poisons its output
+            int n = 0;
+            for (int gq = 0; gq < P; ++gq) s_slot[gq] = s_elneed[gq] ? n++ : -1;
+            if (n > GL) *s_fail = 1;
+        }
         __syncthreads();
     }
     [[maybe_unused]] auto item_owner = [&](int code) -> int {
@@ -1085,10 +1093,13 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     // does this member own an item of pair gq (then it needs the pair's per-point factors)?
     [[maybe_unused]] auto pair_needed = [&](int gq) -> bool { return (s_K[gq] & 64) ? s_sepown[gq] == member : s_elneed[gq] != 0; };
     // one value of the step's exchange: two 8-byte words {tag | low}, {tag | high}
-    // Stores: write-through to the fabric (sc1) in general.  When every member of the candidate sits on ONE XCD -- verified below
-    // from HW_REG_XCC_ID, not assumed from the dispatch order -- they share that XCD's L2: a store that stays in L2 (sc0) is then
-    // visible to the other members' L1-bypassing (sc1) loads after one L2 round trip instead of a trip through the fabric
-    // (measured per horizon step: ~3 us -> see DESIGN).  A different placement changes the speed, never the protocol's validity.
+    // Two buffers, two protocols.  When every member of the candidate sits on ONE XCD -- verified below from HW_REG_XCC_ID, not
+    // assumed from the dispatch order -- they share that XCD's L2: stores that stay in L2 (sc0) to ordinary device memory are visible
+    // to the other members' L1-bypassing (sc1) loads after one L2 round trip.  Members on several XCDs (and the prologue that finds
+    // out) use an UNCACHED buffer with write-through stores and sc1 loads: per-XCD L2s are not coherent with each other, and a clean
+    // line that a reader's own L2 still holds -- from the fill kernel that zeroed the buffer, from an earlier launch -- would be
+    // served to its sc1 loads for the whole bounded wait (seen in round 6 on freshly zeroed ordinary memory); uncached memory has
+    // no such lines.  A different placement changes the speed, never the protocol's validity.
     [[maybe_unused]] unsigned x_tag = 0;
     [[maybe_unused]] unsigned long long* x_cur = xbuf;
     [[maybe_unused]] bool same_xcd = false;
@@ -1121,6 +1132,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
 
     if constexpr (CL) {
         // prologue: the members' XCD ids through the placement-independent form (second buffer, tag of "step -1")
+        // (its words of the ordinary buffer are only ever written by these write-through stores and by the write-through zeroing:
+        //  the sc1-store / sc1-load hand-off of MI355X_MICROARCH.md, valid across XCDs; through the uncached twin it cost ~5 us more)
         x_tag = p.xch_tag0;
         x_cur = xbuf + (size_t)2 * p.xch_n;
         const int my_xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11));       // hwreg(HW_REG_XCC_ID, 0, 4)
@@ -1158,7 +1171,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
         if constexpr (CL) {
             // two exchange buffers by step parity: a member writes step t + 2 only after every member published t + 1, i.e. read t
             x_tag = p.xch_tag0 + (unsigned)t + 1u;
-            x_cur = xbuf + (size_t)(t & 1) * 2 * p.xch_n;
+            x_cur = (same_xcd ? xbuf : xbuf_uc) + (size_t)(t & 1) * 2 * p.xch_n;
         }
 
         for (int q0 = 0; q0 < P || (TILED && q0 == 0); q0 += G) {       // TILED, D = 1: no pair, the mean part still runs
@@ -1302,6 +1315,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     const long long cost_el = (long long)N * N * (D + K + 3) / 64;
                     if (p.force_sep || cost_sep < cost_el) K |= 64;
                 }
+                // (cooperative form: the LDS slot of the pair's records rides in the bits above the degree and the separable flag, so the
+                //  readers of s_K get it without another dependent LDS read)
+                if constexpr (CL) K |= (s_slot[gq] + 1) << 8;
                 s_K[gq] = K;
             }
             if constexpr (TILED) {
@@ -1471,7 +1487,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     const int gq = rowside ? prob - nmean : s_off[prob - nmean - Gc];
                     const int a = s_pa[q0 + gq], b = s_pb[q0 + gq];
                     const int c = rowside ? a : b;                         // the output whose lengthscales scale nu
-                    const int K = s_K[gq] & 63;
+                    const int Kw = s_K[gq];
+                    const int K = Kw & 63;
+                    const int sl = CL ? (Kw >> 8) - 1 : gq;                // LDS slot of the pair's records
                     const double* Z = s_aug + (D + gq) * (D * LD) + D;
                     double u[DP], g[DP];
                     double ks = 0.0;                                       // sum_e nu_e^2 / l_e^2
@@ -1503,22 +1521,22 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     const double kk = c_logvar[c] - 0.5 * ks + 0.5 * qq;                  // k (:168) + u^T Q u
                     const double bc = p.beta[c * N + pt];
                     if (rowside) {
-                        double* rec = a_rows + ((size_t)gq * NR + pt) * RS;
+                        double* rec = a_rows + ((size_t)sl * NR + pt) * RS;
 #pragma unroll
                         for (int d = 0; d < DP; ++d) rec[REC::G + d] = g[d];
                         if (K > 0) {
                             const double ea = fast_exp(kk, c_exptab);
                             rec[REC::EA] = ea;
                             rec[REC::RA] = ea * bc;
-                            if (a == b) a_kb[gq * N + pt] = ea;
+                            if (a == b) a_kb[sl * N + pt] = ea;
                         } else {
                             rec[REC::EA] = kk;
                             rec[REC::RA] = bc;
-                            if (a == b) a_kb[gq * N + pt] = kk;
+                            if (a == b) a_kb[sl * N + pt] = kk;
                         }
                         if constexpr (REC::RS > DP + 2) rec[DP + 2] = 0.0;          // the pad travels with the 16-byte reads
                     } else {
-                        a_kb[gq * N + pt] = (K > 0) ? fast_exp(kk, c_exptab) * bc : kk;
+                        a_kb[sl * N + pt] = (K > 0) ? fast_exp(kk, c_exptab) * bc : kk;
                     }
                 }
             }
@@ -1578,14 +1596,15 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     // separable evaluation: moments  G_alpha = sum_i ra_i g_i^alpha,  W_alpha = sum_j rb_j w_j^alpha.
                     // Item = (side, block of 8 consecutive monomials): lanes own points, the point's x and weight are loaded
                     // once for the 8 monomials, whose exponents are wave-uniform (scalar loop counts).
+                    [[maybe_unused]] const int sl3 = CL ? (Kraw >> 8) - 1 : gq;
                     if constexpr (DX == 3) {
                         // three state dimensions: compile-time monomial structure, items = (side, band of the x0 exponent)
                         const int KS = K <= 3 ? 3 : K;                                   // K <= 6 on this path (P1)
                         const int nbands = sep3_bands(KS);
                         for (int itm = slot; itm < 2 * nbands; itm += wpp) {
                             const int side = itm >= nbands, band = itm - side * nbands;
-                            const double* rec0 = a_rows + (size_t)gq * NR * RS;
-                            const double* kbp = a_kb + gq * N;
+                            const double* rec0 = a_rows + (size_t)sl3 * NR * RS;
+                            const double* kbp = a_kb + sl3 * N;
                             const double* il = c_ils2 + b * E;
                             double* mom = s_mom + (gq * 2 + side) * rnd2(CM);
                             if (K <= 3) sep3_item<3>(band, lane, N, side, rec0, RS, kbp, a_nu, il, mom);
@@ -1611,12 +1630,12 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                             double wt;
                             if (side == 0) {
                                 double r[RS];
-                                REC::template load<RS>(a_rows + ((size_t)gq * NR + pt) * RS, r);
+                                REC::template load<RS>(a_rows + ((size_t)sl3 * NR + pt) * RS, r);
                                 wt = r[REC::RA];
 #pragma unroll
                                 for (int d = 0; d < DP; ++d) x[d] = r[REC::G + d];
                             } else {
-                                wt = a_kb[gq * N + pt];
+                                wt = a_kb[sl3 * N + pt];
 #pragma unroll
                                 for (int d = 0; d < DP; ++d) x[d] = (d < D) ? a_nu[d * N + pt] * c_ils2[b * E + d] : 0.0;
                             }
@@ -1681,8 +1700,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     double w[DP];
 #pragma unroll
                     for (int d = 0; d < DP; ++d) w[d] = (d < D) ? a_nu[d * N + j] * c_ils2[b * E + d] : 0.0;
-                    const double kbj = a_kb[gq * N + j];
-                    const double* rec = a_rows + ((size_t)gq * NR + i0) * RS;
+                    const int sle = CL ? (Kraw >> 8) - 1 : gq;
+                    const double kbj = a_kb[sle * N + j];
+                    const double* rec = a_rows + ((size_t)sle * NR + i0) * RS;
                     const double* Tp = p.Tm + ((size_t)a * (N + kTPad) + i0) * N + j;
                     if constexpr (C2) {
                         // second column: always read (jl is a valid column) and masked by a factor -- four `valid1 ? load : 0`
@@ -1691,7 +1711,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                         const double m1 = valid1 ? 1.0 : 0.0;
 #pragma unroll
                         for (int d = 0; d < DP; ++d) w1[d] = (d < D) ? a_nu[d * N + jl] * (c_ils2[b * E + d] * m1) : 0.0;
-                        const double kb1 = a_kb[gq * N + jl] * m1;
+                        const double kb1 = a_kb[sle * N + jl] * m1;
                         double acc0, acc1;
                         if (K == 0) {
                             item_exp2<DP>(rec, nrows, w, w1, kbj, kb1, diag, Tp, N, c_exptab, acc0, acc1);
