@@ -84,6 +84,7 @@ int gpmpc_destroy(gpmpc_t* g) {
                   &h->hyp, &h->kv, &h->vv, &h->sc, &h->gradws, &h->mllws, &h->cemws, &h->tilews, &h->sepw, &h->tgradws, &h->xch, &h->hio};
     for (Buf* b : all) free_buf(*b);
     if (h->hio_host) (void)hipHostFree(h->hio_host);
+    if (h->hio_flag) (void)hipHostFree(h->hio_flag);
     if (h->xch_uc) (void)hipFree(h->xch_uc);
     if (h->info) (void)hipFree(h->info);
     if (h->mono_exp) (void)hipFree(h->mono_exp);
@@ -284,23 +285,25 @@ int gpmpc_rollout_grad(gpmpc_t* g, const double* actions, const double* mu0, con
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// One evaluation for a host-side optimiser: the action sequence travels to the device as a kernel argument (no DMA engine
-// start-up for 200 bytes), the results come back through a pinned, device-mapped host buffer written by a copy kernel, one
-// stream synchronisation.
+// One evaluation for a host-side optimiser: the action sequence travels to the device in the forward kernel's argument block (no
+// DMA engine start-up, no launch of its own for 200 bytes), the results come back through a pinned, device-mapped host buffer
+// written by the last kernel of the evaluation, which then raises a sequence number the host polls.
 namespace {
 constexpr int kUploadMax = 480;                        // doubles in the argument block (< 4 KiB)
 struct UploadArgs { double v[kUploadMax]; };
 __global__ __launch_bounds__(64) void upload_kernel(double* dst, int n, const UploadArgs a) {
     for (int i = threadIdx.x; i < n; i += 64) dst[i] = a.v[i];
 }
-__global__ __launch_bounds__(256) void export_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) dst[i] = src[i];
-}
 }  // namespace
 
 int gpmpc_objective_grad_host(gpmpc_t* g, const double* actions_host, const double* mu0, const double* S0, int H, int A,
                               int include_time, double time0, const double** result_host, void* stream) {
     Range roctx_range("gpmpc_objective_grad_host");
+#if defined(GPMPC_HOST_TIMING)
+    static double acc[4] = {0, 0, 0, 0}; static int calls = 0;
+    auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+    const double T0 = now();
+#endif
     if (!g) return GPMPC_ERR_ARG;
     if (!actions_host || !result_host) return bad(g, "null argument");
     Handle* h = H_(g);
@@ -321,9 +324,19 @@ int gpmpc_objective_grad_host(gpmpc_t* g, const double* actions_host, const doub
         GPMPC_HIP_CHECK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->hio_host_dev), h->hio_host, 0));
         h->hio_host_cap = n_out;
     }
+    if (!h->hio_flag) {
+        GPMPC_HIP_CHECK(h, hipHostMalloc(reinterpret_cast<void**>(&h->hio_flag), 64, hipHostMallocMapped));
+        GPMPC_HIP_CHECK(h, hipHostGetDevicePointer(reinterpret_cast<void**>(&h->hio_flag_dev), h->hio_flag, 0));
+        *h->hio_flag = 0;
+    }
     double* act_dev = h->hio.p;
     double* out_dev = act_dev + n_act;
-    if (n_act <= kUploadMax) {
+    a.act_inline_n = 0;
+    if (n_act <= kInlineActs) {                 // in the forward kernel's argument block (launch_rollout uploads for the other paths)
+        a.act_inline_n = n_act;
+        a.act_store = act_dev;
+        memcpy(a.act_inline, actions_host, n_act * sizeof(double));
+    } else if (n_act <= kUploadMax) {
         UploadArgs u;
         memcpy(u.v, actions_host, n_act * sizeof(double));
         hipLaunchKernelGGL(upload_kernel, dim3(1), dim3(64), 0, s, act_dev, n_act, u);
@@ -339,12 +352,43 @@ int gpmpc_objective_grad_host(gpmpc_t* g, const double* actions_host, const doub
     a.Sig_out = q; q += (size_t)(H + 1) * D * D;
     a.cm_out = q; q += H + 1;
     a.cv_out = q;
+    // The reverse sweep -- the last kernel of the evaluation -- copies the results to the pinned mirror and then raises this call's
+    // sequence number there; the host polls that word (a stream synchronisation costs ~10 us more than the store takes to arrive)
+    // and asks the stream now and then, so that a failed launch ends the wait.
+    const unsigned long long seq = ++h->hio_seq;
+    h->hx_out = h->hio_host_dev; h->hx_src = out_dev; h->hx_n = (int)n_out;
+#if defined(GPMPC_HOST_TIMING)
+    const double T1 = now();
+    g_host_timing_fwd = 0.0;
+#endif
     rc = launch_rollout_grad(h, a, grad, s);
+    h->hx_n = 0;
     if (rc) return rc;
-    hipLaunchKernelGGL(export_kernel, dim3((unsigned)((n_out + 255) / 256 < 8 ? (n_out + 255) / 256 : 8)), dim3(256), 0, s, out_dev,
-                       h->hio_host_dev, (int)n_out);
-    GPMPC_HIP_CHECK(h, hipGetLastError());
-    GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
+#if defined(GPMPC_HOST_TIMING)
+    const double T2 = now();
+#endif
+    volatile unsigned long long* flag = h->hio_flag;
+    for (unsigned spins = 1; *flag != seq; ++spins) {
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) == 0) {
+            const hipError_t qe = hipStreamQuery(s);
+            if (qe == hipSuccess) {
+                if (*flag == seq) break;
+                h->err = "objective_grad_host: the launches ended without the sweep's completion word";
+                return GPMPC_ERR_HIP;
+            }
+            if (qe != hipErrorNotReady) GPMPC_HIP_CHECK(h, qe);
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+#if defined(GPMPC_HOST_TIMING)
+    const double T3 = now();
+    acc[0] += T1 - T0; acc[1] += g_host_timing_fwd - T1; acc[2] += T2 - g_host_timing_fwd; acc[3] += T3 - T2;
+    if (++calls % 200 == 0) {
+        fprintf(stderr, "HOST TIMING us: set-up %.2f | plan + forward launch %.2f | remaining launches %.2f | wait %.2f\n", acc[0] / 200, acc[1] / 200, acc[2] / 200, acc[3] / 200);
+        acc[0] = acc[1] = acc[2] = acc[3] = 0;
+    }
+#endif
     *result_host = h->hio_host;
     return GPMPC_OK;
 }

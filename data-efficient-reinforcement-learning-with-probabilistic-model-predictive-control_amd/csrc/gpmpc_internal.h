@@ -77,6 +77,10 @@ struct ClusterMap {
 
 // ---------------------------------------------------------------------------------------
 // Kernel argument block of the rollout kernel (passed by value, < 4 KiB).
+#if defined(GPMPC_HOST_TIMING)
+inline double g_host_timing_fwd = 0.0;        // (timing experiment builds: when the forward launch of a gradient call was submitted)
+#endif
+constexpr int kInlineActs = 64;
 struct RolloutArgs {
     // cached model (device)
     const double* Xt;      // (E, N)  inputs, structure-of-arrays
@@ -143,6 +147,11 @@ struct RolloutArgs {
     unsigned long long* xch_uc;  // the same layout in uncached device memory (members on several XCDs; the placement prologue)
     int defer_cost;              // 1: launch_rollout leaves the stage costs / objective to its caller (the few-candidate gradient launch folds them into its moment launch)
     int cl_dbg;                  // timing experiments of the exchange (-DGPMPC_CL_DEBUG builds only)
+    // one sequence from the host (gpmpc_objective_grad_host): the actions ride in this block instead of an upload launch; the
+    // fused-horizon kernel takes them from here and leaves a copy at `act_store` (= actions) for the gradient's kernels
+    int act_inline_n;            // H * A (<= kInlineActs), or 0
+    double* act_store;
+    double act_inline[kInlineActs];
     // initial state distribution
     double mu0[kMaxD];
     double S0[kMaxD * kMaxD];
@@ -197,6 +206,12 @@ struct Handle {
     double* hio_host = nullptr;      // ... and its pinned, device-mapped host mirror (results)
     double* hio_host_dev = nullptr;
     size_t hio_host_cap = 0;
+    // ... whose results the reverse sweep itself copies to the host mirror before it raises a sequence number there (the host
+    // polls that word instead of synchronising the stream): set for the one launch of gpmpc_objective_grad_host
+    unsigned long long* hio_flag = nullptr;          // pinned host word and its device address
+    unsigned long long* hio_flag_dev = nullptr;
+    unsigned long long hio_seq = 0;
+    double* hx_out = nullptr; const double* hx_src = nullptr; int hx_n = 0;      // export request (hx_n = 0: none)
     Buf xch;      // exchange granules of the cooperative few-candidate kernel (zeroed when (re)allocated, tags never repeat)
     unsigned long long* xch_uc = nullptr;    // ... its uncached twin (hipExtMallocWithFlags)
     size_t xch_uc_cap = 0;       // 8-byte words

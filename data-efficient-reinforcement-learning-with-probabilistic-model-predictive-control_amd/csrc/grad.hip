@@ -201,6 +201,9 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     double* want_cm = a.cm_out; double* want_J = a.J_out;
     a.defer_cost = few ? 1 : 0;
     rc = launch_rollout(h, a, s);            // forward: trajectory, costs, J (+ the fused tile moments)
+#if defined(GPMPC_HOST_TIMING)
+    { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); g_host_timing_fwd = ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; }
+#endif
     a.defer_cost = 0;
     if (rc) return rc;
     bool cost_pending = few;
@@ -214,6 +217,8 @@ int launch_rollout_grad(Handle* h, RolloutArgs& a, double* grad_out, hipStream_t
     g.DP = DP; g.NXP = NXP; g.NSP = NSP;
     g.pre_steps = pre_steps;
     g.cols = cols;
+    g.host_out = h->hx_out; g.host_src = h->hx_src; g.host_n = (B == 1) ? h->hx_n : 0;
+    g.host_flag = h->hio_flag_dev; g.host_flag_value = h->hio_seq;
     auto publish_plan = [&]() {
         g.G = G; g.CH = CH; g.RC = RC; g.wpp = wpp; g.gz = gz;
         g.magic_N = magic((unsigned)NCU); g.magic_wpp = magic((unsigned)wpp);

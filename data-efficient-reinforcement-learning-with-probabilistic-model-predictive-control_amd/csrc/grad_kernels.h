@@ -51,6 +51,10 @@ struct GradArgs {
     int share_cu;           // 1: launched as two 512-thread workgroups per CU (pair_moments_kernel, D <= 3)
     int mean_done;          // 1: msum was written by mean_moments_kernel (grad_stream_kernel.h): the streaming pass skips its mean part
     unsigned magic_N, magic_wpp;
+    // one candidate evaluated for a host-side optimiser (gpmpc_objective_grad_host): the sweep copies host_n results from host_src
+    // (device) to host_out (pinned host memory) when it is done and then stores host_flag_value at host_flag (host_n = 0: nothing)
+    double* host_out; const double* host_src; int host_n;
+    unsigned long long* host_flag; unsigned long long host_flag_value;
 };
 
 __host__ __device__ inline int tri_index(int d, int e, int DP) { return d * DP - (d * (d - 1)) / 2 + (e - d); }   // d <= e
@@ -906,17 +910,22 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
     auto fetch = [&](int t) {
         const double* mom = p.mom + ((size_t)c * H + t) * P * NSP;
         const double* ms = p.msum + ((size_t)c * H + t) * D * NM;
+        // one load per value, NO branch between or around the loads (lanes past an array's end read its last element: never
+        // stored): the memory counter is in-order, and after a join of divergent paths the compiler waits for EVERYTHING outstanding
+        // before it touches a register a load may still write -- the next step's loads, issued a few instructions earlier, were
+        // waited for right here (round 6: ~1.6 k of a step's 7.5 k cycles)
+        const double* msrc = (tid < D) ? traj_mu + t * D + tid : act + t * A + (tid < D + A ? tid - D : 0);
+        const double* ssrc = traj_Sig + t * DD + (tid < DD ? tid : 0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int k = 0; k < NPF; ++k) {
             const int i = tid + k * NL;
-            pf_mom[k] = (i < P * NSP) ? mom[i] : 0.0;
-            pf_ms[k] = (i < D * NM) ? ms[i] : 0.0;
+            pf_mom[k] = mom[i < P * NSP ? i : P * NSP - 1];
+            pf_ms[k] = ms[i < D * NM ? i : D * NM - 1];
         }
-        // one load per value, no branch between the loads (a second load into a register still in flight would
-        // make the compiler wait for everything outstanding)
-        const double* msrc = (tid < D) ? traj_mu + t * D + tid : act + t * A + (tid < D + A ? tid - D : 0);
         pf_m = *msrc;                               // lanes >= D + A read a valid dummy; selected away when consumed
-        pf_Sig = traj_Sig[t * DD + (tid < DD ? tid : 0)];
+        pf_Sig = *ssrc;
+        __builtin_amdgcn_sched_barrier(0);
     };
     fetch(H - 1);
     for (int t = H - 1; t >= 0; --t) {
@@ -1194,6 +1203,17 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
         for (int i = tid - W2; i < A; i += NL) if (i >= 0) p.grad[((size_t)c * H + t) * A + i] = mbar[D + i] + gu[t * A + i];
         sync();
         GPMPC_STRACE(9);
+    }
+    if (p.host_n > 0 && c == 0) {
+        // results to the host's pinned mirror (the gradient just stored by other lanes of this workgroup: loads that bypass the L1),
+        // made visible to the host before the sequence number it polls
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        sync();
+        for (int i = tid; i < p.host_n; i += NL)
+            p.host_out[i] = __hip_atomic_load(p.host_src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        sync();
+        if (tid == 0) __hip_atomic_store(p.host_flag, p.host_flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 #if defined(GPMPC_PROF_ON)
     if (threadIdx.x == 0 && blockIdx.x == 0)

@@ -74,6 +74,11 @@ __global__ __launch_bounds__(256) void xch_zero_kernel(unsigned long long* p, si
         __hip_atomic_store(p + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+struct InlineActs { double v[kInlineActs]; };
+__global__ __launch_bounds__(64) void inline_acts_kernel(double* dst, int n, const InlineActs a) {
+    for (int i = threadIdx.x; i < n; i += 64) dst[i] = a.v[i];
+}
+
 static int zero_exchange(Handle* h, unsigned long long* p, size_t words, hipStream_t s) {
     const unsigned blocks = (unsigned)((words + 255) / 256 < 256 ? (words + 255) / 256 : 256);
     hipLaunchKernelGGL(xch_zero_kernel, dim3(blocks ? blocks : 1), dim3(256), 0, s, p, words);
@@ -328,6 +333,14 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
     }
     a.G = G; a.CH = CH; a.RC = RC;
     a.cols2 = (cols2 && !gs) ? 1 : 0;
+    if (a.act_inline_n > 0 && (gs || tiled)) {
+        // only the fused-horizon kernel reads the sequence from its argument block: the other paths get it as its own launch
+        InlineActs u;
+        for (int i = 0; i < kInlineActs; ++i) u.v[i] = a.act_inline[i];
+        hipLaunchKernelGGL(inline_acts_kernel, dim3(1), dim3(64), 0, s, a.act_store, a.act_inline_n, u);
+        GPMPC_HIP_CHECK(h, hipGetLastError());
+        a.act_inline_n = 0;
+    }
     const int NCf = a.cols2 ? NCu : N;
     {
         // exact division by multiply-high: for d >= 2, umulhi(x, ceil(2^32 / d)) == x / d whenever x * d < 2^32

@@ -980,7 +980,15 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     }
     for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
     for (int i = tid; i < 2 * E; i += NT) c_xr[i] = p.xrange[i];
-    for (int i = tid; i < H * A; i += NT) c_act[i] = act[i];
+    if (p.act_inline_n > 0) {            // one sequence from the host: in the argument block; a copy for the gradient's kernels
+        for (int i = tid; i < H * A; i += NT) {
+            const double v = p.act_inline[i < kInlineActs ? i : 0];
+            c_act[i] = v;
+            if (!CL || member == 0) p.act_store[i] = v;
+        }
+    } else {
+        for (int i = tid; i < H * A; i += NT) c_act[i] = act[i];
+    }
     for (int i = tid; i < 64; i += NT) c_exptab[i] = kExp2Tab[i];
     if (p.x_in_lds)
         for (int i = tid; i < E * N; i += NT) smem[L.c_X + i] = p.Xt[i];

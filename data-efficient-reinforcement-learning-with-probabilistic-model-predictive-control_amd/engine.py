@@ -19,6 +19,28 @@ def _hp(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
+class _HostEvaluationPlan:
+    """Per (H, A): staging arrays of gpmpc_objective_grad_host's inputs, the layout of its result buffer and a view of it."""
+
+    def __init__(self, H, A, D):
+        self.actions, self.mu0, self.S0 = np.empty((H, A)), np.empty(D), np.empty((D, D))
+        self.p_actions, self.p_mu0, self.p_S0 = (C.c_void_p(a.ctypes.data) for a in (self.actions, self.mu0, self.S0))
+        self.res = C.POINTER(C.c_double)()
+        self.res_ref = C.byref(self.res)
+        self.n = 1 + H * A + (H + 1) * (D + D * D + 2)
+        o = [int(v) for v in np.cumsum([0, 1, H * A, (H + 1) * D, (H + 1) * D * D, H + 1, H + 1])]
+        shapes = [(1,), (1, H, A), (1, H + 1, D), (1, H + 1, D, D), (1, H + 1), (1, H + 1)]
+        self.fields = [(k, o[i], o[i + 1], shapes[i]) for i, k in enumerate(("J", "grad", "mu", "Sig", "cost_mu", "cost_var"))]
+        self.addr, self.view = None, None
+
+    def result(self):
+        addr = C.cast(self.res, C.c_void_p).value
+        if addr != self.addr:                  # the library's pinned buffer (moves only when it grows)
+            self.addr, self.view = addr, np.ctypeslib.as_array(self.res, shape=(self.n,))
+        flat = self.view.copy()                # the buffer is reused by the next evaluation
+        return {k: flat[lo:hi].reshape(sh) for k, lo, hi, sh in self.fields}
+
+
 class HipEngine:
     """One handle per GPU (gpmpc_create).  All tensors are fp64 on ``device``."""
 
@@ -32,6 +54,7 @@ class HipEngine:
         if rc != L.GPMPC_OK:
             raise L.GpmpcError(rc, "gpmpc_create failed")
         self._h = h
+        self._ogh_plans = {}
         self.N = self.D = self.E = 0
         self._cost = None
 
@@ -222,20 +245,18 @@ class HipEngine:
         (gpmpc_objective_grad_host: the sequence travels as a kernel argument, the results through a pinned host buffer,
         one synchronisation) -- what a host-side optimiser that evaluates one sequence per call needs (the reference's
         scipy L-BFGS-B loop, gp_mpc_controller.py:133-141).  Returns numpy arrays (copies: the buffer is reused)."""
-        actions = _host(actions)
+        actions = np.asarray(actions, dtype=np.float64)
         H, A = actions.shape
-        D = self.D
-        mu0 = _host(mu0, (D,))
-        S0 = _host(S0, (D, D))
-        res = C.POINTER(C.c_double)()
-        self._check(self.lib.gpmpc_objective_grad_host(self._h, _hp(actions), _hp(mu0), _hp(S0), H, A, int(bool(include_time)),
-                                                       float(time0), C.byref(res), self._stream()))
-        n = 1 + H * A + (H + 1) * (D + D * D + 2)
-        flat = np.ctypeslib.as_array(res, shape=(n,)).copy()
-        o = np.cumsum([0, 1, H * A, (H + 1) * D, (H + 1) * D * D, H + 1, H + 1])
-        return {"J": flat[o[0]:o[1]], "grad": flat[o[1]:o[2]].reshape(1, H, A), "mu": flat[o[2]:o[3]].reshape(1, H + 1, D),
-                "Sig": flat[o[3]:o[4]].reshape(1, H + 1, D, D), "cost_mu": flat[o[4]:o[5]].reshape(1, H + 1),
-                "cost_var": flat[o[5]:o[6]].reshape(1, H + 1)}
+        plan = self._ogh_plans.get((H, A))
+        if plan is None:
+            plan = self._ogh_plans[(H, A)] = _HostEvaluationPlan(H, A, self.D)
+        # (staging arrays with known addresses: taking an array's address through ctypes costs more than copying 25 numbers)
+        np.copyto(plan.actions, actions)
+        np.copyto(plan.mu0, np.asarray(mu0, dtype=np.float64).reshape(plan.mu0.shape))
+        np.copyto(plan.S0, np.asarray(S0, dtype=np.float64).reshape(plan.S0.shape))
+        self._check(self.lib.gpmpc_objective_grad_host(self._h, plan.p_actions, plan.p_mu0, plan.p_S0, H, A, int(bool(include_time)),
+                                                       float(time0), plan.res_ref, self._stream()))
+        return plan.result()
 
     @staticmethod
     def host_views(out):

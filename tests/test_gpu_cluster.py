@@ -168,6 +168,32 @@ def test_gradient_on_the_cooperative_forward_and_the_host_entry(engine):
     assert abs(float(host["J"][0]) - J0) < 1e-8 * abs(J0) and rel_err(host["grad"].reshape(-1), g0.reshape(-1)) < 1e-7
 
 
+@pytest.mark.parametrize("N,D,A,H,tm,path", [(200, 3, 1, 25, False, "cooperative"), (60, 2, 2, 12, True, "one workgroup"),
+                                               (150, 3, 2, 40, False, "sequence beyond the argument block"),
+                                               (3000, 3, 1, 4, False, "streaming forward"), (90, 6, 2, 8, False, "wide state")])
+def test_host_entry_equals_the_device_entry(engine, N, D, A, H, tm, path):
+    """gpmpc_objective_grad_host -- the sequence in the forward kernel's argument block (or its own upload launch where another
+    kernel reads it first / it is too long), results copied to the pinned mirror by the reverse sweep, completion polled by the
+    host -- returns bit for bit what gpmpc_rollout_grad leaves on the device, call after call with changing sequences."""
+    w = synth.make_workload(N, D, A, H, 6, include_time=tm, seed=N + D)
+    _model(engine, w)
+    engine.set_option("cluster", 0)
+    for i in (0, 3, 1, 5, 5, 2):
+        host = engine.objective_grad_host(w.actions[i], w.mu0, w.S0, w.include_time, w.time0)
+        out = engine.rollout_grad(w.actions[i:i + 1], w.mu0, w.S0, w.include_time, w.time0, trajectories=True)
+        for k in ("J", "grad", "mu", "Sig", "cost_mu", "cost_var"):
+            assert np.array_equal(host[k], out[k].cpu().numpy()), (path, i, k)
+        assert np.isfinite(host["grad"]).all() and np.abs(host["grad"]).max() > 0
+    if path == "cooperative":
+        assert engine.last_cluster > 1
+    if path == "streaming forward":
+        assert engine.last_rollout_path == 1
+    # a shorter horizon afterwards (the mirror and the staging arrays are per shape)
+    host = engine.objective_grad_host(w.actions[0][:max(H // 2, 1)], w.mu0, w.S0, w.include_time, w.time0)
+    out = engine.rollout_grad(w.actions[0:1, :max(H // 2, 1)], w.mu0, w.S0, w.include_time, w.time0, trajectories=True)
+    assert np.array_equal(host["grad"], out["grad"].cpu().numpy()) and np.array_equal(host["J"], out["J"].cpu().numpy())
+
+
 def test_many_launches_back_to_back(engine):
     """Exchange buffers and tags over many launches of changing shape (tags never repeat while the buffer lives)."""
     ws = [synth.make_workload(200, 3, 1, 9, 3, seed=2), synth.make_workload(300, 2, 2, 7, 9, seed=5)]
