@@ -158,18 +158,24 @@ __device__ __forceinline__ void pair_moments_body(const GradArgs& p, double* sme
     double* a_rows = smem + L.rows;
     double* s_part = smem + L.part;
 
-    for (int i = tid; i < D; i += NT) c_logvar[i] = p.logvar[i];
-    for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
-    for (int i = tid; i < 64; i += NT) c_tab[i] = kExp2Tab[i];
-    for (int i = tid; i < 2 * E; i += NT) c_xr[i] = p.xrange[i];
-    for (int i = tid; i < E; i += NT) {
-        double v;
-        if (i < D) v = p.mu[((size_t)c * (H + 1) + t) * D + i];
-        else if (i < D + A) v = p.actions[((size_t)c * H + t) * A + (i - D)];
-        else v = p.time0 + (double)t;
-        s_m[i] = v;
+    {
+        // constants and the step's state: one element of every array per thread, all loads in flight together (see rollout_kernel.h;
+        // E <= NT, D * D <= NT)
+        const double* msrc = (tid < D) ? p.mu + ((size_t)c * (H + 1) + t) * D + tid
+                                       : p.actions + ((size_t)c * H + t) * A + ((tid < D + A) ? tid - D : 0);
+        const double* ssrc = p.Sig + ((size_t)c * (H + 1) + t) * D * D + (tid < D * D ? tid : 0);
+        __builtin_amdgcn_sched_barrier(0);
+        const double v0 = p.logvar[tid < D ? tid : 0], v1 = p.ils2[tid < D * E ? tid : 0], v2 = kExp2Tab[tid & 63];
+        const double v3 = p.xrange[tid < 2 * E ? tid : 0], v4 = *msrc, v5 = *ssrc;
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid < D) c_logvar[tid] = v0;
+        if (tid < D * E) c_ils2[tid] = v1;
+        if (tid < 64) c_tab[tid] = v2;
+        if (tid < 2 * E) c_xr[tid] = v3;
+        if (tid < E) s_m[tid] = (tid < D + A) ? v4 : p.time0 + (double)t;
+        if (tid < D * D) s_Sig[tid] = v5;
+        for (int i = tid + NT; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
     }
-    for (int i = tid; i < D * D; i += NT) s_Sig[i] = p.Sig[((size_t)c * (H + 1) + t) * D * D + i];
     for (int i = tid; i < G * (NR - N) * RS; i += NT) {
         const int per = (NR - N) * RS;
         const int gq = i / per, k = i - gq * per;
@@ -814,14 +820,30 @@ __global__ __launch_bounds__(NT) void adjoint_sweep_kernel(const GradArgs p) {
     const double inv_n = 1.0 / (double)(H + 1);
     auto pair_of = [&](int q, int& a, int& b) { decode_tri(q, D, a, b); };
 
-    for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
-    for (int i = tid; i < D; i += NT) c_var[i] = p.var[i];
-    for (int i = tid; i < n + n * n + DD + 2 * D; i += NT) c_cost[i] = p.cost[i];
     double* s_tmu = smem + L.tmu; double* s_tSig = smem + L.tSig; double* s_tact = smem + L.tact; double* s_tcv = smem + L.tcv;
-    for (int i = tid; i < (H + 1) * D; i += NT) s_tmu[i] = traj_mu[i];
-    for (int i = tid; i < (H + 1) * DD; i += NT) s_tSig[i] = traj_Sig[i];
-    for (int i = tid; i < H * A; i += NT) s_tact[i] = act[i];
-    for (int i = tid; i <= H; i += NT) s_tcv[i] = cvv[i];
+    {
+        // constants and the stored trajectory: the first element of every array per thread with all loads in flight together (one
+        // copy loop after the other is one global round trip after the other: seven of them, ~5 k cycles, round 6)
+        const int nc = n + n * n + DD + 2 * D, n_mu = (H + 1) * D, n_Sig = (H + 1) * DD, n_act = H * A, n_cv = H + 1;
+        __builtin_amdgcn_sched_barrier(0);
+        const double v0 = p.ils2[tid < D * E ? tid : 0], v1 = p.var[tid < D ? tid : 0], v2 = p.cost[tid < nc ? tid : 0];
+        const double v3 = traj_mu[tid < n_mu ? tid : 0], v4 = traj_Sig[tid < n_Sig ? tid : 0];
+        const double v5 = act[tid < n_act ? tid : 0], v6 = cvv[tid < n_cv ? tid : 0];
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid < D * E) c_ils2[tid] = v0;
+        if (tid < D) c_var[tid] = v1;
+        if (tid < nc) c_cost[tid] = v2;
+        if (tid < n_mu) s_tmu[tid] = v3;
+        if (tid < n_Sig) s_tSig[tid] = v4;
+        if (tid < n_act) s_tact[tid] = v5;
+        if (tid < n_cv) s_tcv[tid] = v6;
+        for (int i = tid + NT; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
+        for (int i = tid + NT; i < nc; i += NT) c_cost[i] = p.cost[i];
+        for (int i = tid + NT; i < n_mu; i += NT) s_tmu[i] = traj_mu[i];
+        for (int i = tid + NT; i < n_Sig; i += NT) s_tSig[i] = traj_Sig[i];
+        for (int i = tid + NT; i < n_act; i += NT) s_tact[i] = act[i];
+        for (int i = tid + NT; i < n_cv; i += NT) s_tcv[i] = cvv[i];
+    }
     sync_all();
     GPMPC_STRACE(10);
     // cost adjoints of every time step (independent of the sweep): one wavefront per step

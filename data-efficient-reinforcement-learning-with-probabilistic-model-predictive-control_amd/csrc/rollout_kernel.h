@@ -974,27 +974,58 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
     if constexpr (TILED) {
         for (int i = tid; i < D; i += NT) { s_mu[i] = p.mu_out[((size_t)c * (H + 1) + p.t_begin) * D + i]; c_logvar[i] = p.logvar[i]; c_var[i] = p.var[i]; }
         for (int i = tid; i < D * D; i += NT) s_Sig2[i] = p.Sig_out[((size_t)c * (H + 1) + p.t_begin) * D * D + i];
-    } else {
-        for (int i = tid; i < D; i += NT) { s_mu[i] = p.mu0[i]; c_logvar[i] = p.logvar[i]; c_var[i] = p.var[i]; }
-        for (int i = tid; i < D * D; i += NT) s_Sig2[i] = p.S0[i];
     }
-    for (int i = tid; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
-    for (int i = tid; i < 2 * E; i += NT) c_xr[i] = p.xrange[i];
-    if (p.act_inline_n > 0) {            // one sequence from the host: in the argument block; a copy for the gradient's kernels
-        for (int i = tid; i < H * A; i += NT) {
-            const double v = p.act_inline[i < kInlineActs ? i : 0];
-            c_act[i] = v;
-            if (!CL || member == 0) p.act_store[i] = v;
+    {
+        // Read-only tables.  The first element (X^T: the first two) of every table per thread with ALL loads in flight together, no
+        // branch between them (lanes past a table's end read its first element and drop it): the memory counter is in-order, and one
+        // `for (i = tid; ...) lds[i] = table[i]` loop after the other is one global round trip after the other -- ten of them
+        // were most of this phase at few candidates (round 6).
+        const bool inl = p.act_inline_n > 0;
+        const int CMc = CM > 0 ? CM : 0;
+        const double* mw = CMc > 0 ? p.mono_w : p.ils2;
+        const int* me = CMc > 0 ? p.mono_exp : reinterpret_cast<const int*>(p.ils2);
+        const int im = tid < CMc ? tid : 0;
+        const int nX = p.x_in_lds ? E * N : 0;
+        __builtin_amdgcn_sched_barrier(0);
+        const double v_lv = p.logvar[tid < D ? tid : 0], v_var = p.var[tid < D ? tid : 0];
+        const double v_ils = p.ils2[tid < D * E ? tid : 0], v_xr = p.xrange[tid < 2 * E ? tid : 0];
+        const double v_act = act[tid < H * A ? tid : 0];
+        const double v_exp = kExp2Tab[tid & 63];
+        const double v_mw = mw[im];
+        const int e0 = me[im * 4], e1 = me[im * 4 + 1], e2 = me[im * 4 + 2], e3 = me[im * 4 + 3];
+        const double v_x0 = p.Xt[tid < nX ? tid : 0], v_x1 = p.Xt[tid + NT < nX ? tid + NT : 0];
+        [[maybe_unused]] const double v_mu0 = p.mu0[tid < D ? tid : 0], v_S0 = p.S0[tid < D * D ? tid : 0];      // (D * D <= 256 <= NT)
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!TILED) {
+            if (tid < D) s_mu[tid] = v_mu0;
+            if (tid < D * D) s_Sig2[tid] = v_S0;
         }
-    } else {
-        for (int i = tid; i < H * A; i += NT) c_act[i] = act[i];
-    }
-    for (int i = tid; i < 64; i += NT) c_exptab[i] = kExp2Tab[i];
-    if (p.x_in_lds)
-        for (int i = tid; i < E * N; i += NT) smem[L.c_X + i] = p.Xt[i];
-    for (int i = tid; i < CM; i += NT) {
-        c_monow[i] = p.mono_w[i];
-        c_monoe[i] = p.mono_exp[i * 4] | (p.mono_exp[i * 4 + 1] << 8) | (p.mono_exp[i * 4 + 2] << 16) | (p.mono_exp[i * 4 + 3] << 24);
+        if (tid < D) { c_logvar[tid] = v_lv; c_var[tid] = v_var; }
+        if (tid < D * E) c_ils2[tid] = v_ils;
+        if (tid < 2 * E) c_xr[tid] = v_xr;
+        if (tid < 64) c_exptab[tid] = v_exp;
+        if (tid < CMc) { c_monow[tid] = v_mw; c_monoe[tid] = e0 | (e1 << 8) | (e2 << 16) | (e3 << 24); }
+        if (tid < nX) smem[L.c_X + tid] = v_x0;
+        if (tid + NT < nX) smem[L.c_X + tid + NT] = v_x1;
+        if (inl) {            // one sequence from the host: in the argument block; a copy for the gradient's kernels
+            for (int i = tid; i < H * A; i += NT) {
+                const double v = p.act_inline[i < kInlineActs ? i : 0];
+                c_act[i] = v;
+                if (!CL || member == 0) p.act_store[i] = v;
+            }
+        } else {
+            if (tid < H * A) c_act[tid] = v_act;
+            for (int i = tid + NT; i < H * A; i += NT) c_act[i] = act[i];
+        }
+        // (what is left of tables longer than the workgroup)
+        for (int i = tid + NT; i < D; i += NT) { c_logvar[i] = p.logvar[i]; c_var[i] = p.var[i]; }
+        for (int i = tid + NT; i < D * E; i += NT) c_ils2[i] = p.ils2[i];
+        for (int i = tid + NT; i < 2 * E; i += NT) c_xr[i] = p.xrange[i];
+        for (int i = tid + 2 * NT; i < nX; i += NT) smem[L.c_X + i] = p.Xt[i];
+        for (int i = tid + NT; i < CMc; i += NT) {
+            c_monow[i] = p.mono_w[i];
+            c_monoe[i] = p.mono_exp[i * 4] | (p.mono_exp[i * 4 + 1] << 8) | (p.mono_exp[i * 4 + 2] << 16) | (p.mono_exp[i * 4 + 3] << 24);
+        }
     }
     for (int i = tid; i < GL * p.CH * RS; i += NT) {
         const int gq = i / (p.CH * RS), k = i - gq * (p.CH * RS);

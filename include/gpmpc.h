@@ -118,7 +118,8 @@ int gpmpc_last_grad_path(gpmpc_t* h);
 /*
  * gpmpc_objective_grad_host  <->  ONE call of compute_mean_lcb_trajectory (gp_mpc_controller.py:229-285) as scipy's L-BFGS-B
  * makes it (:133-141: one action sequence per evaluation, host arrays in, (float, host gradient) out): gpmpc_rollout_grad for
- * B = 1 with host buffers on both sides and ONE synchronisation of `stream`.  actions_host (H,A).  *result_host: pinned host
+ * B = 1 with host buffers on both sides; returns when the results are in *result_host (the last kernel raises a completion word
+ * the call polls; `stream` itself may still be draining).  actions_host (H,A).  *result_host: pinned host
  * buffer owned by the handle, valid until the next call: J (1) | grad (H,A) | mu (H+1,D) | Sig (H+1,D,D) | cost_mu (H+1) |
  * cost_var (H+1) (trajectory and stage costs: what the reference caches for IterationInformation, :279-283).
  */
