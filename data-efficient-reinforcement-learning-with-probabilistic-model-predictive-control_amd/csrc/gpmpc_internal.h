@@ -28,13 +28,19 @@ constexpr int kWave = 64;
 //   separable pair AND a mean sum runs three trips of the per-point pass where the others run two).
 struct ClusterMap {
     int CS, D, P, P_off, wpp, wtri, koff;
+    int CSd;                            // members that own diagonal items (all of them, or all but the separable pairs' owners)
     unsigned char sepown[8];            // owner of off-diagonal pair o when it is separable (D <= 4: P_off <= 6)
     unsigned char meanown[4];           // owner of the mean sums of output a
-    __host__ __device__ int diag_owner(int ord, int slot) const { return ((ord * wtri + slot) * CS) / (D * wtri); }
+    unsigned char dmem[32];             // the diagonal members in order, and ...
+    unsigned char didx[32];             // ... a member's position among them (255: none)
+    __host__ __device__ int diag_owner(int ord, int slot) const { return dmem[((ord * wtri + slot) * CSd) / (D * wtri)]; }
     __host__ __device__ int off_owner(int ord, int slot) const { return ((slot * koff) / wpp + ord * koff) % CS; }
     __host__ __device__ int sep_owner(int ord) const { return sepown[ord]; }
     __host__ __device__ int mean_owner(int a) const { return meanown[a]; }
-    __host__ __device__ bool diag_needed(int ord, int m) const { return diag_owner(ord, 0) <= m && m <= diag_owner(ord, wtri - 1); }
+    __host__ __device__ bool diag_needed(int ord, int m) const {
+        const int i = didx[m];
+        return i != 255 && ((ord * wtri) * CSd) / (D * wtri) <= i && i <= (((ord + 1) * wtri - 1) * CSd) / (D * wtri);
+    }
     __host__ __device__ bool off_needed(int ord, int m) const {            // owns an element-wise slot, or the separable pair
         if (sep_owner(ord) == m) return true;
         const int mp = ((m - (ord * koff) % CS) % CS + CS) % CS;
@@ -43,8 +49,8 @@ struct ClusterMap {
         return s0 < wpp && (s0 * koff) / wpp == mp;
     }
     int diag_count(int m) const {                                          // element-wise items of the diagonal pairs member m owns
-        const int T = D * wtri;
-        return ((m + 1) * T + CS - 1) / CS - (m * T + CS - 1) / CS;
+        const int i = didx[m], T = D * wtri;
+        return i == 255 ? 0 : ((i + 1) * T + CSd - 1) / CSd - (i * T + CSd - 1) / CSd;
     }
     int slots_needed(int m) const {                                        // pairs member m holds per-point records of
         int n = 0;
@@ -56,15 +62,29 @@ struct ClusterMap {
         CS = cs; D = d; P = d * (d + 1) / 2; P_off = d * (d - 1) / 2; wpp = wpp_; wtri = wtri_ > 0 ? wtri_ : 1;
         koff = P_off > 0 ? CS / P_off : 1;
         if (koff < 1) koff = 1;
+        auto everybody = [&] { CSd = CS; for (int m = 0; m < 32; ++m) { dmem[m] = (unsigned char)(m < CS ? m : 0); didx[m] = (unsigned char)(m < CS ? m : 255); } };
+        everybody();
         bool taken[64] = {false};
+        // Members to spare (two per diagonal pair remain): the separable pairs get owners of their OWN, without diagonal items.
+        // A member's per-point pass then covers two problems (a diagonal pair + a mean sum, or the two sides of its off-diagonal
+        // pair) = one trip of its lanes at N <= ~220 instead of two (round 6, config 2: the three members that owned a separable
+        // pair AND diagonal items had 600-800 per-point items on 448 lanes, and everybody waited for them once per step).
+        const bool dedicated = P_off > 0 && P_off <= 8 && CS - P_off >= 2 * D && koff * P_off <= CS;
         for (int o = 0; o < P_off && o < 8; ++o) {
             int best = (o * koff) % CS;
-            for (int k = 1; k < koff; ++k) {
-                const int m = (o * koff + k) % CS;
-                if (diag_count(m) <= diag_count(best)) best = m;
-            }
+            if (!dedicated)
+                for (int k = 1; k < koff; ++k) {
+                    const int m = (o * koff + k) % CS;
+                    if (diag_count(m) <= diag_count(best)) best = m;
+                }
             sepown[o] = (unsigned char)best;
             taken[best] = true;
+        }
+        if (dedicated) {
+            CSd = 0;
+            for (int m = 0; m < 32; ++m) didx[m] = 255;
+            for (int m = 0; m < CS; ++m)
+                if (!taken[m]) { dmem[CSd] = (unsigned char)m; didx[m] = (unsigned char)CSd; ++CSd; }
         }
         for (int a = 0; a < D && a < 4; ++a) {
             int pick = -1;

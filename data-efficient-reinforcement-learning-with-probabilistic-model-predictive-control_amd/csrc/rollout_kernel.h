@@ -149,9 +149,9 @@ __host__ __device__ inline Layout make_layout(int N, int D, int A, int E, int G,
     // failure flag + spare (ints) [2] | per-wavefront problem lists of the per-point pass
     // | static owner tables (bytes): item slots [G * wpp], separable pairs [G], pairs needed in element-wise form [G], mean sums [16]
     // | this member's items of the step (16-bit codes) [G * wpp + 16] + their number
-    // | LDS slot of each pair's records (ints) [G]
+    // | LDS slot of each pair's records (ints) [G] | element-wise item slots of each pair this member owns (64-bit masks) [G]
     L.cl = o;       o += cluster ? rnd2(G) + rnd2((G + 1) / 2) + 2 + kClusterScratch + rnd2((G * wpp + 2 * G + 16 + 7) / 8) +
-                                   rnd2((G * wpp + 16 + 4 + 3) / 4) + rnd2((G + 1) / 2) : 0;
+                                   rnd2((G * wpp + 16 + 4 + 3) / 4) + rnd2((G + 1) / 2) + rnd2(G) : 0;     // (even: the row records behind are read 16 bytes at a time)
     L.c_ils2 = o;   o += rnd2(D * E);
     L.c_logvar = o; o += rnd2(D);
     L.c_var = o;    o += rnd2(D);
@@ -936,6 +936,9 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
         smem + L.cl + rnd2(G) + rnd2((G + 1) / 2) + 2 + kClusterScratch + rnd2((G * wpp + 2 * G + 16 + 7) / 8));
     [[maybe_unused]] int* s_slot = reinterpret_cast<int*>(smem + L.cl + rnd2(G) + rnd2((G + 1) / 2) + 2 + kClusterScratch +
                                                           rnd2((G * wpp + 2 * G + 16 + 7) / 8) + rnd2((G * wpp + 16 + 4 + 3) / 4));
+    [[maybe_unused]] unsigned long long* s_mymask = reinterpret_cast<unsigned long long*>(     // element-wise slots of pair gq this member owns
+        smem + L.cl + rnd2(G) + rnd2((G + 1) / 2) + 2 + kClusterScratch + rnd2((G * wpp + 2 * G + 16 + 7) / 8) +
+        rnd2((G * wpp + 16 + 4 + 3) / 4) + rnd2((G + 1) / 2));
     const int GL = CL ? p.cl_slots : G;             // LDS slots of per-pair records
 
     [[maybe_unused]] unsigned long long* xbuf_uc = CL ? p.xch_uc + (size_t)c * 4 * p.xch_n : nullptr;    // the same in UNCACHED memory: prologue, and the steps of members on several XCDs
@@ -1121,6 +1124,14 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
             int n = 0;
             for (int gq = 0; gq < P; ++gq) s_slot[gq] = s_elneed[gq] ? n++ : -1;
             if (n > GL) *s_fail = 1;
+        }
+        // the element-wise slots of every pair that are this member's, as a mask (up to 64 slots per pair: the step's own-item
+        // list is then a few bit operations per pair; longer pairs take the list walk)
+        for (int gq = tid >> 6; gq < P; gq += NT / 64) {
+            const int k = tid & 63;
+            const int lim = (s_pa[gq] == s_pb[gq]) ? wtri_c : wpp;
+            const unsigned long long m = __ballot(k < lim && k < wpp && s_own[gq * wpp + (k < wpp ? k : 0)] == member);
+            if (k == 0) s_mymask[gq] = m;
         }
         __syncthreads();
     }
@@ -1408,6 +1419,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
             // mean part (output a), row side of a pair (u, g = Z^T u, ka'), column side of an off-diagonal pair (w, kb');
             // for a diagonal pair the column factor is the row factor.
             const int n_off = *s_noff;
+            [[maybe_unused]] bool cl_list_pending = false;
+            [[maybe_unused]] int cl_ns = 0, cl_cls = 3, cl_code0 = 0;
             if (wave == NW - 1) {
                 // Work-item list of this group (the Taylor degrees / evaluation forms of P1 are visible after the barrier), built
                 // by the lanes of ONE wavefront in parallel: lane l < Gc owns pair l, the next nmean lanes a mean-sum item each
@@ -1416,6 +1429,7 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                 const int wtri = (s_tri[p.RC] + 63) >> 6;
                 const int R = Gc + nmean;
                 int ns = 0, cls = 3, code0 = 0;
+                [[maybe_unused]] unsigned long long mymask = 0;           // cooperative form: this entry's items that are this member's
                 if (lane < Gc) {
                     const int Kr = s_K[lane];
                     const bool sep = (Kr & 64) != 0;
@@ -1429,21 +1443,32 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                     cls = sep ? 1 : 0;
                     code0 = lane * wpp;
                     s_nslot[lane] = ns;
+                    if constexpr (CL) {
+                        if (sep) mymask = (s_sepown[lane] == member) ? (ns >= 64 ? ~0ull : (1ull << ns) - 1ull) : 0ull;
+                        else mymask = s_mymask[lane];
+                    }
                 } else if (lane < R) {
                     ns = 1; cls = 2; code0 = 0xffff - (lane - Gc);
+                    if constexpr (CL) mymask = (s_meanown[lane - Gc] == member) ? 1ull : 0ull;
                 }
-                // start = items of all entries that come before this lane's in (class, lane) order
-                int start = 0, total_items = 0;
-                for (int m = 0; m < R; ++m) {
-                    const int nsm = __builtin_amdgcn_readlane(ns, m);
-                    const int clm = __builtin_amdgcn_readlane(cls, m);
-                    start += (clm < cls || (clm == cls && m < lane)) ? nsm : 0;
-                    total_items += nsm;
-                }
-                for (int k = 0; k < ns; ++k) s_items[start + k] = (unsigned short)(cls == 2 ? code0 : code0 + k);
-                if (lane == 0) *s_nitems = total_items;
-                if constexpr (CL) {
-                    // ... and, beside the per-point pass as well, the items of the list this member owns (lanes test 64 entries at a time)
+                // the full list (class order): start = items of all entries that come before this lane's in (class, lane) order
+                auto build_list = [&] {
+                    int start = 0, total_items = 0;
+                    for (int m = 0; m < R; ++m) {
+                        const int nsm = __builtin_amdgcn_readlane(ns, m);
+                        const int clm = __builtin_amdgcn_readlane(cls, m);
+                        start += (clm < cls || (clm == cls && m < lane)) ? nsm : 0;
+                        total_items += nsm;
+                    }
+                    for (int k = 0; k < ns; ++k) s_items[start + k] = (unsigned short)(cls == 2 ? code0 : code0 + k);
+                    if (lane == 0) *s_nitems = total_items;
+                    return total_items;
+                };
+                if constexpr (!CL) {
+                    (void)build_list();
+                } else if (wpp > 64) {
+                    // (pairs of more than 64 slots: the list first, then this member's items by walking it)
+                    const int total_items = build_list();
                     wave_lds_sync();
                     int cnt = 0;
                     for (int base = 0; base < total_items; base += 64) {
@@ -1455,6 +1480,31 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                         cnt += __popcll(mask);
                     }
                     if (lane == 0) s_mine[0] = (unsigned short)cnt;
+                } else {
+                    // Cooperative form: what P3 needs right behind the barrier is THIS member's items (no queue: the j-th goes to
+                    // wavefront j mod NW; in the list's class order -- the long element-wise items first, then the separable pairs',
+                    // then the mean sums) -- a few bit operations per entry.  The full list
+                    // (read by the gather at the END of P3, and its length) is built behind the barrier, beside the items: built
+                    // here first it made this wavefront the last one at the barrier by ~2 k cycles per step (round 6: 5.6 k of
+                    // this lone wavefront's dependent instructions against 2-4.7 k of the per-point pass).
+                    const int mycnt = __popcll(mymask);
+                    int pre = 0, tot = 0, total_items = 0;
+                    for (int m = 0; m < R; ++m) {
+                        const int cm = __builtin_amdgcn_readlane(mycnt, m);
+                        const int clm = __builtin_amdgcn_readlane(cls, m);
+                        pre += (clm < cls || (clm == cls && m < lane)) ? cm : 0;
+                        tot += cm;
+                        total_items += __builtin_amdgcn_readlane(ns, m);
+                    }
+                    unsigned long long mk = mymask;
+                    for (int i = 0; mk != 0; ++i) {
+                        const int k = __builtin_ctzll(mk);
+                        mk &= mk - 1ull;
+                        s_mine[1 + pre + i] = (unsigned short)(cls == 2 ? code0 : code0 + k);
+                    }
+                    if (lane == 0) { s_mine[0] = (unsigned short)tot; *s_nitems = total_items; }
+                    cl_list_pending = true;
+                    cl_ns = ns; cl_cls = cls; cl_code0 = code0;
                 }
             }
             // The per-point items go to all wavefronts but the last one, which builds the work-item list above beside them (with
@@ -1467,7 +1517,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
             //  the spills of the wider live set): the pass is not bound by the latency of one thread's chain.
             //  profiles/r05c_forward_ab.txt, profiles/r05e_p2_three_chains_*.txt)
             int p2_items = (nmean + Gc + n_off) * N;
-            if constexpr (CL) {
+            [[maybe_unused]] bool cl_nu_first = false;
+            if (CL && (NW < 8 || wave != NW - 1)) {       // (the list-building wavefront of a wide member has no per-point items)
                 // only the problems this member owns items of, compacted per wavefront (lane = problem; 255 = nu alone, when
                 // the mean problem of output 0, which stores nu, is another member's)
                 const int nall = nmean + Gc + n_off;
@@ -1476,10 +1527,14 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                 if (lane < nmean) need = s_meanown[lane] == member;
                 else if (lane < nmean + Gc) need = pair_needed(lane - nmean);
                 else if (lane < nall) need = pair_needed(s_off[lane - nmean - Gc]);
-                else if (lane == nall) { need = s_meanown[0] != member; code = 255; }
+                // (nu = X - m, which the mean problem of output 0 stores, is stored by the member's FIRST problem otherwise -- every
+                //  problem visits all points -- or, for a member without problems, by the problem 255 that does nothing else)
+                const unsigned long long mask0 = __ballot(need);
+                if (lane == nall) { need = s_meanown[0] != member && mask0 == 0; code = 255; }
                 const unsigned long long mask = __ballot(need);
                 if (need) s_needw[wave * 64 + __popcll(mask & ((1ull << lane) - 1ull))] = (unsigned char)code;
                 p2_items = __popcll(mask) * N;
+                cl_nu_first = s_meanown[0] != member && mask0 != 0;
                 wave_lds_sync();
             }
             for (int it = tid; it < p2_items && tid < p2_threads; it += p2_threads) {
@@ -1489,6 +1544,11 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
 #pragma unroll
                 for (int d = 0; d < DP; ++d) nu[d] = (d < D) ? (Xs[d * N + pt] - s_m[d]) : 0.0;
                 if constexpr (CL) {
+                    if (cl_nu_first && prob == 0) {
+#pragma unroll
+                        for (int d = 0; d < DP; ++d)
+                            if (d < D) a_nu[d * N + pt] = nu[d];
+                    }
                     prob = s_needw[wave * 64 + prob];
                     if (prob == 255) {
 #pragma unroll
@@ -1584,6 +1644,24 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
 
             // ---- P3: work queue: pairwise items, moment sums, mean sums, stage cost ----------------
             const int total = *s_nitems;
+            if constexpr (CL) {
+                if (cl_list_pending) {           // the full list, for the gather behind the items (a barrier in between)
+                    const int R = Gc + nmean;
+                    int start = 0;
+                    for (int m = 0; m < R; ++m) {
+                        const int nsm = __builtin_amdgcn_readlane(cl_ns, m);
+                        const int clm = __builtin_amdgcn_readlane(cl_cls, m);
+                        start += (clm < cl_cls || (clm == cl_cls && m < lane)) ? nsm : 0;
+                    }
+                    // entry by entry, a lane per slot (<= 64 slots per entry on this path): a lane per entry walking its slots was
+                    // up to 63 dependent trips
+                    for (int m = 0; m < R; ++m) {
+                        const int nsm = __builtin_amdgcn_readlane(cl_ns, m), sm = __builtin_amdgcn_readlane(start, m);
+                        const int clm = __builtin_amdgcn_readlane(cl_cls, m), c0 = __builtin_amdgcn_readlane(cl_code0, m);
+                        if (lane < nsm) s_items[sm + lane] = (unsigned short)(clm == 2 ? c0 : c0 + lane);
+                    }
+                }
+            }
 #if defined(GPMPC_PROF_ON)
             const long long prof_p3 = __builtin_readcyclecounter();
 #endif
@@ -1803,8 +1881,8 @@ __global__ __launch_bounds__(NT) void rollout_kernel(const RolloutArgs p) {
                 // totals of the separable pairs this member owns (its wavefronts filled the pair's moments), then every value of the
                 // step from whichever member formed it
                 const bool own_sep = __ballot(lane < Gc && (s_K[lane < Gc ? lane : 0] & 64) && s_sepown[lane < Gc ? lane : 0] == member) != 0;
+                __syncthreads();                 // (the moments of the separable pairs this member owns; the list built behind the P2 barrier)
                 if (own_sep) {
-                    __syncthreads();
                     for (int gq = wave; gq < Gc; gq += NW) {
                         const int Kraw = s_K[gq];
                         if (!(Kraw & 64) || s_sepown[gq] != member) continue;
