@@ -286,11 +286,23 @@ int launch_rollout(Handle* h, RolloutArgs& a, hipStream_t s) {
         int tri = 0;             // slots of a diagonal pair's triangle (the kernel's s_tri): the element-wise items that are always there
         for (int r = 0; r < RC; ++r) { const int first = (r * CH) / 2; tri += first < NCu ? NCu - first : 0; }
         const int wtri = (tri + 63) / 64;
-        // ~4 element-wise items per member; below ~24 items the exchange costs what the spread gains (N = 50: 0.122 against 0.127 ms,
-        // N = 100: 0.130 / 0.141, N = 130: equal)
-        int cs = h->opt_cluster >= 2 ? h->opt_cluster : (D * wtri >= 24 ? (D * wtri + 3) / 4 : 1);
-        if (cs > 32) cs = 32;
+        // ~4 element-wise items per member, and at least P_off + 2 D members (9 or more) where the chip has them for every candidate:
+        // the separable pairs then sit on members of their own and nobody's per-point pass has more than two problems.  With that
+        // many members the form pays from D^2 wtri ~ 18 on (one candidate, ms per rollout, cooperative / plain: D = 3: N = 50
+        // 0.128 / 0.128, N = 80 0.129 / 0.151, N = 130 0.133 / 0.179; D = 2: N = 100 0.117 / 0.103, N = 150 equal, N = 200 0.139 / 0.173;
+        // D = 1: N = 200 0.118 / 0.112, N = 400 0.139 / 0.203; D = 4: N = 100 0.184 / 0.334); with fewer members per candidate from
+        // ~24 items on, as before
         const int cap = h->num_cu / (8 * groups8);
+        const int items = D * wtri, P_off = D * (D - 1) / 2;
+        const int cs_floor = (P_off + 2 * D > 9) ? P_off + 2 * D : 9;
+        const bool roomy = cap >= cs_floor;
+        int cs = 1;
+        if (h->opt_cluster >= 2) cs = h->opt_cluster;
+        else if (items >= 24 || (roomy && items * D >= 18)) {
+            cs = (items + 3) / 4;
+            if (roomy && cs < cs_floor) cs = cs_floor;
+        }
+        if (cs > 32) cs = 32;
         if (cs > cap) cs = cap;
         // (the pairs a member holds records of depend on how the cluster size divides the pairs: when the size of the rule does not
         //  fit the LDS, the next smaller ones are tried -- down to half of it; a size asked for by option is taken or not at all)

@@ -107,7 +107,8 @@ def test_members_spread_over_the_xcds_take_the_placement_independent_exchange(en
 
 def test_dispatch_rule(engine):
     """Few candidates of a memory with enough pairwise items take the cooperative form; small memories and large batches do not."""
-    for N, H, B, expect in ((200, 25, 1, True), (200, 25, 16, True), (200, 25, 300, False), (50, 15, 1, False), (500, 10, 2, True)):
+    for N, H, B, expect in ((200, 25, 1, True), (200, 25, 16, True), (200, 25, 300, False), (50, 15, 1, False), (500, 10, 2, True),
+                            (120, 15, 1, True), (120, 15, 40, False)):
         w = synth.make_workload(N, 3 if N != 500 else 2, 1, H, B, seed=1)
         _model(engine, w)
         engine.rollout(w.actions, w.mu0, w.S0)
