@@ -356,7 +356,8 @@ int gpmpc_objective_grad_host(gpmpc_t* g, const double* actions_host, const doub
     // sequence number there; the host polls that word (a stream synchronisation costs ~10 us more than the store takes to arrive)
     // and asks the stream now and then, so that a failed launch ends the wait.
     const unsigned long long seq = ++h->hio_seq;
-    h->hx_out = h->hio_host_dev; h->hx_src = out_dev; h->hx_n = (int)n_out;
+    const bool sweep_exports = D <= 8;               // (the wide-state sweep, 8 < D <= 16, has no export: a synchronisation and a copy)
+    h->hx_out = h->hio_host_dev; h->hx_src = out_dev; h->hx_n = sweep_exports ? (int)n_out : 0;
 #if defined(GPMPC_HOST_TIMING)
     const double T1 = now();
     g_host_timing_fwd = 0.0;
@@ -364,6 +365,12 @@ int gpmpc_objective_grad_host(gpmpc_t* g, const double* actions_host, const doub
     rc = launch_rollout_grad(h, a, grad, s);
     h->hx_n = 0;
     if (rc) return rc;
+    if (!sweep_exports) {
+        GPMPC_HIP_CHECK(h, hipStreamSynchronize(s));
+        GPMPC_HIP_CHECK(h, hipMemcpy(h->hio_host, out_dev, n_out * sizeof(double), hipMemcpyDeviceToHost));
+        *result_host = h->hio_host;
+        return GPMPC_OK;
+    }
 #if defined(GPMPC_HOST_TIMING)
     const double T2 = now();
 #endif

@@ -171,7 +171,8 @@ def test_gradient_on_the_cooperative_forward_and_the_host_entry(engine):
 
 @pytest.mark.parametrize("N,D,A,H,tm,path", [(200, 3, 1, 25, False, "cooperative"), (60, 2, 2, 12, True, "one workgroup"),
                                                (150, 3, 2, 40, False, "sequence beyond the argument block"),
-                                               (3000, 3, 1, 4, False, "streaming forward"), (90, 6, 2, 8, False, "wide state")])
+                                               (3000, 3, 1, 4, False, "streaming forward"), (90, 6, 2, 8, False, "six states"),
+                                               (70, 10, 2, 5, False, "wide-state sweep")])
 def test_host_entry_equals_the_device_entry(engine, N, D, A, H, tm, path):
     """gpmpc_objective_grad_host -- the sequence in the forward kernel's argument block (or its own upload launch where another
     kernel reads it first / it is too long), results copied to the pinned mirror by the reverse sweep, completion polled by the
